@@ -1,0 +1,69 @@
+/* efx_oracle.h -- CPU restatement of the espflix hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This library is the parity checker for the HIP implementation in espflix_amd/csrc.  It is a
+ * plain-C restatement of the reference algorithms, each function citing the reference
+ * file:line it follows.  It is pinned against the real reference (compiled unmodified into
+ * oracle/_ref/ by oracle/Makefile) on the two embedded clips, on synthetic streams, on
+ * composite fields and on PDM words -- see tests/test_oracle_vs_ref.py and tests/golden/.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The
+ * product (espflix_amd/) never links, imports or executes anything in oracle/.
+ */
+#ifndef EFX_ORACLE_H
+#define EFX_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EFXO_FRAME_BYTES 101376           /* 12 strips x 16 rows x 528 B (video.h:30-34) */
+
+enum { EFXO_FMT_ES = 0, EFXO_FMT_TS = 1 };
+
+/* Decode a whole elementary stream (EFXO_FMT_ES) or transport stream (EFXO_FMT_TS) exactly as
+ * MpegDecoder::run() would (player.cpp:1355-1367) and record every frame handed to
+ * push_video() (player.cpp:692-702).
+ *   flush_last  != 0: also push the final picture (flush_picture(1), as load_poster does,
+ *                     espflix.cpp:1068).
+ *   frames_out  NULL or room for max_frames x EFXO_FRAME_BYTES
+ *   pts_out     NULL or max_frames int64 (pts handed to push_video)
+ *   hash_out    NULL or max_frames uint64 (FNV-1a-64 of the 101376 frame bytes)
+ * In ES mode there is no PES layer, so picture i is given pts = i (a pts is "seen" before the
+ * first picture, i.e. every picture start pushes/swaps).
+ * Returns the number of frames pushed (may exceed max_frames; extra frames are only counted),
+ * or a negative number on argument error. */
+long efxo_decode(const uint8_t* data, size_t len, int format, int flush_last,
+                 uint8_t* frames_out, int64_t* pts_out, uint64_t* hash_out, long max_frames);
+
+/* TS -> video ES (PID 0x100 payloads, PES headers stripped; player.cpp:381-493).  Writes at
+ * most es_cap bytes, returns the ES length.  pic_pts_out/max_pics (optional) receive the PES
+ * pts latched by flush_picture for each picture start code in order of appearance. */
+size_t efxo_ts_to_es(const uint8_t* ts, size_t len, uint8_t* es_out, size_t es_cap);
+
+/* FNV-1a-64 (offset basis cbf29ce484222325, prime 100000001b3). */
+uint64_t efxo_fnv1a64(const uint8_t* p, size_t n, uint64_t h);
+
+/* Composite video: restatement of video_init + video_isr (video.cpp:572-630,1122-1198).
+ * frames2 = Frame[0] then Frame[1] (2 x EFXO_FRAME_BYTES), front frame = 0, overlay off, no
+ * h-scroll.  Produces nfields fields starting with _frame_counter = frame_counter0, each
+ * line_count x line_width u16.  Returns samples written per field, or <0. */
+long efxo_video_field(const uint8_t* frames2, int ntsc, int frame_counter0, int nfields, uint16_t* out);
+/* geometry: {line_width,line_count,hsync,hsync_long,hsync_short,burst_start,burst_width,active_start} */
+void efxo_video_params(int ntsc, int32_t out8[8]);
+/* the 768-entry colour LUT video_init leaves in _color_tab (video.cpp:584-591) */
+void efxo_color_tab(int ntsc, uint32_t out768[768]);
+
+/* zig-zag scan and IDCT pre-multiplier tables as the restatement derives them */
+void efxo_tables(uint8_t zz_out[64], uint8_t premul_out[64]);
+
+/* PDM: restatement of pdm_second_order (espflix.ino:73-107).  state = {_i0,_i1,_i2}. */
+void efxo_pdm_second_order(int32_t state[3], uint16_t* dst, const int16_t* src, int len);
+/* write_pcm_16 (espflix.ino:123-145): s==NULL -> 256 x 0xAAAA; *beep>0 -> sine burst. */
+void efxo_write_pcm_16(int32_t state[3], int* beep, const int16_t* s, int n, uint16_t out256[256]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,83 @@
+// oracle/_ref video-out harness  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Links against the *unmodified* reference src/video.cpp (force-included oracle/ref_shim.h),
+// player.cpp (for Frame), streamer.cpp and sbc_decoder.cpp, and drives the per-scan-line
+// callback video_isr() (reference src/video.cpp:1122-1198) the way the I2S DMA interrupt does
+// (src/video.cpp:51-56,172-188): once per line, over TWO alternating zero-initialised line
+// buffers.  The displayed frame is published through the reference's own file-scope globals
+// _frames/_current_frame (src/video.cpp:938,943).
+//
+// Usage:
+//   efx_ref_video field <frames.bin> <ntsc:1|0> <nfields> <out.bin>
+//        frames.bin = 2 x 101376 bytes (Frame[0], Frame[1] in strip order); front = 0.
+//        Output: nfields x line_count x line_width little-endian u16 samples.
+//        _frame_counter starts at 0 and is advanced by the ISR itself (dither parity).
+//   efx_ref_video params <ntsc:1|0> <out.bin>
+//        dumps int32 {line_width,line_count,hsync,hsync_long,hsync_short,burst_start,
+//        burst_width,active_start} followed by _color_tab[768] (u32) and dither4x4[8] (u32).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "video.h"      // reference header
+#include "streamer.h"
+#undef printf
+
+extern "C" void video_isr(volatile void* buf);
+extern Frame* _frames;
+extern int8_t _current_frame;
+extern volatile int _line_counter, _frame_counter;
+extern int _line_width, _line_count, _hsync, _hsync_long, _hsync_short, _burst_start, _burst_width, _active_start;
+extern uint32_t _color_tab[256 * 3];
+extern uint32_t dither4x4[];
+
+std::string to_string(int i) { return std::to_string(i); }
+void video_init_hw(int, int) {}
+void ir_sample() {}
+void write_pcm_16(const int16_t*, int, int) {}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) return 2;
+    std::string cmd = argv[1];
+    if (!freopen("/dev/null", "w", stdout)) {}
+    if (cmd == "params" && argc == 4) {
+        video_init(atoi(argv[2]));
+        int32_t p[8] = { _line_width, _line_count, _hsync, _hsync_long, _hsync_short, _burst_start, _burst_width, _active_start };
+        FILE* f = fopen(argv[3], "wb");
+        fwrite(p, 4, 8, f);
+        fwrite(_color_tab, 4, 768, f);
+        fwrite(dither4x4, 4, 8, f);
+        fclose(f);
+        return 0;
+    }
+    if (cmd == "field" && argc == 6) {
+        static Frame fb[2];
+        fb[0].init();
+        fb[1].init();
+        FILE* f = fopen(argv[2], "rb");
+        if (!f) return 2;
+        for (int k = 0; k < 2; k++)
+            for (int s = 0; s < FB_SLICES; s++)
+                if (fread(fb[k]._slices[s], 1, FB_STRIDE * FB_SLICE_HEIGHT, f) != FB_STRIDE * FB_SLICE_HEIGHT) return 2;
+        fclose(f);
+        video_init(atoi(argv[3]));
+        int nfields = atoi(argv[4]);
+        _frames = fb;
+        _current_frame = 0;
+        std::vector<uint16_t> a(_line_width, 0), b(_line_width, 0);
+        FILE* o = fopen(argv[5], "wb");
+        for (int fld = 0; fld < nfields; fld++)
+            for (int l = 0; l < _line_count; l++) {
+                uint16_t* buf = (l & 1) ? &b[0] : &a[0];   // two DMA descriptors ping-pong (src/video.cpp:171-186)
+                video_isr(buf);
+                fwrite(buf, 2, _line_width, o);
+            }
+        fclose(o);
+        return 0;
+    }
+    return 2;
+}
