@@ -1,0 +1,294 @@
+"""espflix_amd -- Python host binding (ctypes) for libefx, the MI355X-native espflix hot path.
+
+This package is a thin mirror of the C-ABI in include/efx.h (which in turn stands in for the
+reference's MpegDecoder / Frame / push_video / video_isr / write_pcm_16 surface, reference
+src/player.h:34-165, src/video.h:36-50, src/video.cpp:1122, espflix.ino:123).  All work happens
+in hand-written HIP kernels inside espflix_amd/libefx.so; there is NO CPU fallback: importing
+works anywhere, but creating a Decoder without the built library or without a gfx950 device
+raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+FRAME_WIDTH = 352
+FRAME_HEIGHT = 192
+FRAME_STRIDE = 528
+STRIP_ROWS = 16
+STRIPS = 12
+STRIP_BYTES = 8448
+FRAME_BYTES = 101376
+
+FORMAT_ES = 0
+FORMAT_TS = 1
+
+STREAM_BAD_SIZE = 1
+STREAM_TRUNCATED = 2
+STREAM_TOO_MANY_UNITS = 4
+STREAM_BAD_VLC = 8
+STREAM_MB_OVERRUN = 16
+STREAM_COEF_OVERRUN = 32
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libefx.so")
+
+
+class EfxError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libefx status {status}: {message}")
+        self.status = status
+
+
+class _Config(C.Structure):
+    _fields_ = [
+        ("device", C.c_int),
+        ("max_streams", C.c_int),
+        ("max_pictures", C.c_int),
+        ("ring_depth", C.c_int),
+        ("max_stream_bytes", C.c_size_t),
+        ("hip_stream", C.c_void_p),
+    ]
+
+
+class _VideoParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("line_width", "line_count", "hsync", "hsync_long", "hsync_short",
+                                       "burst_start", "burst_width", "active_start")]
+
+
+class _Timing(C.Structure):
+    _fields_ = [("index_ms", C.c_float), ("parse_ms", C.c_float), ("recon_ms", C.c_float), ("total_ms", C.c_float),
+                ("pictures", C.c_uint64), ("slices", C.c_uint64), ("coefficients", C.c_uint64), ("es_bytes", C.c_uint64)]
+
+
+# every symbol include/efx.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_SYMBOLS = {
+    "efx_create": (C.c_int, [C.POINTER(_Config), C.POINTER(_P)]),
+    "efx_destroy": (None, [_P]),
+    "efx_last_error": (C.c_char_p, [_P]),
+    "efx_status_string": (C.c_char_p, [C.c_int]),
+    "efx_upload_streams": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t), C.c_int]),
+    "efx_reset": (C.c_int, [_P]),
+    "efx_erase_frames": (C.c_int, [_P]),
+    "efx_decode": (C.c_int, [_P]),
+    "efx_sync": (C.c_int, [_P]),
+    "efx_picture_count": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
+    "efx_stream_status": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32)]),
+    "efx_picture_pts": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "efx_picture_slot": (C.c_int, [_P, C.c_int]),
+    "efx_frame_device_ptr": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "efx_download_frame": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "efx_frame_hashes": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "efx_upload_frame": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "efx_video_get_params": (C.c_int, [C.c_int, C.POINTER(_VideoParams)]),
+    "efx_composite_fields": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "efx_pdm": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
+    "efx_set_timing": (C.c_int, [_P, C.c_int]),
+    "efx_get_timing": (C.c_int, [_P, C.POINTER(_Timing)]),
+    "efx_device_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "efx_device_free": (C.c_int, [_P, _P]),
+    "efx_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "efx_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+}
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load libefx.so and bind every entry point; raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make lib` (or __graft_entry__.build()); "
+                          "espflix_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the C-ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def video_params(ntsc: bool) -> dict:
+    """Geometry video_init(ntsc) establishes (reference src/video.cpp:572-630)."""
+    p = _VideoParams()
+    _check(None, load_library().efx_video_get_params(1 if ntsc else 0, C.byref(p)))
+    return {n: getattr(p, n) for n, _ in _VideoParams._fields_}
+
+
+def _check(ctx, status: int):
+    if status != 0:
+        lib = load_library()
+        msg = lib.efx_status_string(status).decode()
+        if ctx:
+            detail = lib.efx_last_error(ctx).decode()
+            if detail:
+                msg += f" ({detail})"
+        raise EfxError(status, msg)
+
+
+@dataclass
+class Timing:
+    index_ms: float
+    parse_ms: float
+    recon_ms: float
+    total_ms: float
+    pictures: int
+    slices: int
+    coefficients: int
+    es_bytes: int
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned by a Decoder context."""
+
+    def __init__(self, dec: "Decoder", nbytes: int):
+        self._dec = dec
+        self.nbytes = nbytes
+        p = _P()
+        _check(dec._ctx, dec._lib.efx_device_alloc(dec._ctx, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes
+        _check(self._dec._ctx, self._dec._lib.efx_memcpy_h2d(self._dec._ctx, self.ptr, a.ctypes.data, a.nbytes))
+
+    def download(self, dtype, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        _check(self._dec._ctx, self._dec._lib.efx_memcpy_d2h(self._dec._ctx, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self._dec._lib.efx_device_free(self._dec._ctx, self.ptr)
+            self.ptr = None
+
+
+class Decoder:
+    """Batched MpegDecoder: `max_streams` independent streams, `max_pictures` pictures per decode.
+
+    ring_depth = 2 reproduces the reference's two frame buffers (_fb[2], src/player.h:37-40);
+    ring_depth = max_pictures + 1 keeps every decoded picture resident.
+    """
+
+    def __init__(self, max_streams: int, max_pictures: int, ring_depth: int = 2, device: int = 0,
+                 max_stream_bytes: int = 0, hip_stream: int = 0):
+        self._lib = load_library()
+        self._ctx = _P()
+        cfg = _Config(device, max_streams, max_pictures, ring_depth, max_stream_bytes, hip_stream or None)
+        _check(None, self._lib.efx_create(C.byref(cfg), C.byref(self._ctx)))
+        self.max_streams, self.max_pictures, self.ring_depth = max_streams, max_pictures, max(2, ring_depth)
+        self.n_streams = 0
+
+    def close(self):
+        if self._ctx:
+            self._lib.efx_destroy(self._ctx)
+            self._ctx = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- bitstream in ---------------------------------------------------------------------
+    def upload(self, streams, fmt: int = FORMAT_ES):
+        """streams: sequence of bytes / uint8 arrays (one per stream)."""
+        arrs = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray, memoryview))
+                else np.ascontiguousarray(s, dtype=np.uint8) for s in streams]
+        n = len(arrs)
+        ptrs = (_P * n)(*[a.ctypes.data for a in arrs])
+        lens = (C.c_size_t * n)(*[a.size for a in arrs])
+        _check(self._ctx, self._lib.efx_upload_streams(self._ctx, n, ptrs, lens, fmt))
+        self.n_streams = n
+
+    def reset(self):
+        _check(self._ctx, self._lib.efx_reset(self._ctx))
+
+    def erase_frames(self):
+        _check(self._ctx, self._lib.efx_erase_frames(self._ctx))
+
+    # -- decode ---------------------------------------------------------------------------
+    def decode(self, sync: bool = True):
+        _check(self._ctx, self._lib.efx_decode(self._ctx))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        _check(self._ctx, self._lib.efx_sync(self._ctx))
+
+    def picture_count(self, stream: int) -> int:
+        n = C.c_int()
+        _check(self._ctx, self._lib.efx_picture_count(self._ctx, stream, C.byref(n)))
+        return n.value
+
+    def stream_status(self, stream: int) -> int:
+        b = C.c_uint32()
+        _check(self._ctx, self._lib.efx_stream_status(self._ctx, stream, C.byref(b)))
+        return b.value
+
+    def picture_pts(self, stream: int, picture: int) -> int:
+        p = C.c_int64()
+        _check(self._ctx, self._lib.efx_picture_pts(self._ctx, stream, picture, C.byref(p)))
+        return p.value
+
+    def picture_slot(self, picture: int) -> int:
+        return self._lib.efx_picture_slot(self._ctx, picture)
+
+    # -- frames out -----------------------------------------------------------------------
+    def frame_ptr(self, stream: int, slot: int) -> int:
+        p = _P()
+        _check(self._ctx, self._lib.efx_frame_device_ptr(self._ctx, stream, slot, C.byref(p)))
+        return p.value
+
+    def download_frame(self, stream: int, slot: int) -> np.ndarray:
+        out = np.empty(FRAME_BYTES, dtype=np.uint8)
+        _check(self._ctx, self._lib.efx_download_frame(self._ctx, stream, slot, out.ctypes.data))
+        return out
+
+    def download_picture(self, stream: int, picture: int) -> np.ndarray:
+        return self.download_frame(stream, self.picture_slot(picture))
+
+    def upload_frame(self, stream: int, slot: int, frame: np.ndarray):
+        f = np.ascontiguousarray(frame, dtype=np.uint8)
+        assert f.size == FRAME_BYTES
+        _check(self._ctx, self._lib.efx_upload_frame(self._ctx, stream, slot, f.ctypes.data))
+
+    def frame_hashes(self, first_stream: int = 0, n: int | None = None) -> np.ndarray:
+        """FNV-1a-64 of every ring frame, shape (n, ring_depth), computed on the device."""
+        n = self.n_streams - first_stream if n is None else n
+        out = np.empty((n, self.ring_depth), dtype=np.uint64)
+        _check(self._ctx, self._lib.efx_frame_hashes(self._ctx, first_stream, n, out.ctypes.data))
+        return out
+
+    # -- video / audio out ----------------------------------------------------------------
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def composite_fields(self, dst: DeviceBuffer | int, first_stream: int, n_streams: int, slot: int, ntsc: bool,
+                         frame_counter: int):
+        ptr = dst.ptr if isinstance(dst, DeviceBuffer) else dst
+        _check(self._ctx, self._lib.efx_composite_fields(self._ctx, first_stream, n_streams, slot, 1 if ntsc else 0,
+                                                         frame_counter, ptr))
+
+    def pdm(self, n_streams: int, pcm: DeviceBuffer | int, n_samples: int, state: DeviceBuffer | int,
+            dst: DeviceBuffer | int):
+        g = lambda b: b.ptr if isinstance(b, DeviceBuffer) else b
+        _check(self._ctx, self._lib.efx_pdm(self._ctx, n_streams, g(pcm), n_samples, g(state), g(dst)))
+
+    # -- measurement ----------------------------------------------------------------------
+    def set_timing(self, enable: bool):
+        _check(self._ctx, self._lib.efx_set_timing(self._ctx, 1 if enable else 0))
+
+    def timing(self) -> Timing:
+        t = _Timing()
+        _check(self._ctx, self._lib.efx_get_timing(self._ctx, C.byref(t)))
+        return Timing(t.index_ms, t.parse_ms, t.recon_ms, t.total_ms, t.pictures, t.slices, t.coefficients, t.es_bytes)

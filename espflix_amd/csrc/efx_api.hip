@@ -1,0 +1,598 @@
+// efx_api.hip -- the C-ABI of libefx (include/efx.h): context, uploads, kernel launches.
+//
+// Host orchestration only; all arithmetic of the hot path lives in the k_*.hip kernels.  There
+// is no CPU fallback anywhere: without a gfx950 device efx_create fails with
+// EFX_ERR_NO_DEVICE / EFX_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "efx.h"
+#include "efx_internal.h"
+
+namespace efx {
+// kernels (k_index.hip, k_parse.hip, k_recon.hip, k_video.hip)
+__global__ void k_index(const uint8_t*, const uint64_t*, int, PicInfo*, SliceTmp*, uint32_t*, uint32_t*, uint32_t*,
+                        const uint32_t*);
+__global__ void k_slice_scan(const PicInfo*, const uint32_t*, int, int, uint32_t*, DecodeCounters*);
+__global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, const uint64_t*, const uint32_t*, int, int,
+                             SliceDesc*);
+__global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const ParseTables*, const uint32_t*, MbRec*,
+                        uint32_t*, uint32_t*, int, int);
+__global__ void k_recon(const MbRec*, const uint32_t*, uint8_t*, const uint32_t*, int, int, int, int, int);
+__global__ void k_frame_hash(const uint8_t*, int, uint64_t*);
+__global__ void k_fill(uint32_t*, uint32_t, size_t);
+__global__ void k_composite(const uint8_t*, int, int, int, const VideoTables*, int, uint16_t*);
+__global__ void k_pdm(const int16_t*, int, int, int32_t*, uint16_t*);
+}  // namespace efx
+
+using namespace efx;
+
+struct efx_ctx {
+    efx_config cfg{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // capacities
+    size_t es_cap = 0;  // bytes of ES buffer (including tails and guard)
+    int n_streams = 0;  // streams in the current upload
+    size_t es_used = 0;
+    bool uploaded = false, decoded = false, results_valid = false;
+    int epoch = 0;
+
+    // device buffers
+    uint8_t* d_es = nullptr;
+    uint64_t* d_stream_off = nullptr;
+    PicInfo* d_pics = nullptr;
+    SliceTmp* d_slices_tmp = nullptr;
+    uint32_t* d_pic_count = nullptr;
+    uint32_t* d_status = nullptr;
+    uint32_t* d_qtab = nullptr;
+    ParseTables* d_tables = nullptr;
+    uint32_t* d_slice_base = nullptr;
+    DecodeCounters* d_counters = nullptr;
+    SliceDesc* d_descs = nullptr;
+    MbRec* d_mbrecs = nullptr;
+    uint32_t* d_coefs = nullptr;
+    uint8_t* d_frames = nullptr;
+    VideoTables* d_video[2] = {nullptr, nullptr};  // [0] PAL, [1] NTSC
+    uint64_t* d_hash = nullptr;
+
+    // host staging / results
+    uint8_t* h_es = nullptr;  // pinned
+    std::vector<uint64_t> h_stream_off;
+    std::vector<std::vector<int64_t>> pts;  // per stream, per picture (TS input)
+    std::vector<uint32_t> h_pic_count, h_status;
+    DecodeCounters h_counters{};
+
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    efx_timing last_timing{};
+};
+
+namespace {
+
+int fail(efx_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define EFX_HIP(call)                                              \
+    do {                                                           \
+        hipError_t e_ = (call);                                    \
+        if (e_ != hipSuccess)                                      \
+            return fail(ctx, EFX_ERR_DEVICE, #call, e_);           \
+    } while (0)
+
+template <typename T>
+hipError_t dalloc(T** p, size_t n)
+{
+    return hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
+}
+
+// TS -> ES on the host: PID 0x100 payloads with the PES header skipped at the reference's fixed
+// offsets (MpegDecoder::more/demux, player.cpp:381-436,459-493).  pes_pts receives (ES offset of
+// the first payload byte, pts) for every PES that carries a PTS.
+void demux_ts(const uint8_t* ts, size_t len, std::vector<uint8_t>& es, std::vector<std::pair<size_t, int64_t>>& pes_pts)
+{
+    for (size_t pos = 0; pos + 188 <= len; pos += 188) {
+        const uint8_t* p = ts + pos;
+        if (p[0] != 0x47) {
+            es.push_back(0);  // "ts lost sync": the reference hands the bit reader a zero byte
+            continue;
+        }
+        int pid = ((p[1] << 8) + p[2]) & 0x1fff;
+        const uint8_t* pay = p + 4;
+        if (p[3] & 0x20)
+            pay = p + 5 + p[4];
+        if (!(p[3] & 0x10))
+            continue;
+        const uint8_t* end = p + 188;
+        int64_t pts = -1;
+        if (p[1] & 0x40) {
+            if (pay + 9 > end)
+                continue;
+            const uint8_t* q = pay + 6;
+            int flags = (q[0] << 8) | q[1];
+            pay = q + 3 + q[2];
+            q += 3;
+            if ((flags & 0x0080) && q + 5 <= end && (q[0] & 0xF0) == ((flags >> 2) & 0x30)) {
+                pts = ((int64_t)(q[0] & 0x0E)) << 29;
+                pts += (int64_t)((((q[1] << 8) | q[2]) >> 1) << 15);
+                pts += (((q[3] << 8) | q[4]) >> 1);
+            }
+        }
+        if (pid != 0x100)
+            continue;
+        if (pts != -1)
+            pes_pts.emplace_back(es.size(), pts);
+        if (pay < end)
+            es.insert(es.end(), pay, end);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* efx_status_string(int status)
+{
+    switch (status) {
+    case EFX_OK: return "ok";
+    case EFX_ERR_ARG: return "invalid argument";
+    case EFX_ERR_DEVICE: return "HIP runtime error";
+    case EFX_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case EFX_ERR_CAPACITY: return "context capacity exceeded";
+    case EFX_ERR_STATE: return "call out of order";
+    case EFX_ERR_STREAM: return "stream violates a decoder constraint";
+    default: return "unknown status";
+    }
+}
+
+const char* efx_last_error(const efx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int efx_create(const efx_config* cfg, efx_ctx** out)
+{
+    if (!cfg || !out || cfg->max_streams <= 0 || cfg->max_pictures <= 0 || cfg->max_pictures > 255)
+        return EFX_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+        return EFX_ERR_NO_DEVICE;
+    efx_ctx* ctx = new efx_ctx;
+    ctx->cfg = *cfg;
+    if (ctx->cfg.ring_depth < 2)
+        ctx->cfg.ring_depth = 2;
+    if (ctx->cfg.max_stream_bytes == 0)
+        ctx->cfg.max_stream_bytes = (size_t)16384 * cfg->max_pictures * cfg->max_streams;
+    auto bail = [&](int code) {
+        efx_destroy(ctx);
+        return code;
+    };
+    if (hipSetDevice(cfg->device) != hipSuccess)
+        return bail(EFX_ERR_NO_DEVICE);
+    if (cfg->hip_stream)
+        ctx->stream = (hipStream_t)cfg->hip_stream;
+    else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+            return bail(EFX_ERR_DEVICE);
+        ctx->own_stream = true;
+    }
+    const size_t n = (size_t)cfg->max_streams, P = (size_t)cfg->max_pictures, D = (size_t)ctx->cfg.ring_depth;
+    ctx->es_cap = ctx->cfg.max_stream_bytes + n * (kEsTailBytes + 32) + kEsGuardBytes;
+    ctx->es_cap = (ctx->es_cap + 255) & ~(size_t)255;
+    if (ctx->es_cap * kCoefsPerEsByte >= 0xFFFFFFFFull)
+        return bail(EFX_ERR_CAPACITY);  // coefficient indices are 32-bit
+    hipError_t e = hipSuccess;
+    auto A = [&](hipError_t r) {
+        if (e == hipSuccess)
+            e = r;
+    };
+    A(dalloc(&ctx->d_es, ctx->es_cap));
+    A(dalloc(&ctx->d_stream_off, n + 1));
+    A(dalloc(&ctx->d_pics, n * P));
+    A(dalloc(&ctx->d_slices_tmp, n * P * kMaxSlicesPerPicture));
+    A(dalloc(&ctx->d_pic_count, n));
+    A(dalloc(&ctx->d_status, n));
+    A(dalloc(&ctx->d_qtab, n * P * 64));
+    A(dalloc(&ctx->d_tables, 1));
+    A(dalloc(&ctx->d_slice_base, n * P + 1));
+    A(dalloc(&ctx->d_counters, 1));
+    A(dalloc(&ctx->d_descs, n * P * kMaxSlicesPerPicture));
+    A(dalloc(&ctx->d_mbrecs, n * P * kMbCount));
+    A(dalloc(&ctx->d_coefs, ctx->es_cap * kCoefsPerEsByte));
+    A(dalloc(&ctx->d_frames, n * D * kFrameBytes));
+    A(dalloc(&ctx->d_video[0], 1));
+    A(dalloc(&ctx->d_video[1], 1));
+    A(dalloc(&ctx->d_hash, n * D));
+    A(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_es), ctx->es_cap, hipHostMallocDefault));
+    if (e != hipSuccess) {
+        fprintf(stderr, "efx_create: %s\n", hipGetErrorString(e));
+        return bail(EFX_ERR_DEVICE);
+    }
+    ParseTables* pt = new ParseTables;
+    build_parse_tables(pt);
+    A(hipMemcpy(ctx->d_tables, pt, sizeof(ParseTables), hipMemcpyHostToDevice));
+    delete pt;
+    for (int ntsc = 0; ntsc < 2; ntsc++) {
+        VideoTables vt;
+        build_video_tables(ntsc, &vt);
+        A(hipMemcpy(ctx->d_video[ntsc], &vt, sizeof(vt), hipMemcpyHostToDevice));
+    }
+    A(hipMemset(ctx->d_frames, 0, n * D * kFrameBytes));
+    A(hipMemset(ctx->d_mbrecs, 0, n * P * kMbCount * sizeof(MbRec)));
+    A(hipMemset(ctx->d_es, 0, ctx->es_cap));
+    for (auto& ev : ctx->ev)
+        A(hipEventCreate(&ev));
+    if (e != hipSuccess)
+        return bail(EFX_ERR_DEVICE);
+    *out = ctx;
+    return EFX_OK;
+}
+
+void efx_destroy(efx_ctx* ctx)
+{
+    if (!ctx)
+        return;
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    void* bufs[] = {ctx->d_es,         ctx->d_stream_off, ctx->d_pics,     ctx->d_slices_tmp, ctx->d_pic_count, ctx->d_status,
+                    ctx->d_qtab,       ctx->d_tables,     ctx->d_slice_base, ctx->d_counters, ctx->d_descs,     ctx->d_mbrecs,
+                    ctx->d_coefs,      ctx->d_frames,     ctx->d_video[0], ctx->d_video[1],   ctx->d_hash};
+    for (void* b : bufs)
+        if (b)
+            (void)hipFree(b);
+    if (ctx->h_es)
+        (void)hipHostFree(ctx->h_es);
+    for (auto& ev : ctx->ev)
+        if (ev)
+            (void)hipEventDestroy(ev);
+    if (ctx->own_stream && ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, const size_t* len, int format)
+{
+    if (!ctx || !data || !len || n_streams <= 0 || (format != EFX_FORMAT_ES && format != EFX_FORMAT_TS))
+        return fail(ctx, EFX_ERR_ARG, "efx_upload_streams: bad argument");
+    if (n_streams > ctx->cfg.max_streams)
+        return fail(ctx, EFX_ERR_CAPACITY, "efx_upload_streams: more streams than max_streams");
+    EFX_HIP(hipStreamSynchronize(ctx->stream));  // the staging buffer may still be in flight
+    static const uint8_t tail[kEsTailBytes] = {0, 0, 0, 1, 0xB7, 0, 0, 1, 0xB7};
+    ctx->h_stream_off.assign((size_t)n_streams + 1, 0);
+    ctx->pts.assign((size_t)n_streams, {});
+    size_t pos = 0;
+    std::vector<uint8_t> es;
+    std::vector<std::pair<size_t, int64_t>> pes;
+    for (int i = 0; i < n_streams; i++) {
+        const uint8_t* src = data[i];
+        size_t n = len[i];
+        if (!src && n)
+            return fail(ctx, EFX_ERR_ARG, "efx_upload_streams: null stream");
+        if (format == EFX_FORMAT_TS) {
+            es.clear();
+            pes.clear();
+            demux_ts(src, n, es, pes);
+            src = es.data();
+            n = es.size();
+        }
+        size_t padded = (n + kEsTailBytes + 15) & ~(size_t)15;
+        if (pos + padded + kEsGuardBytes > ctx->es_cap)
+            return fail(ctx, EFX_ERR_CAPACITY, "efx_upload_streams: more bytes than max_stream_bytes");
+        ctx->h_stream_off[i] = pos;
+        if (n)
+            memcpy(ctx->h_es + pos, src, n);
+        memcpy(ctx->h_es + pos + n, tail, kEsTailBytes);
+        memset(ctx->h_es + pos + n + kEsTailBytes, 0, padded - n - kEsTailBytes);
+        if (format == EFX_FORMAT_TS) {
+            // PTS latched at each picture start code: the newest PES whose payload began no later
+            // than two bytes past the picture_start_code (the bit reader's look-ahead,
+            // player.cpp:348-352,692-702)
+            size_t k = 0;
+            int64_t cur = -1;
+            const uint8_t* b = ctx->h_es + pos;
+            for (size_t j = 0; j + 3 < n; j++)
+                if (b[j] == 0 && b[j + 1] == 0 && b[j + 2] == 1 && b[j + 3] == 0) {
+                    while (k < pes.size() && pes[k].first <= j + 3 + 2)
+                        cur = pes[k++].second;
+                    ctx->pts[i].push_back(cur);
+                }
+        }
+        pos += padded;
+    }
+    memset(ctx->h_es + pos, 0, kEsGuardBytes);
+    ctx->h_stream_off[n_streams] = pos;
+    ctx->es_used = pos;
+    ctx->n_streams = n_streams;
+    EFX_HIP(hipMemcpyAsync(ctx->d_es, ctx->h_es, pos + kEsGuardBytes, hipMemcpyHostToDevice, ctx->stream));
+    EFX_HIP(hipMemcpyAsync(ctx->d_stream_off, ctx->h_stream_off.data(), ((size_t)n_streams + 1) * sizeof(uint64_t),
+                           hipMemcpyHostToDevice, ctx->stream));
+    EFX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->uploaded = true;
+    ctx->decoded = false;
+    ctx->results_valid = false;
+    return EFX_OK;
+}
+
+int efx_reset(efx_ctx* ctx)
+{
+    if (!ctx)
+        return EFX_ERR_ARG;
+    size_t bytes = (size_t)ctx->cfg.max_streams * ctx->cfg.ring_depth * kFrameBytes;
+    EFX_HIP(hipMemsetAsync(ctx->d_frames, 0, bytes, ctx->stream));
+    return EFX_OK;
+}
+
+int efx_erase_frames(efx_ctx* ctx)
+{
+    if (!ctx)
+        return EFX_ERR_ARG;
+    size_t bytes = (size_t)ctx->cfg.max_streams * ctx->cfg.ring_depth * kFrameBytes;
+    EFX_HIP(hipMemsetAsync(ctx->d_frames, 0x30, bytes, ctx->stream));
+    return EFX_OK;
+}
+
+int efx_decode(efx_ctx* ctx)
+{
+    if (!ctx)
+        return EFX_ERR_ARG;
+    if (!ctx->uploaded)
+        return fail(ctx, EFX_ERR_STATE, "efx_decode: no streams uploaded");
+    const int n = ctx->n_streams, P = ctx->cfg.max_pictures, D = ctx->cfg.ring_depth;
+    hipStream_t st = ctx->stream;
+    // macroblock records carry the epoch that wrote them; recycle the tag space by clearing
+    if (++ctx->epoch > 255) {
+        EFX_HIP(hipMemsetAsync(ctx->d_mbrecs, 0, (size_t)ctx->cfg.max_streams * P * kMbCount * sizeof(MbRec), st));
+        ctx->epoch = 1;
+    }
+    if (ctx->timing)
+        EFX_HIP(hipEventRecord(ctx->ev[0], st));
+    hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, st, ctx->d_es, ctx->d_stream_off, P, ctx->d_pics, ctx->d_slices_tmp,
+                       ctx->d_pic_count, ctx->d_status, ctx->d_qtab, ctx->d_tables->scan);
+    hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, st, ctx->d_pics, ctx->d_pic_count, n, P, ctx->d_slice_base,
+                       ctx->d_counters);
+    hipLaunchKernelGGL(k_slice_emit, dim3((n * P + 255) / 256), dim3(256), 0, st, ctx->d_pics, ctx->d_slices_tmp,
+                       ctx->d_pic_count, ctx->d_stream_off, ctx->d_slice_base, n, P, ctx->d_descs);
+    if (ctx->timing)
+        EFX_HIP(hipEventRecord(ctx->ev[1], st));
+    const int max_slices = n * P * kMaxSlicesPerPicture;
+    hipLaunchKernelGGL(k_parse, dim3((max_slices + 255) / 256), dim3(256), 0, st, ctx->d_es, ctx->d_descs, ctx->d_counters,
+                       ctx->d_tables, ctx->d_qtab, ctx->d_mbrecs, ctx->d_coefs, ctx->d_status, P, ctx->epoch);
+    if (ctx->timing)
+        EFX_HIP(hipEventRecord(ctx->ev[2], st));
+    for (int p = 0; p < P; p++)
+        hipLaunchKernelGGL(k_recon, dim3(n * kMbCount), dim3(64), 0, st, ctx->d_mbrecs, ctx->d_coefs, ctx->d_frames,
+                           ctx->d_pic_count, n, P, D, p, ctx->epoch);
+    if (ctx->timing)
+        EFX_HIP(hipEventRecord(ctx->ev[3], st));
+    EFX_HIP(hipGetLastError());
+    ctx->decoded = true;
+    ctx->results_valid = false;
+    return EFX_OK;
+}
+
+int efx_sync(efx_ctx* ctx)
+{
+    if (!ctx)
+        return EFX_ERR_ARG;
+    EFX_HIP(hipStreamSynchronize(ctx->stream));
+    return EFX_OK;
+}
+
+static int fetch_results(efx_ctx* ctx)
+{
+    if (!ctx->decoded)
+        return fail(ctx, EFX_ERR_STATE, "no decode has run");
+    if (ctx->results_valid)
+        return EFX_OK;
+    EFX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->h_pic_count.resize(ctx->n_streams);
+    ctx->h_status.resize(ctx->n_streams);
+    EFX_HIP(hipMemcpy(ctx->h_pic_count.data(), ctx->d_pic_count, ctx->n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    EFX_HIP(hipMemcpy(ctx->h_status.data(), ctx->d_status, ctx->n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    EFX_HIP(hipMemcpy(&ctx->h_counters, ctx->d_counters, sizeof(DecodeCounters), hipMemcpyDeviceToHost));
+    ctx->results_valid = true;
+    return EFX_OK;
+}
+
+int efx_picture_count(efx_ctx* ctx, int stream, int* n_pictures)
+{
+    if (!ctx || !n_pictures || stream < 0 || stream >= ctx->n_streams)
+        return EFX_ERR_ARG;
+    int r = fetch_results(ctx);
+    if (r)
+        return r;
+    *n_pictures = (int)ctx->h_pic_count[stream];
+    return EFX_OK;
+}
+
+int efx_stream_status(efx_ctx* ctx, int stream, uint32_t* bits)
+{
+    if (!ctx || !bits || stream < 0 || stream >= ctx->n_streams)
+        return EFX_ERR_ARG;
+    int r = fetch_results(ctx);
+    if (r)
+        return r;
+    *bits = ctx->h_status[stream];
+    return EFX_OK;
+}
+
+int efx_picture_pts(efx_ctx* ctx, int stream, int picture, int64_t* pts)
+{
+    if (!ctx || !pts || stream < 0 || stream >= ctx->n_streams || picture < 0)
+        return EFX_ERR_ARG;
+    const auto& v = ctx->pts[stream];
+    *pts = v.empty() ? (int64_t)picture : (picture < (int)v.size() ? v[picture] : -1);
+    return EFX_OK;
+}
+
+int efx_picture_slot(const efx_ctx* ctx, int picture)
+{
+    if (!ctx || picture < 0)
+        return EFX_ERR_ARG;
+    return (picture + 1) % ctx->cfg.ring_depth;
+}
+
+int efx_frame_device_ptr(efx_ctx* ctx, int stream, int slot, void** dptr)
+{
+    if (!ctx || !dptr || stream < 0 || stream >= ctx->cfg.max_streams || slot < 0 || slot >= ctx->cfg.ring_depth)
+        return EFX_ERR_ARG;
+    *dptr = ctx->d_frames + ((size_t)stream * ctx->cfg.ring_depth + slot) * kFrameBytes;
+    return EFX_OK;
+}
+
+int efx_download_frame(efx_ctx* ctx, int stream, int slot, uint8_t* dst)
+{
+    void* p;
+    int r = efx_frame_device_ptr(ctx, stream, slot, &p);
+    if (r || !dst)
+        return r ? r : EFX_ERR_ARG;
+    EFX_HIP(hipStreamSynchronize(ctx->stream));
+    EFX_HIP(hipMemcpy(dst, p, kFrameBytes, hipMemcpyDeviceToHost));
+    return EFX_OK;
+}
+
+int efx_upload_frame(efx_ctx* ctx, int stream, int slot, const uint8_t* src)
+{
+    void* p;
+    int r = efx_frame_device_ptr(ctx, stream, slot, &p);
+    if (r || !src)
+        return r ? r : EFX_ERR_ARG;
+    EFX_HIP(hipStreamSynchronize(ctx->stream));
+    EFX_HIP(hipMemcpy(p, src, kFrameBytes, hipMemcpyHostToDevice));
+    return EFX_OK;
+}
+
+int efx_frame_hashes(efx_ctx* ctx, int first_stream, int n, uint64_t* out)
+{
+    if (!ctx || !out || first_stream < 0 || n <= 0 || first_stream + n > ctx->cfg.max_streams)
+        return EFX_ERR_ARG;
+    const int D = ctx->cfg.ring_depth;
+    const int frames = n * D;
+    hipLaunchKernelGGL(k_frame_hash, dim3((frames + 63) / 64), dim3(64), 0, ctx->stream,
+                       ctx->d_frames + (size_t)first_stream * D * kFrameBytes, frames, ctx->d_hash);
+    EFX_HIP(hipGetLastError());
+    EFX_HIP(hipStreamSynchronize(ctx->stream));
+    EFX_HIP(hipMemcpy(out, ctx->d_hash, (size_t)frames * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return EFX_OK;
+}
+
+int efx_video_get_params(int ntsc, efx_video_params* out)
+{
+    if (!out)
+        return EFX_ERR_ARG;
+    VideoTables vt;
+    build_video_tables(ntsc ? 1 : 0, &vt);
+    out->line_width = vt.line_width;
+    out->line_count = vt.line_count;
+    out->hsync = vt.hsync;
+    out->hsync_long = vt.hsync_long;
+    out->hsync_short = vt.hsync_short;
+    out->burst_start = vt.burst_start;
+    out->burst_width = vt.burst_width;
+    out->active_start = vt.active_start;
+    return EFX_OK;
+}
+
+int efx_composite_fields(efx_ctx* ctx, int first_stream, int n_streams, int slot, int ntsc, int frame_counter,
+                         uint16_t* dst_device)
+{
+    if (!ctx || !dst_device || first_stream < 0 || n_streams <= 0 || first_stream + n_streams > ctx->cfg.max_streams ||
+        slot < 0 || slot >= ctx->cfg.ring_depth)
+        return EFX_ERR_ARG;
+    const int lines = ntsc ? 262 : 312;
+    const int blocks = n_streams * ((lines + 7) / 8);
+    hipLaunchKernelGGL(k_composite, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_frames, first_stream, ctx->cfg.ring_depth,
+                       slot, ctx->d_video[ntsc ? 1 : 0], frame_counter, dst_device);
+    EFX_HIP(hipGetLastError());
+    return EFX_OK;
+}
+
+int efx_pdm(efx_ctx* ctx, int n_streams, const int16_t* pcm_device, int n_samples, int32_t* state_device, uint16_t* dst_device)
+{
+    if (!ctx || !pcm_device || !state_device || !dst_device || n_streams <= 0 || n_samples <= 0)
+        return EFX_ERR_ARG;
+    hipLaunchKernelGGL(k_pdm, dim3((n_streams + 63) / 64), dim3(64), 0, ctx->stream, pcm_device, n_streams, n_samples,
+                       state_device, dst_device);
+    EFX_HIP(hipGetLastError());
+    return EFX_OK;
+}
+
+int efx_set_timing(efx_ctx* ctx, int enable)
+{
+    if (!ctx)
+        return EFX_ERR_ARG;
+    ctx->timing = enable != 0;
+    return EFX_OK;
+}
+
+int efx_get_timing(efx_ctx* ctx, efx_timing* out)
+{
+    if (!ctx || !out)
+        return EFX_ERR_ARG;
+    int r = fetch_results(ctx);
+    if (r)
+        return r;
+    efx_timing t{};
+    if (ctx->timing) {
+        EFX_HIP(hipEventSynchronize(ctx->ev[3]));
+        EFX_HIP(hipEventElapsedTime(&t.index_ms, ctx->ev[0], ctx->ev[1]));
+        EFX_HIP(hipEventElapsedTime(&t.parse_ms, ctx->ev[1], ctx->ev[2]));
+        EFX_HIP(hipEventElapsedTime(&t.recon_ms, ctx->ev[2], ctx->ev[3]));
+        EFX_HIP(hipEventElapsedTime(&t.total_ms, ctx->ev[0], ctx->ev[3]));
+    }
+    for (int i = 0; i < ctx->n_streams; i++)
+        t.pictures += ctx->h_pic_count[i];
+    t.slices = ctx->h_counters.total_slices;
+    t.coefficients = ctx->h_counters.coefficients;
+    t.es_bytes = ctx->es_used;
+    *out = t;
+    return EFX_OK;
+}
+
+int efx_device_alloc(efx_ctx* ctx, size_t bytes, void** dptr)
+{
+    if (!ctx || !dptr)
+        return EFX_ERR_ARG;
+    EFX_HIP(hipMalloc(dptr, bytes));
+    return EFX_OK;
+}
+
+int efx_device_free(efx_ctx* ctx, void* dptr)
+{
+    if (!ctx)
+        return EFX_ERR_ARG;
+    EFX_HIP(hipFree(dptr));
+    return EFX_OK;
+}
+
+int efx_memcpy_h2d(efx_ctx* ctx, void* dst_device, const void* src, size_t bytes)
+{
+    if (!ctx || !dst_device || !src)
+        return EFX_ERR_ARG;
+    EFX_HIP(hipStreamSynchronize(ctx->stream));
+    EFX_HIP(hipMemcpy(dst_device, src, bytes, hipMemcpyHostToDevice));
+    return EFX_OK;
+}
+
+int efx_memcpy_d2h(efx_ctx* ctx, void* dst, const void* src_device, size_t bytes)
+{
+    if (!ctx || !dst || !src_device)
+        return EFX_ERR_ARG;
+    EFX_HIP(hipStreamSynchronize(ctx->stream));
+    EFX_HIP(hipMemcpy(dst, src_device, bytes, hipMemcpyDeviceToHost));
+    return EFX_OK;
+}
+
+}  // extern "C"

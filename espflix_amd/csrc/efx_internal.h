@@ -1,0 +1,93 @@
+// efx_internal.h -- structures shared by the host side of libefx and its gfx950 kernels.
+//
+// Pipeline of one efx_decode():
+//   k_index        one wave per stream: start-code scan + header parse      (player.cpp:1355-1367,646-730)
+//   k_slice_scan   prefix sum of slice counts in picture-major order
+//   k_slice_emit   dense slice descriptors
+//   k_parse        one lane per slice: VLC parse + dequant -> macroblock records + coefficient list
+//                                                                            (player.cpp:1238-1316,999-1122,891-920)
+//   k_recon        one wave per macroblock, one launch per picture index: IDCT + half-pel
+//                  motion compensation + clamp + strip-layout store          (player.cpp:922-996,732-889,1151-1236)
+#pragma once
+#include <cstdint>
+
+namespace efx {
+
+constexpr int kMbW = 22, kMbH = 12, kMbCount = 264;
+constexpr int kStride = 528, kStripBytes = 8448, kFrameBytes = 101376;
+constexpr int kMaxSlicesPerPicture = 16;   // slice start codes kept per picture
+constexpr int kMaxUnitsPerStream = 4096;   // start codes indexed per stream per decode
+constexpr int kCoefsPerEsByte = 3;         // a coefficient costs >= 3 bits (2 + EOB for singletons)
+constexpr int kEsTailBytes = 9;            // 00 | 00 00 01 B7 | 00 00 01 B7   (player.cpp:456,472)
+constexpr int kEsGuardBytes = 64;          // zero guard after the last stream
+
+// per (stream, picture)
+struct PicInfo {
+    uint32_t first_slice;  // index into the stream's temporary slice list
+    uint16_t n_slices;
+    uint8_t type;          // 1 = I, 2 = decoded with the P books (P, and B/D headers the reference ignores)
+    uint8_t full_pel;
+    uint8_t r_size;        // forward_f_code - 1
+    uint8_t custom_q;      // 1: quantiser tables at qtab[(stream*max_pictures+pic)*64]
+    uint16_t reserved;
+    uint32_t seq_off;      // stream-relative offset of the governing sequence header payload
+};
+
+struct SliceTmp {
+    uint32_t off;       // stream-relative offset of the first byte after the slice start code
+    uint32_t len_code;  // (bytes up to the next start code) << 8 | slice start code value
+};
+
+struct SliceDesc {
+    uint32_t es_off;   // absolute offset in the ES buffer
+    uint32_t es_len;   // bytes up to the next start code
+    uint32_t stream;
+    uint32_t pic_code_flags;  // pic | code << 8 | type << 16 | full_pel << 18 | r_size << 19 | custom_q << 22
+    uint32_t reserved[2];
+};
+
+// one macroblock of one picture, written by k_parse, consumed by k_recon
+struct MbRec {
+    uint32_t coef_base;  // absolute index of the first coefficient entry
+    uint8_t cnt[6];      // entries per block (intra: including the DC entry)
+    uint8_t flags;       // bit0 intra, bit1 skipped (copy co-located), bits 2-7 block dropped mask
+    uint8_t epoch;       // decode epoch that wrote the record (0 = never)
+    int16_t mvx, mvy;    // half-pel luma displacement after full_pel scaling
+};
+static_assert(sizeof(MbRec) == 16, "MbRec must be 16 bytes");
+
+// coefficient entry: (dequantised value * IDCT pre-multiplier) << 6 | raster position
+// (the reference's b[zz] = v * scale_dct_q[zz], player.cpp:1121)
+
+// flat VLC look-up tables (built on the host from mpeg1_codebook.h, staged in LDS by k_parse)
+struct ParseTables {
+    uint16_t dct_hi[256];    // index: top 8 bits of a 16-bit peek (codes of <= 8 bits, escape)
+    uint16_t dct_lo[1024];   // index: low 10 bits of a 16-bit peek whose top 6 bits are 0
+    uint16_t mba[2048];      // index: 11-bit peek -> len | value << 4
+    uint16_t motion[2048];   // index: 11-bit peek -> len | (code + 16) << 4
+    uint16_t cbp[512];       // index: 9-bit peek  -> len | value << 4
+    uint8_t type_p[64];      // index: 6-bit peek  -> len | value << 3
+    uint32_t scan[64];       // scan position n -> zz | premul << 8 | default intra q << 16 | 16 << 24
+};
+// dct entry: len (5 bits) | run << 5 (5 bits) | level << 10 (6 bits); level 0 = escape; len 0 = invalid
+
+struct DecodeCounters {
+    uint32_t total_slices;
+    uint32_t pad;
+    unsigned long long coefficients;
+    unsigned long long macroblocks;
+};
+
+// composite video geometry + tables (video.cpp:514-630)
+struct VideoTables {
+    int32_t line_width, line_count, hsync, hsync_long, hsync_short, burst_start, burst_width, active_start;
+    int32_t pal;
+    uint16_t sync_level, blanking_level, black_level, pad;
+    int16_t burst0[64], burst1[64];
+    uint32_t color_tab[768];
+};
+
+void build_parse_tables(ParseTables* t);
+void build_video_tables(int ntsc, VideoTables* t);
+
+}  // namespace efx

@@ -1,0 +1,155 @@
+// efx_tables.cpp -- host-side construction of the look-up tables the kernels use.
+//
+//  * ParseTables: flat VLC decode tables expanded from the ISO 11172-2 code books in
+//    mpeg1_codebook.h (the reference walks bit-serial tree tables instead, player.cpp:516-530,
+//    and a prefix-class decoder for DCT coefficients, player.cpp:548-644).
+//  * VideoTables: composite-video geometry, sync/burst levels and the chroma-phase LUT, derived
+//    with the same float/double arithmetic the reference uses at init time
+//    (video_init/pal_init/usec, video.cpp:554-630; LUT derivation gen_palettes,
+//    espflix.cpp:1091-1161).  tests/test_tables_vs_reference.py pins every value.
+#include <cmath>
+#include <cstring>
+
+#include "efx_internal.h"
+#include "mpeg1_codebook.h"
+
+namespace efx {
+
+namespace {
+
+template <typename T, int N, typename F>
+void expand(T (&table)[N], int index_bits, int code, int len, F make_entry)
+{
+    // every index whose top `len` bits equal `code` maps to this code word
+    int free_bits = index_bits - len;
+    int first = code << free_bits;
+    for (int i = 0; i < (1 << free_bits); i++)
+        table[first + i] = make_entry();
+}
+
+}  // namespace
+
+void build_parse_tables(ParseTables* t)
+{
+    std::memset(t, 0, sizeof(*t));
+
+    // DCT coefficients.  dct_hi covers code words of <= 8 bits (index = their 8-bit prefix);
+    // longer words all start with six zero bits and are resolved through dct_lo, indexed by
+    // bits 6..15 of a 16-bit peek.
+    for (const DctCode& c : kDctCodes) {
+        uint16_t e = (uint16_t)(c.len | (c.run << 5) | (c.level << 10));
+        if (c.len <= 8)
+            expand(t->dct_hi, 8, c.code, c.len, [&] { return e; });
+        else
+            expand(t->dct_lo, 10, c.code & ((1 << (c.len - 6)) - 1), c.len - 6, [&] { return e; });
+    }
+    expand(t->dct_hi, 8, kDctEscapeCode, kDctEscapeLen, [&] { return (uint16_t)kDctEscapeLen; });  // level 0 = escape
+
+    for (const VlcCode& c : kMbaCodes)
+        expand(t->mba, 11, c.code, c.len, [&] { return (uint16_t)(c.len | (c.value << 4)); });
+    for (const VlcCode& c : kMotionCodes)
+        expand(t->motion, 11, c.code, c.len, [&] { return (uint16_t)(c.len | ((c.value + 16) << 4)); });
+    for (const VlcCode& c : kCbpCodes)
+        expand(t->cbp, 9, c.code, c.len, [&] { return (uint16_t)(c.len | (c.value << 4)); });
+    for (const VlcCode& c : kTypePCodes)
+        expand(t->type_p, 6, c.code, c.len, [&] { return (uint8_t)(c.len | (c.value << 3)); });
+
+    // IDCT pre-multipliers round(32 s_i s_j), s_0 = 1, s_k = sqrt(2) cos(k pi / 16): the scaled
+    // AAN factors the reference tabulates as scale_dct_q (player.cpp:161-170).
+    double s[8];
+    s[0] = 1.0;
+    for (int k = 1; k < 8; k++)
+        s[k] = std::sqrt(2.0) * std::cos(k * M_PI / 16);
+    for (int n = 0; n < 64; n++) {
+        int zz = kZigZag[n];
+        int premul = (int)std::floor(32.0 * s[zz >> 3] * s[zz & 7] + 0.5);
+        t->scan[n] = (uint32_t)zz | ((uint32_t)premul << 8) | ((uint32_t)kDefaultIntraQ[zz] << 16) | (16u << 24);
+    }
+}
+
+namespace {
+
+uint32_t ire(double x)  // IRE(), video.cpp:520: DAC code for an IRE level, in the high byte
+{
+    return ((uint32_t)((x + 40) * 255 / 3.3 / 147.5)) << 8;
+}
+
+int usec(float us, float sample_rate, int samples_per_cc)  // video.cpp:554-558
+{
+    uint32_t r = (uint32_t)(us * sample_rate);
+    return (int)(((r + samples_per_cc) / (samples_per_cc << 1)) * (samples_per_cc << 1));
+}
+
+int round_half_up(float v)  // RUP(float), espflix.cpp:1071-1077
+{
+    if (v < 0)
+        return -round_half_up(-v);
+    return (int)(v + 0.5);
+}
+
+// Four carrier-phase samples of one 8-bit chroma value around 2 x black, clipped to 0..127, in
+// the blitter's 0,2,1,3 byte order (espflix.cpp:1079-1161).
+uint32_t chroma_phases(int c, bool cosine, bool negate)
+{
+    int black = (int)(ire(7.5) >> 8);
+    float scale = (float)black / 33;
+    int amp = 128 - c;
+    uint32_t v = 0;
+    for (int i = 0; i < 4; i++) {
+        double w = cosine ? std::cos(2 * M_PI * i / 4) : std::sin(2 * M_PI * i / 4);
+        if (negate)
+            w = -w;
+        int p = round_half_up(w * amp * scale) + 2 * black;
+        p = p < 0 ? 0 : (p < 127 ? p : 127);
+        v = (v << 8) | (uint32_t)p;
+    }
+    return (v & 0xFF0000FFu) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u);
+}
+
+}  // namespace
+
+void build_video_tables(int ntsc, VideoTables* t)
+{
+    std::memset(t, 0, sizeof(*t));
+    const int spc = 4;
+    t->sync_level = (uint16_t)ire(-40);
+    t->blanking_level = (uint16_t)ire(0);
+    t->black_level = (uint16_t)ire(7.5);
+    if (ntsc) {
+        float rate = 315.0 / 88 * spc;
+        t->line_width = 228 * spc;
+        t->line_count = 262;
+        t->hsync_long = usec(63.555 - 4.7, rate, spc);
+        t->active_start = usec(10, rate, spc);
+        t->hsync = usec(4.7, rate, spc);
+        for (int c = 0; c < 256; c++) {
+            t->color_tab[c] = chroma_phases(c, false, false);
+            t->color_tab[256 + c] = t->color_tab[512 + c] = chroma_phases(c, true, false);
+        }
+    } else {
+        float rate = 4433618.75 * spc / 1000000.0;
+        t->pal = 1;
+        t->line_width = 284 * spc;
+        t->line_count = 312;
+        t->hsync_short = usec(2, rate, spc);
+        t->hsync_long = usec(30, rate, spc);
+        t->hsync = usec(4.7, rate, spc);
+        t->burst_start = usec(5.6, rate, spc);
+        t->burst_width = (int)(10 * spc + 4) & 0xFFFE;
+        t->active_start = usec(10.4, rate, spc);
+        uint32_t blank = ire(0);
+        float phase = 2 * M_PI / 2;
+        for (int i = 0; i < t->burst_width; i++) {
+            t->burst0[i] = (int16_t)(blank + std::sin(phase + 3 * M_PI / 4) * blank / 1.5);
+            t->burst1[i] = (int16_t)(blank + std::sin(phase - 3 * M_PI / 4) * blank / 1.5);
+            phase += 2 * M_PI / spc;
+        }
+        for (int c = 0; c < 256; c++) {
+            t->color_tab[c] = chroma_phases(c, false, false);
+            t->color_tab[256 + c] = chroma_phases(c, true, false);
+            t->color_tab[512 + c] = chroma_phases(c, true, true);
+        }
+    }
+}
+
+}  // namespace efx

@@ -1,0 +1,288 @@
+// k_index.hip -- start-code indexing and header parsing (gfx950).
+//
+// Restates, for a whole batch, what MpegDecoder::run()/marker() do serially per stream
+// (reference src/player.cpp:1355-1367,1318-1340): find every 00 00 01 xx start code, read
+// sequence (player.cpp:658-678) and picture headers (704-724), and hand each slice
+// (0x01..0xAF) to the slice decoder together with the picture state in force.
+//
+// k_index: ONE WAVE PER STREAM.  Lanes read 16 contiguous bytes each (1 KiB per wave load,
+// 4 loads in flight), test 16 byte positions, and append hits to an LDS unit list in stream
+// order via a wave prefix sum.  Header fields of all units are then pre-parsed lane-parallel
+// and one lane walks the (short) unit list to apply the reference's sequential state rules.
+#include <hip/hip_runtime.h>
+
+#include "efx_internal.h"
+#include "efx.h"
+
+namespace efx {
+
+namespace {
+
+__device__ inline uint32_t wave_excl_scan(uint32_t v, uint32_t* total)
+{
+    // inclusive Hillis-Steele over 64 lanes
+    uint32_t x = v;
+    int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d)
+            x += y;
+    }
+    *total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+__device__ inline uint32_t load_bits(const uint8_t* p, uint32_t bitpos, int n)  // n <= 24, MSB first
+{
+    const uint8_t* q = p + (bitpos >> 3);
+    uint32_t w = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+    return (w << (bitpos & 7)) >> (32 - n);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, const uint64_t* __restrict__ stream_off,
+                                              int max_pictures, PicInfo* __restrict__ pics,
+                                              SliceTmp* __restrict__ slices_tmp, uint32_t* __restrict__ pic_count,
+                                              uint32_t* __restrict__ status, uint32_t* __restrict__ qtab,
+                                              const uint32_t* __restrict__ scan_tab)
+{
+    __shared__ uint32_t u_off[kMaxUnitsPerStream];
+    __shared__ uint32_t u_info[kMaxUnitsPerStream];
+    __shared__ uint32_t sh_misc[4];
+
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint8_t* base = es + stream_off[s];
+    const uint32_t len = (uint32_t)(stream_off[s + 1] - stream_off[s]);  // padded, multiple of 16
+
+    // ---- 1. start-code scan -------------------------------------------------------------
+    uint32_t n_units = 0;
+    for (uint32_t chunk = 0; chunk < len; chunk += 64 * 16) {
+        uint32_t pos = chunk + lane * 16;
+        uint32_t w[5] = {0, 0, 0, 0, 0};
+        if (pos < len) {
+            uint4 d = *reinterpret_cast<const uint4*>(base + pos);
+            w[0] = d.x;
+            w[1] = d.y;
+            w[2] = d.z;
+            w[3] = d.w;
+            w[4] = *reinterpret_cast<const uint32_t*>(base + pos + 16);  // guard bytes make this safe
+        }
+        uint32_t mask = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            // bytes i, i+1, i+2 as a little-endian 24-bit value must be 0x010000
+            uint32_t lo = w[i >> 2], hi = w[(i >> 2) + 1];
+            uint32_t v = (i & 3) ? __builtin_amdgcn_alignbyte(hi, lo, i & 3) : lo;
+            if ((v & 0xFFFFFF) == 0x010000)
+                mask |= 1u << i;
+        }
+        uint32_t cnt = __popc(mask);
+        if (__ballot(cnt != 0)) {
+            uint32_t total;
+            uint32_t idx = n_units + wave_excl_scan(cnt, &total);
+            while (mask) {
+                int i = __ffs(mask) - 1;
+                mask &= mask - 1;
+                if (idx < kMaxUnitsPerStream) {
+                    uint32_t lo = w[(i + 3) >> 2];
+                    u_off[idx] = pos + i + 4;
+                    u_info[idx] = (lo >> (((i + 3) & 3) * 8)) & 0xFF;
+                }
+                idx++;
+            }
+            n_units += total;
+        }
+    }
+    uint32_t st = 0;
+    if (n_units > kMaxUnitsPerStream) {
+        n_units = kMaxUnitsPerStream;
+        st |= EFX_STREAM_TOO_MANY_UNITS;
+    }
+    __syncthreads();
+
+    // ---- 2. lane-parallel header pre-parse -------------------------------------------------
+    for (uint32_t i = lane; i < n_units; i += 64) {
+        uint32_t code = u_info[i], off = u_off[i];
+        const uint8_t* p = base + off;
+        if (code == 0x00) {  // picture: temporal_reference 10, type 3, vbv_delay 16, [full_pel 1, f_code 3]
+            uint32_t type = load_bits(p, 10, 3);
+            uint32_t fp = load_bits(p, 29, 1), fc = load_bits(p, 30, 3);
+            u_info[i] = code | (type << 8) | (fp << 11) | (fc << 12);
+        } else if (code == 0xB3) {  // sequence: 12+12+4+4+18+12 bits, then the two load flags
+            uint32_t wdt = load_bits(p, 0, 12), hgt = load_bits(p, 12, 12);
+            uint32_t li = load_bits(p, 62, 1);
+            uint32_t ln = load_bits(p, li ? 63 + 512 : 63, 1);
+            uint32_t bad = (wdt != EFX_FRAME_WIDTH || hgt != EFX_FRAME_HEIGHT);
+            u_info[i] = code | (bad << 16) | (li << 17) | (ln << 18);
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. sequential state walk (one lane; the list is a few hundred entries at most) ------
+    PicInfo* mypics = pics + (size_t)s * max_pictures;
+    SliceTmp* myslices = slices_tmp + (size_t)s * max_pictures * kMaxSlicesPerPicture;
+    if (lane == 0) {
+        int pic = -1;
+        uint32_t slice_total = 0;
+        uint32_t p_full = 0, p_r = 0;  // forward_r_size / full_pel_forward persist across pictures
+        uint32_t seq_flags = 0, seq_off = 0;
+        uint16_t nsl = 0;
+        bool dead = false;
+        for (uint32_t i = 0; i < n_units; i++) {
+            uint32_t info = u_info[i], code = info & 0xFF;
+            if (code == 0xB7)  // sequence_end: the reference pauses here (player.cpp:1324-1327)
+                break;
+            if (code == 0xB3) {
+                seq_flags = (info >> 17) & 3;
+                seq_off = u_off[i];
+                if (info & (1u << 16)) {
+                    st |= EFX_STREAM_BAD_SIZE;
+                    dead = true;
+                }
+            } else if (code == 0x00) {
+                if (pic >= 0)
+                    mypics[pic].n_slices = nsl;
+                if (pic + 1 >= max_pictures) {
+                    st |= EFX_STREAM_TRUNCATED;
+                    break;
+                }
+                pic++;
+                nsl = 0;
+                uint32_t type = (info >> 8) & 7;
+                if (type == 2) {
+                    p_full = (info >> 11) & 1;
+                    uint32_t fc = (info >> 12) & 7;
+                    p_r = fc ? fc - 1 : 0;  // f_code 0 is forbidden; the reference would shift by -1
+                }
+                PicInfo pi;
+                pi.first_slice = slice_total;
+                pi.n_slices = 0;
+                pi.type = (type == 1) ? 1 : 2;
+                pi.full_pel = (uint8_t)p_full;
+                pi.r_size = (uint8_t)p_r;
+                pi.custom_q = seq_flags ? 1 : 0;
+                pi.reserved = (uint16_t)seq_flags;
+                pi.seq_off = seq_off;
+                mypics[pic] = pi;
+            } else if (code >= 0x01 && code <= 0xAF) {
+                // slice(): rows beyond the picture are rejected (player.cpp:1255-1258)
+                if (pic >= 0 && !dead && (int)code - 2 < kMbH) {
+                    if (nsl < kMaxSlicesPerPicture) {
+                        uint32_t next = (i + 1 < n_units) ? u_off[i + 1] - 4 : len;
+                        SliceTmp t;
+                        t.off = u_off[i];
+                        t.len_code = ((next - u_off[i]) << 8) | code;
+                        myslices[slice_total++] = t;
+                        nsl++;
+                    } else
+                        st |= EFX_STREAM_TRUNCATED;
+                }
+            }
+        }
+        if (pic >= 0)
+            mypics[pic].n_slices = nsl;
+        pic_count[s] = (uint32_t)(pic + 1);
+        status[s] = st;
+        sh_misc[0] = (uint32_t)(pic + 1);
+    }
+    __syncthreads();
+
+    // ---- 4. custom quantiser tables (sequence header loaded matrices, player.cpp:666-673) ----
+    // The reference stores a loaded matrix in arrival order and later indexes it with the RASTER
+    // position zz (player.cpp:646-651,1113); so entry zz of the table is the zz-th byte sent.
+    uint32_t npics = sh_misc[0];
+    for (uint32_t p = 0; p < npics; p++) {
+        PicInfo pi = mypics[p];
+        if (!pi.custom_q)
+            continue;
+        uint32_t flags = pi.reserved;  // bit0 load_intra, bit1 load_non_intra
+        const uint8_t* sp = base + pi.seq_off;
+        uint32_t intra_bit = 63, non_intra_bit = (flags & 1) ? 64 + 512 : 64;
+        uint32_t t = scan_tab[lane];
+        uint32_t zz = t & 0xFF;
+        uint32_t qi = (flags & 1) ? load_bits(sp, intra_bit + 8 * zz, 8) : ((t >> 16) & 0xFF);
+        uint32_t qn = (flags & 2) ? load_bits(sp, non_intra_bit + 8 * zz, 8) : 16;
+        qtab[((size_t)s * max_pictures + p) * 64 + lane] = (t & 0xFFFF) | (qi << 16) | (qn << 24);
+    }
+}
+
+// Exclusive prefix sum of slice counts over (picture, stream) pairs in picture-major order, so
+// that the slices of one picture index are contiguous: a parse wave then holds 64 slices of the
+// same picture type.  Single workgroup.
+__global__ __launch_bounds__(1024) void k_slice_scan(const PicInfo* __restrict__ pics,
+                                                     const uint32_t* __restrict__ pic_count, int n_streams,
+                                                     int max_pictures, uint32_t* __restrict__ slice_base,
+                                                     DecodeCounters* __restrict__ counters)
+{
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = n_streams * max_pictures;
+    if (tid == 0)
+        carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + tid;
+        uint32_t v = 0;
+        if (i < n) {
+            int p = i / n_streams, s = i - p * n_streams;
+            if ((uint32_t)p < pic_count[s])
+                v = pics[(size_t)s * max_pictures + p].n_slices;
+        }
+        uint32_t tot;
+        uint32_t ex = wave_excl_scan(v, &tot);
+        if (lane == 63)
+            wave_tot[wv] = tot;
+        __syncthreads();
+        uint32_t off = carry;
+        for (int k = 0; k < wv; k++)
+            off += wave_tot[k];
+        if (i < n)
+            slice_base[i] = off + ex;
+        __syncthreads();
+        if (tid == 1023)
+            carry = off + ex + v;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        counters->total_slices = carry;
+        counters->coefficients = 0;
+        counters->macroblocks = 0;
+        slice_base[n] = carry;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_slice_emit(const PicInfo* __restrict__ pics,
+                                                    const SliceTmp* __restrict__ slices_tmp,
+                                                    const uint32_t* __restrict__ pic_count,
+                                                    const uint64_t* __restrict__ stream_off,
+                                                    const uint32_t* __restrict__ slice_base, int n_streams,
+                                                    int max_pictures, SliceDesc* __restrict__ descs)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_streams * max_pictures)
+        return;
+    int p = i / n_streams, s = i - p * n_streams;
+    if ((uint32_t)p >= pic_count[s])
+        return;
+    PicInfo pi = pics[(size_t)s * max_pictures + p];
+    const SliceTmp* src = slices_tmp + (size_t)s * max_pictures * kMaxSlicesPerPicture + pi.first_slice;
+    SliceDesc* dst = descs + slice_base[i];
+    uint32_t base = (uint32_t)stream_off[s];
+    for (int k = 0; k < pi.n_slices; k++) {
+        SliceTmp t = src[k];
+        SliceDesc d;
+        d.es_off = base + t.off;
+        d.es_len = t.len_code >> 8;
+        d.stream = (uint32_t)s;
+        d.pic_code_flags = (uint32_t)p | ((t.len_code & 0xFF) << 8) | ((uint32_t)pi.type << 16) |
+                           ((uint32_t)pi.full_pel << 18) | ((uint32_t)pi.r_size << 19) | ((uint32_t)pi.custom_q << 22);
+        d.reserved[0] = d.reserved[1] = 0;
+        dst[k] = d;
+    }
+}
+
+}  // namespace efx

@@ -1,0 +1,357 @@
+// k_recon.hip -- macroblock reconstruction: IDCT + half-pel motion compensation + store (gfx950).
+//
+// ONE WAVE (64-thread workgroup) PER MACROBLOCK, one launch per picture index (a P picture
+// needs the previous picture of its own stream; streams and macroblocks are independent).
+// Restates idct() (reference src/player.cpp:922-996), predict()/predict_zero()/mocomp()
+// (732-889) and copy_block/add_block[_dc] (1151-1236):
+//
+//   * the macroblock's compact coefficient entries (k_parse) are scattered into a 6 x 64 int32
+//     LDS tile (row pitch padded to 72 words: conflict-free column reads);
+//   * lanes 0..47 each run one 8-point column butterfly, then one 8-point row butterfly
+//     (6 blocks x 8) -- the same scaled integer AAN arithmetic as the reference, transposition
+//     through LDS;
+//   * for predicted macroblocks the 17 x 20-byte luma and two 9 x 12-byte chroma reference
+//     windows are staged in LDS with aligned dword loads (the reference's _src_align staging,
+//     player.cpp:739-759) and the four half-pel cases are evaluated with packed-byte arithmetic;
+//   * each lane adds its 8 residuals to its 8 predicted pixels, clamps to 0..248 (PIN,
+//     player.cpp:183-236) and issues one 8-byte store into the 16-line strip layout
+//     (Frame, src/video.h:36-44).
+//
+// blockIdx = mb * n_streams + stream: all macroblocks of a stream land on XCD (stream % 8), so
+// the partial 64-byte lines written by neighbouring macroblocks merge in one L2.
+#include <hip/hip_runtime.h>
+
+#include "efx_internal.h"
+#include "efx.h"
+
+namespace efx {
+
+namespace {
+
+constexpr int kBlkPitch = 72;   // ints per block in LDS (64 + 8 pad)
+constexpr int kLumaPitch = 24;  // bytes per staged luma row (5 dwords used)
+constexpr int kChromaPitch = 16;
+
+// one 8-point pass of the reference's scaled integer IDCT (player.cpp:938-995)
+__device__ inline void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v5, int& v6, int& v7)
+{
+    int b3 = v2 + v6;
+    int b4 = v5 - v3;
+    int t1 = v1 + v7;
+    int t2 = v3 + v5;
+    int b6 = v1 - v7;
+    int b7 = t1 + t2;
+    int x4 = ((b6 * 473 - b4 * 196 + 128) >> 8) - b7;
+    int x0 = x4 - (((t1 - t2) * 362 + 128) >> 8);
+    int x1 = v0 - v4;
+    int x2 = (((v2 - v6) * 362 + 128) >> 8) - b3;
+    int x3 = v0 + v4;
+    int y3 = x1 + x2;
+    int y4 = x3 + b3;
+    int y5 = x1 - x2;
+    int y6 = x3 - b3;
+    int y7 = -x0 - ((b4 * 473 + b6 * 196 + 128) >> 8);
+    v0 = b7 + y4;
+    v1 = x4 + y3;
+    v2 = y5 - x0;
+    v3 = y6 - y7;
+    v4 = y6 + y7;
+    v5 = x0 + y5;
+    v6 = y3 - x4;
+    v7 = y4 - b7;
+}
+
+__device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// byte offset of plane row inside a frame (Frame::get_y/get_cr/get_cb, player.cpp:33-46)
+__device__ inline int luma_row_off(int y) { return (y >> 4) * kStripBytes + (y & 15) * kStride; }
+__device__ inline int chroma_row_off(int plane, int c)
+{
+    return (c >> 3) * kStripBytes + ((c & 7) + (plane == 2 ? 8 : 0)) * kStride + EFX_FRAME_WIDTH;
+}
+
+__device__ inline uint32_t avg_up(uint32_t a, uint32_t b)  // per byte (a + b + 1) >> 1
+{
+    return (a | b) - (((a ^ b) >> 1) & 0x7F7F7F7Fu);
+}
+
+__device__ inline uint32_t avg4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)  // per byte (a+b+c+d+2) >> 2
+{
+    const uint32_t m = 0x00FF00FFu;
+    uint32_t e = (a & m) + (b & m) + (c & m) + (d & m) + 0x00020002u;
+    uint32_t o = ((a >> 8) & m) + ((b >> 8) & m) + ((c >> 8) & m) + ((d >> 8) & m) + 0x00020002u;
+    return ((e >> 2) & m) | (((o >> 2) & m) << 8);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, const uint32_t* __restrict__ coefs,
+                                              uint8_t* __restrict__ frames, const uint32_t* __restrict__ pic_count,
+                                              int n_streams, int max_pictures, int ring_depth, int pic, int epoch)
+{
+    __shared__ int cf[6 * kBlkPitch];
+    __shared__ uint32_t luma_tile[17 * kLumaPitch / 4];
+    __shared__ uint32_t chroma_tile[2 * 9 * kChromaPitch / 4];
+
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x % n_streams;
+    const int mb = blockIdx.x / n_streams;
+    if ((uint32_t)pic >= pic_count[s])
+        return;
+
+    const MbRec rec = mbrecs[((size_t)s * max_pictures + pic) * kMbCount + mb];
+    if (rec.epoch != (uint8_t)epoch)
+        return;  // macroblock not covered by any slice: the ring slot keeps its old content
+
+    const int mb_x = mb % kMbW, mb_y = mb / kMbW;
+    uint8_t* cur = frames + ((size_t)s * ring_depth + (pic + 1) % ring_depth) * kFrameBytes;
+    const uint8_t* ref = frames + ((size_t)s * ring_depth + pic % ring_depth) * kFrameBytes;
+    const bool intra = rec.flags & 1;
+
+    int pre[7];  // exclusive prefix of the per-block entry counts
+    pre[0] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        pre[k + 1] = pre[k] + rec.cnt[k];
+    const int total = pre[6];
+
+    // luma / chroma fetch geometry, predict() player.cpp:870-889
+    const int X = (mb_x << 5) + rec.mvx, Y = (mb_y << 5) + rec.mvy;
+    const int CX = X >> 1, CY = Y >> 1;  // chroma uses the floor of the halved POSITION
+    const int x0 = X >> 1, y0 = Y >> 1, cx0 = CX >> 1, cy0 = CY >> 1;
+
+    if (!intra) {
+        // ---- stage the reference windows ---------------------------------------------------
+        const bool inside = x0 >= 0 && y0 >= 0 && x0 + 16 + (X & 1) <= EFX_FRAME_WIDTH &&
+                            y0 + 16 + (Y & 1) <= EFX_FRAME_HEIGHT && cx0 >= 0 && cy0 >= 0 &&
+                            cx0 + 8 + (CX & 1) <= EFX_FRAME_WIDTH / 2 && cy0 + 8 + (CY & 1) <= EFX_FRAME_HEIGHT / 2;
+        if (inside) {
+            // every pixel that reaches the output is inside the picture: aligned dword loads.
+            // Rows / dwords beyond the needed window are clamped to stay inside the frame buffer;
+            // their values are never used.
+            const int xa = x0 & ~3, cxa = cx0 & ~3;
+            for (int i = lane; i < 17 * 5 + 2 * 9 * 3; i += 64) {
+                if (i < 85) {
+                    int r = i / 5, c = i - r * 5;
+                    int yy = min(y0 + r, EFX_FRAME_HEIGHT - 1);
+                    int xx = min(xa + 4 * c, EFX_FRAME_STRIDE - 4);
+                    luma_tile[r * (kLumaPitch / 4) + c] = *reinterpret_cast<const uint32_t*>(ref + luma_row_off(yy) + xx);
+                } else {
+                    int j = i - 85;
+                    int plane = 1 + j / 27;
+                    j -= (plane - 1) * 27;
+                    int r = j / 3, c = j - r * 3;
+                    int yy = min(cy0 + r, EFX_FRAME_HEIGHT / 2 - 1);
+                    int xx = min(cxa + 4 * c, EFX_FRAME_WIDTH / 2 - 4);
+                    chroma_tile[((plane - 1) * 9 + r) * (kChromaPitch / 4) + c] =
+                        *reinterpret_cast<const uint32_t*>(ref + chroma_row_off(plane, yy) + xx);
+                }
+            }
+        } else {
+            // vector points outside the picture (undefined in the reference): clamp per pixel
+            uint8_t* lt = reinterpret_cast<uint8_t*>(luma_tile);
+            uint8_t* ct = reinterpret_cast<uint8_t*>(chroma_tile);
+            for (int i = lane; i < 17 * 17 + 2 * 9 * 9; i += 64) {
+                if (i < 289) {
+                    int r = i / 17, c = i - r * 17;
+                    int yy = clampi(y0 + r, 0, EFX_FRAME_HEIGHT - 1), xx = clampi(x0 + c, 0, EFX_FRAME_WIDTH - 1);
+                    lt[r * kLumaPitch + (x0 & 3) + c] = ref[luma_row_off(yy) + xx];
+                } else {
+                    int j = i - 289;
+                    int plane = 1 + j / 81;
+                    j -= (plane - 1) * 81;
+                    int r = j / 9, c = j - r * 9;
+                    int yy = clampi(cy0 + r, 0, EFX_FRAME_HEIGHT / 2 - 1), xx = clampi(cx0 + c, 0, EFX_FRAME_WIDTH / 2 - 1);
+                    ct[((plane - 1) * 9 + r) * kChromaPitch + (cx0 & 3) + c] = ref[chroma_row_off(plane, yy) + xx];
+                }
+            }
+        }
+    }
+
+    // ---- scatter the coefficient entries ----------------------------------------------------
+    const int blk = lane >> 3, sub = lane & 7;  // lanes 0..47: (block, column) then (block, row)
+    const bool worker = lane < 48;
+    int my_cnt = 0;
+    if (worker) {
+        my_cnt = rec.cnt[blk];
+        if (my_cnt > 0) {
+#pragma unroll
+            for (int j = 0; j < 9; j++)
+                cf[blk * kBlkPitch + sub * 9 + j] = 0;
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < total; i += 64) {
+        uint32_t e = coefs[rec.coef_base + i];
+        int b = (i >= pre[1]) + (i >= pre[2]) + (i >= pre[3]) + (i >= pre[4]) + (i >= pre[5]);
+        cf[b * kBlkPitch + (e & 63)] = (int)e >> 6;
+    }
+    __syncthreads();
+
+    // A block whose only coefficient sits at scan position 0 takes the reference's "n == 1"
+    // shortcut (player.cpp:1133-1140): dc = b[0] >> 8 (floor), no IDCT; for intra blocks the
+    // byte is replicated WITHOUT the 0..248 clamp (copy_block_dc, player.cpp:1175-1187).
+    bool dc_only = false;
+    int dc = 0;
+    if (worker && my_cnt == 1) {
+        uint32_t e = coefs[rec.coef_base + pre[blk]];
+        if ((e & 63) == 0) {
+            dc_only = true;
+            dc = ((int)e >> 6) >> 8;
+        }
+    }
+    const bool full = worker && my_cnt > 0 && !dc_only;
+
+    // ---- column pass ---------------------------------------------------------------------------
+    if (full) {
+        int* c = cf + blk * kBlkPitch + sub;
+        int v0 = c[0], v1 = c[8], v2 = c[16], v3 = c[24], v4 = c[32], v5 = c[40], v6 = c[48], v7 = c[56];
+        idct8(v0, v1, v2, v3, v4, v5, v6, v7);
+        c[0] = v0;
+        c[8] = v1;
+        c[16] = v2;
+        c[24] = v3;
+        c[32] = v4;
+        c[40] = v5;
+        c[48] = v6;
+        c[56] = v7;
+    }
+    __syncthreads();
+
+    if (!worker)
+        return;
+
+    // ---- row pass --------------------------------------------------------------------------------
+    int r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0;
+    if (full) {
+        const int4* c = reinterpret_cast<const int4*>(cf + blk * kBlkPitch + sub * 8);
+        int4 a = c[0], b = c[1];
+        r0 = a.x, r1 = a.y, r2 = a.z, r3 = a.w, r4 = b.x, r5 = b.y, r6 = b.z, r7 = b.w;
+        idct8(r0, r1, r2, r3, r4, r5, r6, r7);
+        r0 = (r0 + 128) >> 8;
+        r1 = (r1 + 128) >> 8;
+        r2 = (r2 + 128) >> 8;
+        r3 = (r3 + 128) >> 8;
+        r4 = (r4 + 128) >> 8;
+        r5 = (r5 + 128) >> 8;
+        r6 = (r6 + 128) >> 8;
+        r7 = (r7 + 128) >> 8;
+    } else if (dc_only)
+        r0 = r1 = r2 = r3 = r4 = r5 = r6 = r7 = dc;
+
+    // destination of this lane's 8 pixels (block(), player.cpp:1124-1131)
+    const int row = sub;
+    int dst_off;
+    if (blk < 4)
+        dst_off = luma_row_off(mb_y * 16 + (blk >> 1) * 8 + row) + mb_x * 16 + (blk & 1) * 8;
+    else
+        dst_off = chroma_row_off(blk - 3, mb_y * 8 + row) + mb_x * 8;
+    uint2* dst = reinterpret_cast<uint2*>(cur + dst_off);
+
+    if (intra) {
+        if (my_cnt == 0)
+            return;  // block abandoned by the parser: nothing is stored (player.cpp:1106-1107)
+        uint32_t lo, hi;
+        if (dc_only) {
+            uint32_t w = (uint32_t)dc;
+            w |= w << 8;
+            w |= w << 16;
+            lo = hi = w;
+        } else {
+            lo = (uint32_t)clampi(r0, 0, 248) | ((uint32_t)clampi(r1, 0, 248) << 8) | ((uint32_t)clampi(r2, 0, 248) << 16) |
+                 ((uint32_t)clampi(r3, 0, 248) << 24);
+            hi = (uint32_t)clampi(r4, 0, 248) | ((uint32_t)clampi(r5, 0, 248) << 8) | ((uint32_t)clampi(r6, 0, 248) << 16) |
+                 ((uint32_t)clampi(r7, 0, 248) << 24);
+        }
+        *dst = make_uint2(lo, hi);
+        return;
+    }
+
+    // ---- prediction: the four half-pel cases of mocomp(), player.cpp:767-820 ----------------------
+    uint32_t p_lo, p_hi;
+    {
+        const uint32_t* t;
+        int pitch, col, hx, hy;
+        if (blk < 4) {
+            t = luma_tile + ((blk >> 1) * 8 + row) * (kLumaPitch / 4);
+            pitch = kLumaPitch / 4;
+            col = (x0 & 3) + (blk & 1) * 8;
+            hx = X & 1;
+            hy = Y & 1;
+        } else {
+            t = chroma_tile + ((blk - 4) * 9 + row) * (kChromaPitch / 4);
+            pitch = kChromaPitch / 4;
+            col = cx0 & 3;
+            hx = CX & 1;
+            hy = CY & 1;
+        }
+        const int w0 = col >> 2, sh = col & 3;
+        // 12 bytes starting at the dword holding `col`, for this row and the next
+        uint32_t a0 = t[w0], a1 = t[w0 + 1], a2 = t[w0 + 2];
+        uint32_t b0 = t[pitch + w0], b1 = t[pitch + w0 + 1], b2 = t[pitch + w0 + 2];
+        // pixels col..col+7 and col+1..col+8
+        uint32_t A_lo = __builtin_amdgcn_alignbit(a1, a0, sh * 8), A_hi = __builtin_amdgcn_alignbit(a2, a1, sh * 8);
+        uint32_t B_lo = __builtin_amdgcn_alignbit(b1, b0, sh * 8), B_hi = __builtin_amdgcn_alignbit(b2, b1, sh * 8);
+        // pixel col + 8 is byte `sh` of the third dword
+        uint32_t A9, B9;
+        A9 = (a2 >> (sh * 8)) & 0xFF;
+        B9 = (b2 >> (sh * 8)) & 0xFF;
+        uint32_t A1_lo = (A_lo >> 8) | (A_hi << 24), A1_hi = (A_hi >> 8) | (A9 << 24);
+        uint32_t B1_lo = (B_lo >> 8) | (B_hi << 24), B1_hi = (B_hi >> 8) | (B9 << 24);
+        if (!hx && !hy) {
+            p_lo = A_lo;
+            p_hi = A_hi;
+        } else if (hx && !hy) {
+            p_lo = avg_up(A_lo, A1_lo);
+            p_hi = avg_up(A_hi, A1_hi);
+        } else if (!hx) {
+            p_lo = avg_up(A_lo, B_lo);
+            p_hi = avg_up(A_hi, B_hi);
+        } else {
+            p_lo = avg4(A_lo, A1_lo, B_lo, B1_lo);
+            p_hi = avg4(A_hi, A1_hi, B_hi, B1_hi);
+        }
+    }
+
+    if (my_cnt == 0) {  // prediction only (skipped macroblock, or block without coefficients)
+        *dst = make_uint2(p_lo, p_hi);
+        return;
+    }
+    // add_block / add_block_dc, player.cpp:1189-1236
+    uint32_t lo = (uint32_t)clampi(r0 + (int)(p_lo & 0xFF), 0, 248) | ((uint32_t)clampi(r1 + (int)((p_lo >> 8) & 0xFF), 0, 248) << 8) |
+                  ((uint32_t)clampi(r2 + (int)((p_lo >> 16) & 0xFF), 0, 248) << 16) |
+                  ((uint32_t)clampi(r3 + (int)(p_lo >> 24), 0, 248) << 24);
+    uint32_t hi = (uint32_t)clampi(r4 + (int)(p_hi & 0xFF), 0, 248) | ((uint32_t)clampi(r5 + (int)((p_hi >> 8) & 0xFF), 0, 248) << 8) |
+                  ((uint32_t)clampi(r6 + (int)((p_hi >> 16) & 0xFF), 0, 248) << 16) |
+                  ((uint32_t)clampi(r7 + (int)(p_hi >> 24), 0, 248) << 24);
+    *dst = make_uint2(lo, hi);
+}
+
+// FNV-1a-64 of whole ring frames, one lane per frame (verification helper, not on the timed path)
+__global__ void k_frame_hash(const uint8_t* __restrict__ frames, int n_frames, uint64_t* __restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_frames)
+        return;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(frames + (size_t)i * kFrameBytes);
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (int k = 0; k < kFrameBytes / 4; k++) {
+        uint32_t w = p[k];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            h ^= (w >> (8 * b)) & 0xFF;
+            h *= 0x100000001b3ull;
+        }
+    }
+    out[i] = h;
+}
+
+__global__ void k_fill(uint32_t* __restrict__ p, uint32_t v, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        p[i] = v;
+}
+
+}  // namespace efx

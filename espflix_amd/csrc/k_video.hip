@@ -1,0 +1,195 @@
+// k_video.hip -- composite-video field synthesis and PDM delta-sigma modulation (gfx950).
+//
+// k_composite restates video_isr() and everything it calls (reference src/video.cpp:1122-1198:
+// sync 889-893, burst 806-837, burst_pal 636-644, blanking 904-914, pal_sync 918-934 and the
+// pixel blitter blit 690-804) as a pure function of (front frame, standard, _frame_counter):
+// the ISR writes every sample of every line either directly or through the black fill the
+// preceding blanking lines left in the two ping-pong DMA buffers, so a whole field is
+// data-parallel over (stream, line, 8-sample group).  One workgroup renders 8 consecutive lines
+// of one stream; the 3 KiB chroma-phase LUT lives in LDS; every thread produces one 16-byte
+// (8-sample) store, so line writes are fully coalesced.
+//
+// k_pdm restates pdm_second_order() (espflix.ino:73-107): the recurrence is serial per stream,
+// so one lane owns one stream and walks its samples.
+#include <hip/hip_runtime.h>
+
+#include "efx_internal.h"
+#include "efx.h"
+
+namespace efx {
+
+namespace {
+
+constexpr int kLinesPerBlock = 8;
+
+__device__ inline int luma_row_off(int y) { return (y >> 4) * kStripBytes + (y & 15) * kStride; }
+__device__ inline int chroma_row_off(int plane, int c)
+{
+    return (c >> 3) * kStripBytes + ((c & 7) + (plane == 2 ? 8 : 0)) * kStride + EFX_FRAME_WIDTH;
+}
+
+__constant__ uint32_t c_dither[8] = {  // dither4x4, video.cpp:673-683: 4 lines x 2 frame phases
+    0x00020301, 0x03010002, 0x02030100, 0x01000203, 0x03010002, 0x00020301, 0x01000203, 0x02030100};
+
+// sample i of a line that carries no picture data at that position
+__device__ inline uint32_t line_sample(const VideoTables& v, int kind, int i, int line_counter)
+{
+    // kind 0: normal line (sync, burst, black)   1: NTSC vertical blanking   2: PAL sync lines
+    if (kind == 0) {
+        if (i < v.hsync)
+            return v.sync_level;
+        if (v.pal) {
+            int j = i - v.burst_start;
+            if (j >= 0 && j < v.burst_width) {
+                const int16_t* b = (line_counter & 1) ? v.burst0 : v.burst1;
+                return (uint16_t)b[j ^ 1];
+            }
+        } else {
+            int j = i - v.hsync;
+            if (j < 40) {  // 10 cycles of burst, 4 samples per cycle (video.cpp:817-822)
+                int ph = j & 3;
+                uint32_t bl = v.blanking_level;
+                return ph == 0 ? bl + bl / 2 : (ph == 2 ? bl - bl / 2 : bl);
+            }
+        }
+        return v.black_level;
+    }
+    if (kind == 1)
+        return i < v.hsync_long ? v.sync_level : v.blanking_level;
+    // PAL lines 304..311: two half lines with long or short sync (video.cpp:918-934)
+    const uint32_t types = 0x00233000u;  // _sync_type[8] = {0,0,0,3,3,2,0,0}, one nibble each
+    int t = (types >> ((line_counter - 1 - 304) * 4)) & 0xF;
+    int half = v.line_width / 2;
+    int h = i >= half;
+    int sw = (t & (h ? 1 : 2)) ? v.hsync_long : v.hsync_short;
+    return (i - h * half) < sw ? v.sync_level : v.blanking_level;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_composite(const uint8_t* __restrict__ frames, int first_stream, int ring_depth,
+                                                   int slot, const VideoTables* __restrict__ vt, int frame_counter,
+                                                   uint16_t* __restrict__ out)
+{
+    __shared__ VideoTables v;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(vt);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&v);
+        for (int i = threadIdx.x; i < (int)(sizeof(VideoTables) / 4); i += blockDim.x)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int blocks_per_field = (v.line_count + kLinesPerBlock - 1) / kLinesPerBlock;
+    const int s = blockIdx.x / blocks_per_field;
+    const int line0 = (blockIdx.x - s * blocks_per_field) * kLinesPerBlock;
+    const uint8_t* frame = frames + ((size_t)(first_stream + s) * ring_depth + slot) * kFrameBytes;
+    const int groups = v.line_width / 8;  // 16-byte groups per line
+    const int active_top = 32 + (v.pal ? 32 : 0);
+    const int vsync_start = v.line_count - (v.pal ? 8 : 3);
+    const int first_pix_group = (v.active_start + 16 + (v.pal ? 80 : 0)) / 8;
+
+    for (int item = threadIdx.x; item < kLinesPerBlock * groups; item += blockDim.x) {
+        const int li = item / groups, g = item - li * groups;
+        const int i = line0 + li;
+        if (i >= v.line_count)
+            break;
+        uint4 o;
+        const int pg = g - first_pix_group;
+        const bool active = i >= active_top && i < active_top + 192;
+        if (active && pg >= 0 && pg < EFX_FRAME_WIDTH / 4) {
+            // blit(), video.cpp:690-804: 4 luma pixels -> 8 samples
+            const int line = i - active_top;
+            const int odd = line & 1;
+            const uint8_t* yrow = frame + luma_row_off(line);
+            uint32_t y4 = *reinterpret_cast<const uint32_t*>(yrow + pg * 4);
+            const int crow = line >> 1;
+            const int coff = (pg >> 1) * 4;
+            uint32_t u4 = *reinterpret_cast<const uint32_t*>(frame + chroma_row_off(1, crow) + coff);
+            uint32_t v4 = *reinterpret_cast<const uint32_t*>(frame + chroma_row_off(2, crow) + coff);
+            if (odd) {  // vertical chroma interpolation on odd lines (video.cpp:705-717)
+                int n = crow + (line == 191 ? 0 : 1);
+                uint32_t u2 = *reinterpret_cast<const uint32_t*>(frame + chroma_row_off(1, n) + coff);
+                uint32_t v2 = *reinterpret_cast<const uint32_t*>(frame + chroma_row_off(2, n) + coff);
+                u4 = ((u4 >> 1) & 0x7F7F7F7Fu) + ((u2 >> 1) & 0x7F7F7F7Fu);
+                v4 = ((v4 >> 1) & 0x7F7F7F7Fu) + ((v2 >> 1) & 0x7F7F7F7Fu);
+            }
+            const uint32_t dither = c_dither[(line & 3) + ((frame_counter & 1) << 2)];
+            // running luma average starts from the previous group's last pixel (0 at the line start)
+            uint32_t lum = 0;
+            if (pg > 0) {
+                uint32_t yp = *reinterpret_cast<const uint32_t*>(yrow + pg * 4 - 4);
+                lum = (((yp + dither) & 0xFCFCFCFCu) >> 2) >> 24;
+            }
+            uint32_t p0 = (y4 + dither) & 0xFCFCFCFCu;
+            uint32_t p1 = ((p0 >> 1) + (p0 >> 9)) & 0xFCFCFCFCu;
+            p0 >>= 2;
+            p1 >>= 2;
+            const uint32_t* tab_v = v.color_tab + (odd ? 512 : 256);
+            const int sh = (pg & 1) * 16;
+            uint32_t c = ((v.color_tab[(u4 >> sh) & 0xFF] + tab_v[(v4 >> sh) & 0xFF]) & 0xFCFCFCFCu) >> 2;
+            lum = (((p0 & 0xFF) + lum) >> 1) & 0xFF;
+            o.x = ((lum << 24) | ((p0 & 0xFF) << 8)) + c;
+            o.y = ((p1 << 24) | (p0 & 0xFF00)) + (c << 8);
+            c = ((v.color_tab[(u4 >> (sh + 8)) & 0xFF] + tab_v[(v4 >> (sh + 8)) & 0xFF]) & 0xFCFCFCFCu) >> 2;
+            o.z = ((p1 << 16) | (p0 >> 8)) + c;
+            o.w = (((p1 << 8) & 0xFF000000u) | (p0 >> 16)) + (c << 8);
+        } else {
+            const int kind = (active || i < vsync_start) ? 0 : (v.pal ? 2 : 1);
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t a = line_sample(v, kind, g * 8 + 2 * k, i + 1) & 0xFFFF;
+                uint32_t b = line_sample(v, kind, g * 8 + 2 * k + 1, i + 1) & 0xFFFF;
+                w[k] = a | (b << 16);
+            }
+            o = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        uint16_t* dst = out + ((size_t)s * v.line_count + i) * v.line_width + g * 8;
+        *reinterpret_cast<uint4*>(dst) = o;
+    }
+}
+
+// pdm_second_order(), espflix.ino:73-107: two half-steps per PCM sample, 16 delta-sigma steps
+// per half-step, one 16-bit word (MSB first) per half-step.
+__global__ void k_pdm(const int16_t* __restrict__ pcm, int n_streams, int n_samples, int32_t* __restrict__ state,
+                      uint16_t* __restrict__ dst)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams)
+        return;
+    const int32_t a1 = 38973;  // int32(0x7FFF * 1.18940)
+    const int32_t a2 = 69577;  // int(0x7FFF * 2.12340)
+    uint32_t i0 = (uint32_t)state[s * 3 + 0], i1 = (uint32_t)state[s * 3 + 1], i2 = (uint32_t)state[s * 3 + 2];
+    const int16_t* src = pcm + (size_t)s * n_samples;
+    uint32_t* out = reinterpret_cast<uint32_t*>(dst + (size_t)s * 2 * n_samples);
+    for (int n = 0; n < n_samples; n++) {
+        int32_t x = (int32_t)src[n] * 2;
+        uint32_t word = 0;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            i0 = (uint32_t)(((int32_t)(i0 + (uint32_t)x)) >> 1);
+            uint32_t bits = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                bits <<= 1;
+                uint32_t fb = (uint32_t)(((int32_t)i2) >> 7);
+                if ((int32_t)i2 >= 0) {
+                    i1 += i0 - (uint32_t)a1 - fb;
+                    i2 += i1 - (uint32_t)a2;
+                    bits |= 1;
+                } else {
+                    i1 += i0 + (uint32_t)a1 - fb;
+                    i2 += i1 + (uint32_t)a2;
+                }
+            }
+            word |= (bits & 0xFFFF) << (16 * half);  // consecutive uint16 words, little endian
+        }
+        out[n] = word;
+    }
+    state[s * 3 + 0] = (int32_t)i0;
+    state[s * 3 + 1] = (int32_t)i1;
+    state[s * 3 + 2] = (int32_t)i2;
+}
+
+}  // namespace efx

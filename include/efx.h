@@ -1,0 +1,159 @@
+/* efx.h -- C-ABI of libefx: batched MPEG-1 video decode, composite-video line synthesis and
+ * PDM modulation on AMD Instinct MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the espflix hot path.  The reference (rossumur/espflix) has
+ * no FFI layer: its host player talks to a C++ class and a handful of free functions.  Each
+ * entry point below names the reference interface it stands in for (file:line under the
+ * reference tree); include/efx_player.hpp re-declares that C++ surface (Frame, MpegDecoder,
+ * push_video, video_isr, write_pcm_16) on top of this header for batch = 1.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 (EFX_OK) or a negative
+ * efx_status; nothing throws; one context per host thread (thread-compatible, no global state).
+ * All work is queued on the context's HIP stream; efx_sync() waits for it.
+ */
+#ifndef EFX_H
+#define EFX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EFX_FRAME_WIDTH 352          /* FB_WIDTH,  src/video.h:30 */
+#define EFX_FRAME_HEIGHT 192         /* FB_HEIGHT, src/video.h:31 */
+#define EFX_FRAME_STRIDE 528         /* FB_STRIDE, src/video.h:32: 352 luma + 176 chroma bytes */
+#define EFX_STRIP_ROWS 16            /* FB_SLICE_HEIGHT, src/video.h:33 */
+#define EFX_STRIPS 12                /* FB_SLICES, src/video.h:34 */
+#define EFX_STRIP_BYTES 8448         /* 16 x 528 */
+#define EFX_FRAME_BYTES 101376       /* 12 x 8448; class Frame, src/video.h:36-44 */
+
+typedef enum efx_status {
+    EFX_OK = 0,
+    EFX_ERR_ARG = -1,           /* null / out-of-range argument */
+    EFX_ERR_DEVICE = -2,        /* HIP runtime error (efx_last_error has the text) */
+    EFX_ERR_NO_DEVICE = -3,     /* no gfx950 device / device index out of range */
+    EFX_ERR_CAPACITY = -4,      /* more streams / bytes / pictures than the context was sized for */
+    EFX_ERR_STATE = -5,         /* call made in the wrong order (e.g. decode before upload) */
+    EFX_ERR_STREAM = -6         /* a stream violated a constraint; see efx_stream_status */
+} efx_status;
+
+/* per-stream status bits reported by efx_stream_status() */
+#define EFX_STREAM_OK 0u
+#define EFX_STREAM_BAD_SIZE 1u        /* sequence header is not 352x192 (frame store is fixed) */
+#define EFX_STREAM_TRUNCATED 2u       /* more pictures than max_pictures: the rest was ignored */
+#define EFX_STREAM_TOO_MANY_UNITS 4u  /* start-code index overflow */
+#define EFX_STREAM_BAD_VLC 8u         /* an invalid code ended a slice early */
+#define EFX_STREAM_MB_OVERRUN 16u     /* a slice ran past the last macroblock row */
+#define EFX_STREAM_COEF_OVERRUN 32u   /* a block ran past 64 coefficients (block dropped) */
+
+typedef enum efx_format {
+    EFX_FORMAT_ES = 0, /* raw ISO 11172-2 video elementary stream */
+    EFX_FORMAT_TS = 1  /* 188-byte transport packets, video on PID 0x100 (src/player.cpp:381-493);
+                          demultiplexed on the host at upload, PES PTS kept per picture */
+} efx_format;
+
+typedef struct efx_config {
+    int device;              /* HIP device ordinal */
+    int max_streams;         /* batch capacity */
+    int max_pictures;        /* pictures per stream per efx_decode() call */
+    int ring_depth;          /* frames kept per stream: 2 = the reference's double buffer
+                                (MpegDecoder::_fb, src/player.h:37-40); max_pictures+1 keeps all */
+    size_t max_stream_bytes; /* total ES bytes per upload (0 = 16 KiB x pictures x streams) */
+    void* hip_stream;        /* hipStream_t to run on, or NULL for a private stream */
+} efx_config;
+
+typedef struct efx_ctx efx_ctx;
+
+/* -- lifetime --------------------------------------------------------------------------- */
+/* MpegDecoder::MpegDecoder + Frame::init (src/player.cpp:354-369,25-31): allocates the frame
+ * rings (zero filled) and all scratch in HBM. */
+int efx_create(const efx_config* cfg, efx_ctx** out);
+void efx_destroy(efx_ctx* ctx);
+const char* efx_last_error(const efx_ctx* ctx);
+const char* efx_status_string(int status);
+
+/* -- bitstream in ------------------------------------------------------------------------ */
+/* Stands in for the Buffer hand-off MpegDecoder::push_full / pop_empty (src/player.cpp:371-379,
+ * src/streamer.h:139-143) for a whole batch: copies n_streams byte ranges (host pointers, the
+ * caller keeps ownership) into HBM.  TS input is demultiplexed on the host first.  Like
+ * MpegDecoder::more() at end of data (src/player.cpp:456,469-473) each stream is terminated
+ * with 00 | 00 00 01 B7 | 00 00 01 B7.  Does NOT reset the frame rings. */
+int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, const size_t* len, int format);
+
+/* MpegDecoder::reset + Frame::init (src/player.cpp:439-453): zero the frame rings and restart
+ * picture numbering. */
+int efx_reset(efx_ctx* ctx);
+/* Frame::erase (src/player.cpp:48-52): fill every ring frame with 0x30. */
+int efx_erase_frames(efx_ctx* ctx);
+
+/* -- decode ------------------------------------------------------------------------------ */
+/* MpegDecoder::run() over the uploaded batch (src/player.cpp:1355-1367 and everything below
+ * it: marker/sequence/gop/picture/slice/block/idct/mocomp).  Asynchronous on the context's
+ * stream.  Picture i of a stream (counting every picture start code) is reconstructed into
+ * ring slot (i+1) % ring_depth from slot i % ring_depth, exactly as the reference alternates
+ * _current/_reference (src/player.cpp:692-702). */
+int efx_decode(efx_ctx* ctx);
+int efx_sync(efx_ctx* ctx);
+
+/* number of pictures found in a stream by the last efx_decode (valid after efx_sync) */
+int efx_picture_count(efx_ctx* ctx, int stream, int* n_pictures);
+/* OR of EFX_STREAM_* bits for a stream (valid after efx_sync) */
+int efx_stream_status(efx_ctx* ctx, int stream, uint32_t* bits);
+/* PES PTS latched for picture `picture` (flush_picture, src/player.cpp:692-702); ES input
+ * yields the picture index. */
+int efx_picture_pts(efx_ctx* ctx, int stream, int picture, int64_t* pts);
+
+/* -- frames out (the push_video up-call surface, src/video.h:49) ------------------------- */
+/* Ring slot that holds picture `picture` of the last decode. */
+int efx_picture_slot(const efx_ctx* ctx, int picture);
+/* Device pointer to a ring frame in the reference strip layout (12 x 8448 bytes). */
+int efx_frame_device_ptr(efx_ctx* ctx, int stream, int slot, void** dptr);
+/* Copy one ring frame to host memory (EFX_FRAME_BYTES). Synchronous. */
+int efx_download_frame(efx_ctx* ctx, int stream, int slot, uint8_t* dst);
+/* FNV-1a-64 of ring frames [first_stream, first_stream+n) x [0, ring_depth), computed on the
+ * device, written to host memory as n x ring_depth uint64.  Synchronous. */
+int efx_frame_hashes(efx_ctx* ctx, int first_stream, int n, uint64_t* out);
+/* Overwrite one ring frame from host memory (tests, poster upload). Synchronous. */
+int efx_upload_frame(efx_ctx* ctx, int stream, int slot, const uint8_t* src);
+
+/* -- composite video out (video_init / video_isr, src/video.cpp:572-630,1122-1198) -------- */
+typedef struct efx_video_params {
+    int line_width, line_count;        /* samples per line, lines per field */
+    int hsync, hsync_long, hsync_short;
+    int burst_start, burst_width, active_start;
+} efx_video_params;
+/* geometry video_init(ntsc) establishes: NTSC 912 x 262, PAL 1136 x 312 */
+int efx_video_get_params(int ntsc, efx_video_params* out);
+/* One field per selected stream: n_streams x line_count x line_width uint16 DAC words into
+ * dst (device memory), from ring slot `slot` of streams first_stream..+n.  frame_counter
+ * supplies the dither phase (_frame_counter & 1, src/video.cpp:701).  Asynchronous. */
+int efx_composite_fields(efx_ctx* ctx, int first_stream, int n_streams, int slot, int ntsc, int frame_counter,
+                         uint16_t* dst_device);
+
+/* -- PDM audio out (pdm_second_order / write_pcm_16, espflix.ino:73-145) ------------------ */
+/* n_streams independent modulators.  pcm: n_streams x n_samples int16 (stream-major, device);
+ * state: n_streams x 3 int32 (_i0,_i1,_i2; device, updated in place); dst: n_streams x
+ * 2*n_samples uint16 (device).  Asynchronous. */
+int efx_pdm(efx_ctx* ctx, int n_streams, const int16_t* pcm_device, int n_samples, int32_t* state_device,
+            uint16_t* dst_device);
+
+/* -- measurement -------------------------------------------------------------------------- */
+typedef struct efx_timing {
+    float index_ms, parse_ms, recon_ms, total_ms; /* HIP-event times of the last efx_decode */
+    uint64_t pictures, slices, coefficients, es_bytes;
+} efx_timing;
+/* Enable HIP-event timing of the decode stages (off by default: events serialise the stages). */
+int efx_set_timing(efx_ctx* ctx, int enable);
+int efx_get_timing(efx_ctx* ctx, efx_timing* out);
+
+/* raw device allocations for callers without their own allocator (bench, tests) */
+int efx_device_alloc(efx_ctx* ctx, size_t bytes, void** dptr);
+int efx_device_free(efx_ctx* ctx, void* dptr);
+int efx_memcpy_h2d(efx_ctx* ctx, void* dst_device, const void* src, size_t bytes);
+int efx_memcpy_d2h(efx_ctx* ctx, void* dst, const void* src_device, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EFX_H */

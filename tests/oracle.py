@@ -1,0 +1,176 @@
+"""ctypes binding of the TEST oracle (oracle/_build/libefx_oracle.so) and of the compiled
+reference harnesses (oracle/_ref/*).  Only tests, smoke() and bench.py's cpu_baseline leg use it."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(ROOT, "oracle", "_build", "libefx_oracle.so")
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+FRAME_BYTES = 101376
+FNV_BASIS = 0xCBF29CE484222325
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "port"], check=True, capture_output=True)
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.efxo_decode.restype = C.c_long
+        L.efxo_decode.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, vp, vp, vp, C.c_long]
+        L.efxo_ts_to_es.restype = C.c_size_t
+        L.efxo_ts_to_es.argtypes = [vp, C.c_size_t, vp, C.c_size_t]
+        L.efxo_fnv1a64.restype = C.c_uint64
+        L.efxo_fnv1a64.argtypes = [vp, C.c_size_t, C.c_uint64]
+        L.efxo_video_field.restype = C.c_long
+        L.efxo_video_field.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+        L.efxo_video_params.argtypes = [C.c_int, vp]
+        L.efxo_color_tab.argtypes = [C.c_int, vp]
+        L.efxo_tables.argtypes = [vp, vp]
+        L.efxo_pdm_second_order.argtypes = [vp, vp, vp, C.c_int]
+        L.efxo_write_pcm_16.argtypes = [vp, vp, vp, C.c_int, vp]
+        _lib = L
+    return _lib
+
+
+def decode(data: np.ndarray, fmt: int, flush_last: bool = True, want_frames: bool = False, max_frames: int = 512):
+    """Returns (n, hashes[n], pts[n], frames[n, FRAME_BYTES] or None)."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    hashes = np.zeros(max_frames, dtype=np.uint64)
+    pts = np.zeros(max_frames, dtype=np.int64)
+    frames = np.zeros((max_frames, FRAME_BYTES), dtype=np.uint8) if want_frames else None
+    n = lib().efxo_decode(data.ctypes.data, data.size, fmt, 1 if flush_last else 0,
+                          frames.ctypes.data if want_frames else None, pts.ctypes.data, hashes.ctypes.data, max_frames)
+    n = min(n, max_frames)
+    return n, hashes[:n], pts[:n], (frames[:n] if want_frames else None)
+
+
+def ts_to_es(ts: np.ndarray) -> np.ndarray:
+    ts = np.ascontiguousarray(ts, dtype=np.uint8)
+    out = np.zeros(ts.size, dtype=np.uint8)
+    n = lib().efxo_ts_to_es(ts.ctypes.data, ts.size, out.ctypes.data, out.size)
+    return out[:n].copy()
+
+
+def fnv1a64(buf: np.ndarray, h: int = FNV_BASIS) -> int:
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    return int(lib().efxo_fnv1a64(buf.ctypes.data, buf.size, h))
+
+
+def chain_hash(hashes) -> int:
+    h = FNV_BASIS
+    for x in hashes:
+        h = fnv1a64(np.frombuffer(int(x).to_bytes(8, "little"), dtype=np.uint8), h)
+    return h
+
+
+def video_params(ntsc: bool) -> np.ndarray:
+    p = np.zeros(8, dtype=np.int32)
+    lib().efxo_video_params(1 if ntsc else 0, p.ctypes.data)
+    return p
+
+
+def video_field(frames2: np.ndarray, ntsc: bool, frame_counter0: int, nfields: int) -> np.ndarray:
+    frames2 = np.ascontiguousarray(frames2, dtype=np.uint8)
+    assert frames2.size == 2 * FRAME_BYTES
+    p = video_params(ntsc)
+    out = np.zeros((nfields, p[1], p[0]), dtype=np.uint16)
+    r = lib().efxo_video_field(frames2.ctypes.data, 1 if ntsc else 0, frame_counter0, nfields, out.ctypes.data)
+    assert r == p[0] * p[1]
+    return out
+
+
+def color_tab(ntsc: bool) -> np.ndarray:
+    t = np.zeros(768, dtype=np.uint32)
+    lib().efxo_color_tab(1 if ntsc else 0, t.ctypes.data)
+    return t
+
+
+def tables():
+    zz = np.zeros(64, dtype=np.uint8)
+    pm = np.zeros(64, dtype=np.uint8)
+    lib().efxo_tables(zz.ctypes.data, pm.ctypes.data)
+    return zz, pm
+
+
+def pdm(state: np.ndarray, pcm: np.ndarray) -> np.ndarray:
+    """pdm_second_order over the whole buffer; state (3 x int32) is updated in place."""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    out = np.zeros(2 * pcm.size, dtype=np.uint16)
+    lib().efxo_pdm_second_order(state.ctypes.data, out.ctypes.data, pcm.ctypes.data, pcm.size)
+    return out
+
+
+def write_pcm_16(state: np.ndarray, beep: C.c_int, samples) -> np.ndarray:
+    out = np.zeros(256, dtype=np.uint16)
+    if samples is None:
+        lib().efxo_write_pcm_16(state.ctypes.data, C.addressof(beep), None, 128, out.ctypes.data)
+    else:
+        s = np.ascontiguousarray(samples, dtype=np.int16)
+        lib().efxo_write_pcm_16(state.ctypes.data, C.addressof(beep), s.ctypes.data, s.size, out.ctypes.data)
+    return out
+
+
+# ---- the compiled, unmodified reference (only where oracle/_ref has been built) ---------------
+
+def have_ref() -> bool:
+    return all(os.path.exists(os.path.join(REF_DIR, n)) for n in ("efx_ref_decode", "efx_ref_video", "efx_ref_pdm"))
+
+
+def ref_decode(ts: np.ndarray | str, flush_last: bool = True, want_frames: bool = False):
+    """Run the reference decoder on a TS blob (or '@splash' / '@vmedia').  Returns
+    (hashes, pts, frames or None)."""
+    with tempfile.TemporaryDirectory() as td:
+        if isinstance(ts, str):
+            src = ts
+        else:
+            src = os.path.join(td, "in.ts")
+            np.ascontiguousarray(ts, dtype=np.uint8).tofile(src)
+        out = os.path.join(td, "out.bin") if want_frames else "-"
+        cmd = [os.path.join(REF_DIR, "efx_ref_decode"), "decode", src, out] + (["flush"] if flush_last else [])
+        p = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True, timeout=600)
+        rows = [l.split() for l in p.stderr.splitlines() if l.startswith("F ")]
+        hashes = np.array([int(r[3], 16) for r in rows], dtype=np.uint64)
+        pts = np.array([int(r[2]) for r in rows], dtype=np.int64)
+        frames = np.fromfile(out, dtype=np.uint8).reshape(-1, FRAME_BYTES) if want_frames else None
+        return hashes, pts, frames
+
+
+def ref_video_field(frames2: np.ndarray, ntsc: bool, nfields: int) -> np.ndarray:
+    with tempfile.TemporaryDirectory() as td:
+        src, out = os.path.join(td, "f.bin"), os.path.join(td, "o.bin")
+        np.ascontiguousarray(frames2, dtype=np.uint8).tofile(src)
+        subprocess.run([os.path.join(REF_DIR, "efx_ref_video"), "field", src, "1" if ntsc else "0", str(nfields), out],
+                       check=True, timeout=600)
+        p = video_params(ntsc)
+        return np.fromfile(out, dtype=np.uint16).reshape(nfields, p[1], p[0])
+
+
+def ref_video_params(ntsc: bool):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "p.bin")
+        subprocess.run([os.path.join(REF_DIR, "efx_ref_video"), "params", "1" if ntsc else "0", out], check=True)
+        raw = np.fromfile(out, dtype=np.uint32)
+        return raw[:8].view(np.int32), raw[8:8 + 768], raw[8 + 768:8 + 768 + 8]
+
+
+def ref_pdm(pcm: np.ndarray, silence_every: int = 0, beep_at: int = -1) -> np.ndarray:
+    with tempfile.TemporaryDirectory() as td:
+        src, out = os.path.join(td, "pcm.bin"), os.path.join(td, "o.bin")
+        np.ascontiguousarray(pcm, dtype=np.int16).tofile(src)
+        cmd = [os.path.join(REF_DIR, "efx_ref_pdm"), src, out]
+        if silence_every:
+            cmd += ["silence_every", str(silence_every)]
+        if beep_at >= 0:
+            cmd += ["beep_at", str(beep_at)]
+        subprocess.run(cmd, check=True, timeout=600)
+        return np.fromfile(out, dtype=np.uint16)
