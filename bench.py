@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- MPEG-1 352x192 decode throughput of the MI355X hot path (BASELINE.json metric).
+
+One "step" = one efx_decode() pass over the whole resident batch: start-code index, VLC parse,
+dequantisation, IDCT, half-pel motion compensation and strip-layout store of every picture of
+every stream.  Workload at N = 1 (BASELINE.json configs[2], the per-GPU shard of configs[4]):
+1024 synthetic 352x192 streams x one GOP(12) = I + 11 P pictures,
+bitstreams already resident in HBM when the timed region starts.  At N > 1 every rank decodes its
+own 1024 streams (ids rank*1024 ...): weak scaling, no collective on the data path; RCCL is only
+used for the barrier, the max-over-ranks time and the checksum-of-checksums report.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel's algorithmic GB/s vs the 8 TB/s HBM peak (HIP-event stage times
+                measured inside the timed region on the decode stream)
+  cpu_baseline  the unmodified reference decoder (oracle/_ref, kind "reference") -- or the C
+                restatement (kind "port") when the reference build is absent -- timed on this
+                box's host cores over the same TS-wrapped streams (N = 1, rank 0 only)
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAME_BYTES = 101376
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def shard(rank: int, world: int, streams_per_gpu: int):
+    """Stream ids owned by `rank` (contiguous blocks)."""
+    first = rank * streams_per_gpu
+    return first, streams_per_gpu
+
+
+def algorithmic_bytes(es_bytes: int, n_i: int, n_p: int) -> int:
+    """I picture = B + 101376, P picture = B + 202752."""
+    return es_bytes + n_i * FRAME_BYTES + n_p * 2 * FRAME_BYTES
+
+
+def cpu_baseline(batch, n_streams: int, n_pictures: int, budget_streams: int):
+    """Time the reference decoder on this host over the first `budget_streams` streams."""
+    cores = os.cpu_count() or 1
+    n = min(n_streams, budget_streams)
+    ref = os.path.join(ROOT, "oracle", "_ref", "efx_ref_decode")
+    sample = f"first {n} of the {n_streams} streams x {n_pictures} pictures, TS-wrapped (PID 0x100), {cores} worker processes"
+    if os.path.exists(ref):
+        with tempfile.TemporaryDirectory() as td:
+            lst = os.path.join(td, "list.txt")
+            with open(lst, "w") as f:
+                for i in range(n):
+                    path = os.path.join(td, f"{i}.ts")
+                    batch.ts(i).tofile(path)
+                    f.write(path + "\n")
+            # aim at ~5 s of wall time on all cores (the reference does ~2-4 k frames/s/core)
+            repeat = max(1, int(5.0 * cores * 2000 / (n * n_pictures)))
+            p = subprocess.run([ref, "bench", str(cores), lst, str(repeat)], stderr=subprocess.PIPE,
+                               stdout=subprocess.DEVNULL, text=True, timeout=900)
+        line = [l for l in p.stderr.splitlines() if l.startswith("BENCH")]
+        if line:
+            kv = dict(x.split("=") for x in line[0].split()[1:])
+            return {"value": int(kv["pictures"]) / float(kv["seconds"]), "unit": "frames/s", "cores": int(kv["workers"]),
+                    "kind": "reference", "sample": sample + f", each worker replays its share {kv['repeat']}x "
+                    f"({kv['pictures']} pictures in {float(kv['seconds']):.2f} s)"}
+    # fall back to the C restatement, one process per core
+    import multiprocessing as mp
+    blobs = [batch.ts(i) for i in range(n)]
+    t0 = time.perf_counter()
+    with mp.Pool(cores) as pool:
+        counts = pool.map(_port_decode, blobs, chunksize=max(1, n // (4 * cores)))
+    dt = time.perf_counter() - t0
+    return {"value": sum(counts) / dt, "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample}
+
+
+def _port_decode(ts):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    n, _, _, _ = oracle.decode(ts, 1, flush_last=True, max_frames=64)
+    return n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
+    ap.add_argument("--pictures", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import espflix_amd as efx
+    from espflix_amd import gen
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: espflix_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    first, S = shard(rank, world, args.streams)
+    P = args.pictures
+    threads = max(1, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    t_gen = time.perf_counter()
+    batch = gen.Batch(first, S, P, 12, 0, threads)
+    streams = batch.all_es()
+    t_gen = time.perf_counter() - t_gen
+    es_bytes = int(sum(s.size for s in streams))
+    n_i = S * ((P + 11) // 12)
+    n_p = S * P - n_i
+
+    dec = efx.Decoder(max_streams=S, max_pictures=P, ring_depth=2, device=local_rank, max_stream_bytes=es_bytes + 64 * S)
+    dec.upload(streams, efx.FORMAT_ES)  # bitstreams resident in HBM from here on
+    dec.set_timing(True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        dec.decode(sync=True)
+    stage = np.zeros(3)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dec.decode(sync=True)
+        t = dec.timing()
+        stage += (t.index_ms, t.parse_ms, t.recon_ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # verification riding along: every stream decoded all its pictures with a clean status, and
+    # a checksum of the per-stream frame checksums (deterministic for a given shard)
+    t = dec.timing()
+    assert t.pictures == S * P, (t.pictures, S * P)
+    bad = [i for i in range(S) if dec.stream_status(i) != 0]
+    assert not bad, f"streams with non-zero status: {bad[:8]}"
+    hashes = dec.frame_hashes()
+    csum = int(np.bitwise_xor.reduce(hashes.reshape(-1) * np.uint64(0x9E3779B97F4A7C15)))
+    if dist is not None:
+        cs = torch.tensor([csum & 0x7FFFFFFFFFFFFFFF], device="cuda", dtype=torch.int64)
+        gathered = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(gathered, cs)
+        csum = 0
+        for g in gathered:
+            csum ^= int(g.item())
+
+    if rank == 0:
+        frames = world * S * P * args.steps
+        value = frames / elapsed
+        stage_ms = stage / args.steps
+        names = ["k_index(+scan,emit)", "k_parse", "k_recon x%d" % P]
+        k = int(np.argmax(stage_ms))
+        alg = algorithmic_bytes(es_bytes, n_i, n_p)
+        launches = [1, 1, P]
+        dur_s = stage_ms[k] / 1e3 / launches[k]
+        achieved = alg / launches[k] / dur_s / 1e9
+        out = {
+            "metric": "MPEG-1 352x192 frames/s", "value": value, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
+            "config": {"workload": f"{S} streams/GPU x GOP(12) I+11P, 352x192 MPEG-1 ES resident in HBM, "
+                                   f"ids {first}..{first + S - 1} per rank (BASELINE configs[2]; shard of configs[4])",
+                       "streams_per_gpu": S, "pictures_per_stream": P, "es_bytes_per_gpu": es_bytes,
+                       "mean_bytes_per_picture": es_bytes / (S * P), "parallelism": f"stream-partition x{world}",
+                       "ring_depth": 2},
+            "roofline": {"bound": "hbm", "kernel": names[k], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg / launches[k], "avg_launch_ms": dur_s * 1e3,
+                         "whole_step_achieved_GBs": alg / (elapsed / args.steps) / 1e9,
+                         "stage_ms": dict(zip(names, [float(x) for x in stage_ms]))},
+            "checksum_of_checksums": f"{csum:016x}",
+            "gen_seconds": t_gen,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(batch, S, P, 1024)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    dec.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -898,6 +898,8 @@ static void run_decoder(dec_t* d)
             get_bits(d, 1);
         get_bits(d, 24);
         int m = get_bits(d, 8);
+        if (d->eos_stage == 2 && m != 0xB7)
+            break; /* ran off the end-of-stream pad: the reference would block in _full_q.pop() */
         switch (m) {
         case 0xB3: sequence_header(d); break;
         case 0xB8: /* gop, player.cpp:680-690: 25 + 7 bits, values unused */

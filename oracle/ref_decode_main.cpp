@@ -15,9 +15,15 @@
 //        "flush" additionally calls flush_picture(1) at the end (as load_poster does) so the
 //        last picture is pushed too.
 //   efx_ref_decode fixture <@splash|@vmedia> <out.ts>      dump an embedded clip
-//   efx_ref_decode bench <nworkers> <list.txt>             CPU baseline: decode every TS file
-//        named in list.txt, one forked process per stream, nworkers in flight; prints
-//        "BENCH streams=<n> pictures=<n> seconds=<s> workers=<n>".
+//   efx_ref_decode bench <nworkers> <list.txt> [repeat]    CPU baseline: decode every TS file
+//        named in list.txt with nworkers forked worker PROCESSES (the reference keeps scratch
+//        and event state in process globals, src/player.cpp:732, src/streamer.cpp:305-339, so
+//        one decoder per process).  Worker w plays streams w, w+W, ... back to back through
+//        ONE MpegDecoder exactly as the reference app plays clip after clip (reset();
+//        set_events(DECODER_RUN); feed; wait DECODER_PAUSED, src/espflix.cpp:1043-1058).
+//        Prints "BENCH streams=<n> pictures=<n> seconds=<s> workers=<n>" (wall time from the
+//        first fork to the last exit; inputs pre-loaded in memory).  repeat > 1 makes every
+//        worker play its share that many times (a longer, steadier measurement).
 //   efx_ref_decode tables <out.bin>                        dump zig_zag[64] + scale_dct_q[64]
 #include <stdio.h>
 #include <stdlib.h>
@@ -76,29 +82,49 @@ static MpegDecoder* g_dec = 0;
 
 static void decoder_thread(void*) { g_dec->run(); }
 
-static int decode_rom(const uint8_t* data, int len, bool flush)
+static void decoder_start()
 {
     g_fb[0].init();
     g_fb[1].init();
     g_dec = new MpegDecoder(&g_fb[0], &g_fb[1]);
+    set_events(DECODER_RUN);                 // before the thread starts: the event word is racy
+    start_thread(decoder_thread, 0);
+}
+
+// one play_rom() cycle (src/espflix.cpp:1043-1058) on the running decoder
+static int play(const uint8_t* data, int len, bool flush)
+{
+    int before = g_frames;
     Streamer st;
     st.get_rom(data, len);
     g_dec->reset();
-    set_events(DECODER_RUN);                 // before the thread starts: the event word is racy
-    start_thread(decoder_thread, 0);
+    // the desktop event word is a plain int with unlocked read-modify-write and a condition
+    // variable that can miss a notify (src/streamer.cpp:305-339): keep signalling until the
+    // decoder thread has left pause()
+    while (get_events() & DECODER_PAUSED) {
+        set_events(DECODER_RUN);
+        usleep(20);
+    }
+    set_events(DECODER_RUN);
     for (;;) {
         Buffer* b = g_dec->pop_empty();
-        if (!b) break;
+        if (!b) continue;                     // the 0 pause() pushes to unstick a waiting feeder
         int n = (int)st.read(b->data, (int)sizeof(b->data));
         b->len = n;
         g_dec->push_full(b);
         if (!n) break;
     }
     while (!(get_events() & DECODER_PAUSED))  // poll: wait_events() can lose the wake-up
-        usleep(50);
+        usleep(20);
     if (flush)
         g_dec->flush_picture(1);
-    return g_frames;
+    return g_frames - before;
+}
+
+static int decode_rom(const uint8_t* data, int len, bool flush)
+{
+    decoder_start();
+    return play(data, len, flush);
 }
 
 static std::vector<uint8_t> slurp(const char* path)
@@ -160,7 +186,9 @@ int main(int argc, char** argv)
         fflush(g_log);
         _exit(0);       // decoder thread is parked in pause(); do not run static destructors under it
     }
-    if (cmd == "bench" && argc == 4) {
+    if (cmd == "bench" && argc >= 4) {
+        int repeat = argc > 4 ? atoi(argv[4]) : 1;
+        if (repeat < 1) repeat = 1;
         int workers = atoi(argv[2]);
         std::vector<std::string> files;
         {
@@ -179,33 +207,31 @@ int main(int argc, char** argv)
         g_quiet = 1;
         int pfd[2];
         if (pipe(pfd)) return 3;
-        double t0 = now();
-        size_t next = 0;
-        int live = 0;
+        if (workers < 1) workers = 1;
+        if ((size_t)workers > blobs.size()) workers = (int)blobs.size();
         long pictures = 0;
-        while (next < blobs.size() || live) {
-            while (live < workers && next < blobs.size()) {
-                pid_t p = fork();
-                if (p == 0) {
-                    // one decoder instance per process: the reference keeps scratch and event
-                    // state in process globals (src/player.cpp:732, src/streamer.cpp:305-339)
-                    int n = decode_rom(&blobs[next][0], (int)blobs[next].size(), true);
-                    int32_t r = n;
-                    if (write(pfd[1], &r, 4) != 4) {}
-                    _exit(0);
-                }
-                next++;
-                live++;
-            }
-            int status;
-            if (wait(&status) > 0) {
-                live--;
-                int32_t r = 0;      // the child wrote its count before exiting
-                if (WIFEXITED(status) && read(pfd[0], &r, 4) == 4) pictures += r;
+        double t0 = now();
+        for (int w = 0; w < workers; w++) {
+            pid_t p = fork();
+            if (p == 0) {
+                int32_t n = 0;
+                decoder_start();
+                for (int r = 0; r < repeat; r++)
+                    for (size_t i = w; i < blobs.size(); i += workers)
+                        n += play(&blobs[i][0], (int)blobs[i].size(), true);
+                if (write(pfd[1], &n, 4) != 4) {}
+                _exit(0);
             }
         }
+        for (int w = 0; w < workers; w++) {
+            int status;
+            wait(&status);
+        }
         double t1 = now();
-        fprintf(stderr, "BENCH streams=%zu pictures=%ld seconds=%.6f workers=%d\n", blobs.size(), pictures, t1 - t0, workers);
+        close(pfd[1]);
+        int32_t r;
+        while (read(pfd[0], &r, 4) == 4) pictures += r;
+        fprintf(stderr, "BENCH streams=%zu pictures=%ld seconds=%.6f workers=%d repeat=%d\n", blobs.size(), pictures, t1 - t0, workers, repeat);
         return 0;
     }
     fprintf(stderr, "bad command\n");

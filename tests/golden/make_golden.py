@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/{splash.ts,vmedia.ts,golden.json} by RUNNING THE UNMODIFIED REFERENCE
+(oracle/_ref, built by `make ref` from /root/reference).  Run in the build container only:
+
+    make ref gen oracle && python tests/golden/make_golden.py
+
+Everything in golden.json is an output of the reference itself:
+  clips      per-frame FNV-1a-64 + pts of every frame push_video() received for the two clips
+             embedded in the reference (src/splash.h, src/vmedia.h), with and without the final
+             flush_picture(1)
+  synthetic  the same for generator streams (TS-wrapped) of several flavours
+  composite  FNV of video_isr() fields (NTSC and PAL, 3 fields) for LCG / random / decoded frames
+  pdm        FNV of write_pcm_16() output incl. silence and beep calls
+  tables     zig_zag, scale_dct_q, _color_tab, video geometry
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import common
+import oracle
+from espflix_amd import gen
+
+assert oracle.have_ref(), "build oracle/_ref first (make ref)"
+out = {"clips": {}, "synthetic": {}, "composite": {}, "pdm": {}, "tables": {}}
+
+for clip in ("splash", "vmedia"):
+    subprocess.run([os.path.join(oracle.REF_DIR, "efx_ref_decode"), "fixture", "@" + clip,
+                    os.path.join(HERE, clip + ".ts")], check=True)
+    h, pts, _ = oracle.ref_decode("@" + clip, flush_last=True)
+    h2, _, _ = oracle.ref_decode("@" + clip, flush_last=False)
+    assert len(h2) == len(h) - 1 and (h2 == h[:-1]).all()
+    out["clips"][clip] = {"hashes": [f"{int(x):016x}" for x in h], "pts": [int(x) for x in pts],
+                          "pushed_without_flush": len(h2), "chain": f"{oracle.chain_hash(h2):016x}"}
+
+for flags in common.SYN_FLAGS:
+    b = gen.Batch(0, 8, 12, 12, flags)
+    for k in common.SYN_IDS:
+        h, pts, _ = oracle.ref_decode(b.ts(k), flush_last=True)
+        out["synthetic"][f"{flags}:{k}"] = {"hashes": [f"{int(x):016x}" for x in h], "pts": [int(x) for x in pts],
+                                            "es_fnv": f"{common.fnv_bytes(b.es(k)):016x}"}
+
+_, _, frames = oracle.ref_decode(gen.Batch(0, 1, 12, 12, 0).ts(0), flush_last=True, want_frames=True)
+inputs = {"lcg": common.lcg_frames(), "random": common.random_frames(7), "decoded": np.concatenate([frames[10], frames[11]])}
+for name, fr in inputs.items():
+    for ntsc in (True, False):
+        f = oracle.ref_video_field(fr, ntsc, 3)
+        out["composite"][f"{name}:{'ntsc' if ntsc else 'pal'}"] = [f"{common.fnv_bytes(f[i]):016x}" for i in range(3)]
+
+pcm = common.pdm_pcm(0, 40)
+out["pdm"]["sine220_silence7_beep3"] = f"{common.fnv_bytes(oracle.ref_pdm(pcm, silence_every=7, beep_at=3)):016x}"
+out["pdm"]["sine220"] = f"{common.fnv_bytes(oracle.ref_pdm(pcm)):016x}"
+
+for ntsc in (True, False):
+    params, ctab, dither = oracle.ref_video_params(ntsc)
+    out["tables"]["params_" + ("ntsc" if ntsc else "pal")] = [int(x) for x in params]
+    out["tables"]["color_tab_" + ("ntsc" if ntsc else "pal")] = f"{common.fnv_bytes(ctab):016x}"
+    out["tables"]["dither4x4"] = [int(x) for x in dither]
+tb = os.path.join(HERE, "_t.bin")
+subprocess.run([os.path.join(oracle.REF_DIR, "efx_ref_decode"), "tables", tb], check=True)
+t = np.fromfile(tb, dtype=np.uint8)
+os.remove(tb)
+out["tables"]["zig_zag"] = [int(x) for x in t[:64]]
+out["tables"]["scale_dct_q"] = [int(x) for x in t[64:]]
+
+with open(os.path.join(HERE, "golden.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print("wrote golden.json:", {k: len(v) for k, v in out.items()})

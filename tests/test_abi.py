@@ -1,0 +1,52 @@
+"""The C-ABI library loads and exports every symbol include/efx.h declares (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import espflix_amd as efx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "efx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(efx_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(efx._SYMBOLS)
+
+
+def test_library_exports_every_symbol():
+    assert os.path.exists(efx.LIB_PATH), "build libefx.so first (make lib / __graft_entry__.build())"
+    lib = ctypes.CDLL(efx.LIB_PATH)
+    for name in declared_symbols():
+        getattr(lib, name)
+
+
+def test_host_only_entry_points(golden):
+    assert efx.load_library().efx_status_string(0) == b"ok"
+    for ntsc in (True, False):
+        p = efx.video_params(ntsc)
+        want = golden["tables"]["params_" + ("ntsc" if ntsc else "pal")]
+        assert [p[k] for k in ("line_width", "line_count", "hsync", "hsync_long", "hsync_short", "burst_start",
+                               "burst_width", "active_start")] == want
+
+
+def test_constants_match_header():
+    hdr = open(os.path.join(ROOT, "include", "efx.h")).read()
+    for name, val in (("EFX_FRAME_BYTES", efx.FRAME_BYTES), ("EFX_FRAME_STRIDE", efx.FRAME_STRIDE),
+                      ("EFX_STRIP_BYTES", efx.STRIP_BYTES), ("EFX_STRIPS", efx.STRIPS)):
+        assert int(re.search(name + r"\s+(\d+)", hdr).group(1)) == val
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(efx.EfxError) as e:
+        efx.Decoder(1, 1)
+    assert e.value.status in (-2, -3)

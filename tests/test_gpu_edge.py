@@ -1,0 +1,127 @@
+"""Edge cases of the batch API: empty / ragged / garbage / truncated inputs, capacity errors,
+streams the reference leaves undefined (the HIP path and the oracle define the same result)."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def efx():
+    import espflix_amd
+    espflix_amd.load_library()
+    return espflix_amd
+
+
+def run(efx, streams, max_pictures=12):
+    dec = efx.Decoder(len(streams), max_pictures, max_pictures + 1, max_stream_bytes=sum(len(s) for s in streams) + 4096)
+    dec.upload(streams, efx.FORMAT_ES)
+    dec.decode()
+    h = dec.frame_hashes()
+    out = [(dec.picture_count(i), dec.stream_status(i), [int(h[i, dec.picture_slot(p)]) for p in range(dec.picture_count(i))])
+           for i in range(len(streams))]
+    dec.close()
+    return out
+
+
+def test_ragged_batch_with_empty_and_short_streams(efx):
+    from espflix_amd import gen
+    b = gen.Batch(0, 4, 12, 12, 0)
+    offs1, offs2 = b.picture_offsets(1), b.picture_offsets(2)
+    streams = [b.es(0), np.zeros(0, dtype=np.uint8), b.es(1)[:offs1[3]], np.zeros(777, dtype=np.uint8),
+               b.es(2)[:offs2[1]], b.es(3)]
+    res = run(efx, streams)
+    assert [r[0] for r in res] == [12, 0, 3, 0, 1, 12]
+    assert all(r[1] == 0 for r in res)
+    for i in (0, 2, 4, 5):
+        n, h, _, _ = oracle.decode(streams[i], 0)
+        assert res[i][2] == [int(x) for x in h]
+
+
+def test_garbage_streams_terminate(efx):
+    rng = np.random.default_rng(5)
+    streams = [rng.integers(0, 256, 20000, dtype=np.uint8) for _ in range(16)]
+    res = run(efx, streams)          # must return; contents are undefined in the reference
+    assert len(res) == 16
+
+
+def test_too_many_pictures_is_flagged(efx):
+    from espflix_amd import gen
+    es = gen.Batch(0, 1, 12, 12, 0).es(0)
+    n, st, hashes = run(efx, [es], max_pictures=5)[0]
+    assert n == 5 and (st & efx.STREAM_TRUNCATED)
+    _, h, _, _ = oracle.decode(es, 0)
+    assert hashes == [int(x) for x in h[:5]]
+
+
+def test_wrong_picture_size_is_rejected(efx):
+    from espflix_amd import gen
+    es = gen.Batch(0, 1, 2, 12, 0).es(0).copy()
+    assert es[:4].tolist() == [0, 0, 1, 0xB3]
+    es[4] = 0x14            # horizontal_size 0x140 = 320
+    n, st, _ = run(efx, [es])[0]
+    assert st & efx.STREAM_BAD_SIZE
+
+
+def test_capacity_and_argument_errors(efx):
+    from espflix_amd import gen
+    b = gen.Batch(0, 3, 2, 12, 0)
+    dec = efx.Decoder(2, 2, 2, max_stream_bytes=100000)
+    with pytest.raises(efx.EfxError) as e:
+        dec.upload(b.all_es(), efx.FORMAT_ES)          # 3 streams into a 2-stream context
+    assert e.value.status == -4
+    with pytest.raises(efx.EfxError) as e:
+        dec.decode()                                    # nothing uploaded
+    assert e.value.status == -5
+    big = [np.zeros(200000, dtype=np.uint8)]
+    with pytest.raises(efx.EfxError) as e:
+        dec.upload(big, efx.FORMAT_ES)
+    assert e.value.status == -4
+    dec.upload(b.all_es()[:2], efx.FORMAT_ES)
+    dec.decode()
+    assert dec.picture_count(0) == 2
+    with pytest.raises(efx.EfxError):
+        dec.picture_count(5)
+    dec.close()
+
+
+def test_motion_vectors_outside_the_picture_are_clamped_like_the_oracle(efx):
+    """Undefined in the reference (out-of-bounds reads); libefx and the oracle both clamp the
+    source coordinates.  Build the case by patching a P picture's f_code so every vector doubles."""
+    from espflix_amd import gen
+    b = gen.Batch(1, 1, 4, 12, 0)          # stream id 1: forward_f_code = 2
+    es = b.es(0).copy()
+    offs = b.picture_offsets(0)
+    hits = 0
+    for p in range(1, 4):
+        o = int(offs[p])
+        assert es[o:o + 4].tolist() == [0, 0, 1, 0]
+        # picture header: 10 + 3 + 16 bits, then full_pel_forward (bit 29) and f_code (bits 30-32)
+        es[o + 4 + 3] |= 0x04               # set full_pel_forward: vectors are doubled
+        hits += 1
+    assert hits == 3
+    n, st, hashes = run(efx, [es], max_pictures=4)[0]
+    on, oh, _, _ = oracle.decode(es, 0)
+    assert n == on == 4 and hashes == [int(x) for x in oh]
+
+
+def test_decode_continues_across_uploads_with_double_buffer(efx):
+    """ring_depth = 2: a second upload that starts with P pictures predicts from what the first
+    left in the ring, like the reference decoder fed a file in pieces."""
+    from espflix_amd import gen
+    b = gen.Batch(2, 1, 12, 12, 0)
+    es, offs = b.es(0), b.picture_offsets(0)
+    _, h, _, _ = oracle.decode(es, 0)
+    dec = efx.Decoder(1, 6, 2)
+    dec.upload([es[:offs[6]]], efx.FORMAT_ES)
+    dec.decode()
+    assert dec.picture_count(0) == 6
+    dec.upload([es[offs[6]:]], efx.FORMAT_ES)
+    dec.decode()
+    hh = dec.frame_hashes()
+    # 6 pictures per call: picture 11 sits in the slot of "picture 5" of the second call
+    assert int(hh[0, dec.picture_slot(5)]) == int(h[11])
+    assert int(hh[0, dec.picture_slot(4)]) == int(h[10])
+    dec.close()

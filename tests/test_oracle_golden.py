@@ -1,0 +1,118 @@
+"""The CPU restatement (oracle/efx_oracle.c) against golden vectors produced by the unmodified
+reference (tests/golden/golden.json, made by tests/golden/make_golden.py).  Runs anywhere."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import common
+import oracle
+from espflix_amd import gen
+
+
+def hx(h):
+    return [f"{int(x):016x}" for x in h]
+
+
+@pytest.mark.parametrize("clip", ["splash", "vmedia"])
+def test_embedded_clip_ts(clip, clips, golden):
+    g = golden["clips"][clip]
+    n, h, pts, _ = oracle.decode(clips[clip], 1, flush_last=True)
+    assert n == len(g["hashes"])
+    assert hx(h) == g["hashes"]
+    assert [int(p) for p in pts] == g["pts"]
+    # without the final flush_picture(1) the last picture is never pushed (player.cpp:692-702)
+    n2, h2, _, _ = oracle.decode(clips[clip], 1, flush_last=False)
+    assert n2 == g["pushed_without_flush"]
+    assert f"{oracle.chain_hash(h2):016x}" == g["chain"]
+
+
+@pytest.mark.parametrize("clip", ["splash", "vmedia"])
+def test_embedded_clip_es_equals_ts(clip, clips):
+    """Feeding the demultiplexed ES gives the same frames (pts become picture indices)."""
+    es = oracle.ts_to_es(clips[clip])
+    n1, h1, _, _ = oracle.decode(clips[clip], 1)
+    n2, h2, pts2, _ = oracle.decode(es, 0)
+    assert n1 == n2 and (h1 == h2).all()
+    assert list(pts2) == list(range(n2))
+
+
+@pytest.mark.parametrize("flags", common.SYN_FLAGS)
+def test_synthetic_streams(flags, golden):
+    b = gen.Batch(0, 8, 12, 12, flags)
+    for k in common.SYN_IDS:
+        g = golden["synthetic"][f"{flags}:{k}"]
+        assert f"{common.fnv_bytes(b.es(k)):016x}" == g["es_fnv"], "generator is not deterministic"
+        n, h, pts, _ = oracle.decode(b.ts(k), 1)
+        assert hx(h) == g["hashes"] and [int(p) for p in pts] == g["pts"]
+        n2, h2, _, _ = oracle.decode(b.es(k), 0)
+        assert hx(h2) == g["hashes"]
+
+
+def test_composite_fields(golden):
+    _, _, _, frames = oracle.decode(gen.Batch(0, 1, 12, 12, 0).ts(0), 1, want_frames=True)
+    inputs = {"lcg": common.lcg_frames(), "random": common.random_frames(7),
+              "decoded": np.concatenate([frames[10], frames[11]])}
+    for name, fr in inputs.items():
+        for ntsc in (True, False):
+            f = oracle.video_field(fr, ntsc, 0, 3)
+            got = [f"{common.fnv_bytes(f[i]):016x}" for i in range(3)]
+            assert got == golden["composite"][f"{name}:{'ntsc' if ntsc else 'pal'}"]
+
+
+def test_pdm(golden):
+    pcm = common.pdm_pcm(0, 40)
+    st = np.zeros(3, dtype=np.int32)
+    beep = ctypes.c_int(0)
+    words = []
+    for c in range(40):
+        if c == 3:
+            beep.value = 5
+        silent = (c % 7) == 6
+        words.append(oracle.write_pcm_16(st, beep, None if silent else pcm[c * 128:(c + 1) * 128]))
+    assert f"{common.fnv_bytes(np.concatenate(words)):016x}" == golden["pdm"]["sine220_silence7_beep3"]
+    st = np.zeros(3, dtype=np.int32)
+    assert f"{common.fnv_bytes(oracle.pdm(st, pcm)):016x}" == golden["pdm"]["sine220"]
+    # state carries across calls: one long call == many short calls
+    st2 = np.zeros(3, dtype=np.int32)
+    parts = [oracle.pdm(st2, pcm[i:i + 128]) for i in range(0, pcm.size, 128)]
+    assert np.array_equal(np.concatenate(parts), oracle.pdm(np.zeros(3, dtype=np.int32), pcm))
+    assert np.array_equal(st, st2)
+
+
+def test_tables(golden):
+    zz, pm = oracle.tables()
+    assert list(zz) == golden["tables"]["zig_zag"]
+    assert list(pm) == golden["tables"]["scale_dct_q"]
+    for ntsc in (True, False):
+        key = "ntsc" if ntsc else "pal"
+        assert list(oracle.video_params(ntsc)) == golden["tables"]["params_" + key]
+        assert f"{common.fnv_bytes(oracle.color_tab(ntsc)):016x}" == golden["tables"]["color_tab_" + key]
+
+
+def test_empty_and_garbage_inputs():
+    # no picture start code -> nothing is ever pushed (flush_picture(1) alone would push the
+    # untouched frame buffer, as load_poster does)
+    assert oracle.decode(np.zeros(0, dtype=np.uint8), 0, flush_last=False)[0] == 0
+    assert oracle.decode(np.zeros(1000, dtype=np.uint8), 0, flush_last=False)[0] == 0
+    assert oracle.decode(np.zeros(0, dtype=np.uint8), 0, flush_last=True)[0] == 1
+    rng = np.random.default_rng(3)
+    for _ in range(20):  # must terminate and not crash on noise
+        oracle.decode(rng.integers(0, 256, 5000, dtype=np.uint8), 0)
+        oracle.decode(rng.integers(0, 256, 188 * 20, dtype=np.uint8), 1)
+
+
+def test_truncated_stream_stops_cleanly():
+    b = gen.Batch(0, 1, 12, 12, 0)
+    es, offs = b.es(0), b.picture_offsets(0)
+    full = oracle.decode(es, 0)[1]
+    # cut at picture boundaries: exactly the pictures before the cut come out, unchanged
+    for k in (1, 5, 11):
+        n, h, _, _ = oracle.decode(es[:offs[k]], 0)
+        assert n == k and (h == full[:k]).all()
+    # cut inside a slice: the decoder must terminate; pictures well before the cut are unaffected
+    # (the damaged tail may resynchronise on a phantom start code, as in the reference)
+    for cut in (100, 5000, es.size // 2, es.size - 3):
+        n, h, _, _ = oracle.decode(es[:cut], 0)
+        k = int(np.searchsorted(offs, cut, side="right")) - 1   # pictures wholly before the cut
+        assert n >= k and (h[:k] == full[:k]).all()

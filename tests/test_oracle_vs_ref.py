@@ -1,0 +1,58 @@
+"""Pins the CPU restatement against the reference ITSELF, run live: the unmodified reference
+sources compiled into oracle/_ref by `make ref`.  Skipped where those binaries are absent."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import common
+import oracle
+from espflix_amd import gen
+
+pytestmark = pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+
+
+@pytest.mark.parametrize("clip", ["splash", "vmedia"])
+def test_clips_frame_by_frame(clip, clips):
+    rh, rpts, rframes = oracle.ref_decode(clips[clip], flush_last=True, want_frames=True)
+    n, h, pts, frames = oracle.decode(clips[clip], 1, want_frames=True)
+    assert n == len(rh) and (h == rh).all() and (pts == rpts).all()
+    assert np.array_equal(frames, rframes)
+
+
+@pytest.mark.parametrize("flags", [0, 2, 4, 8, 16, 2 | 4 | 16])
+def test_fresh_synthetic_streams(flags):
+    """Stream ids beyond the committed golden set."""
+    b = gen.Batch(100, 6, 24, 12, flags)   # two GOPs: sequence header repeated mid-stream
+    for k in range(6):
+        rh, rpts, _ = oracle.ref_decode(b.ts(k))
+        n, h, pts, _ = oracle.decode(b.ts(k), 1)
+        assert n == len(rh) == 24 and (h == rh).all() and (pts == rpts).all()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_composite_random_frames(seed):
+    fr = common.random_frames(seed)
+    for ntsc in (True, False):
+        assert np.array_equal(oracle.video_field(fr, ntsc, 0, 2), oracle.ref_video_field(fr, ntsc, 2))
+
+
+def test_video_tables():
+    for ntsc in (True, False):
+        params, ctab, dither = oracle.ref_video_params(ntsc)
+        assert np.array_equal(params, oracle.video_params(ntsc))
+        assert np.array_equal(ctab, oracle.color_tab(ntsc))
+
+
+@pytest.mark.parametrize("k", [0, 5])
+def test_pdm_random(k):
+    pcm = common.pdm_pcm(k, 30)
+    ref = oracle.ref_pdm(pcm, silence_every=5, beep_at=2)
+    st = np.zeros(3, dtype=np.int32)
+    beep = ctypes.c_int(0)
+    words = []
+    for c in range(30):
+        if c == 2:
+            beep.value = 5
+        words.append(oracle.write_pcm_16(st, beep, None if (c % 5) == 4 else pcm[c * 128:(c + 1) * 128]))
+    assert np.array_equal(np.concatenate(words), ref)
