@@ -19,7 +19,7 @@ constexpr int kMaxSlicesPerPicture = 16;   // slice start codes kept per picture
 constexpr int kMaxUnitsPerStream = 4096;   // start codes indexed per stream per decode
 constexpr int kCoefsPerEsByte = 3;         // a coefficient costs >= 3 bits (2 + EOB for singletons)
 constexpr int kEsTailBytes = 9;            // 00 | 00 00 01 B7 | 00 00 01 B7   (player.cpp:456,472)
-constexpr int kEsGuardBytes = 64;          // zero guard after the last stream
+constexpr int kEsGuardBytes = 512;         // zero guard after the last stream (parse lanes read 128 B ahead)
 
 // per (stream, picture)
 struct PicInfo {
@@ -69,7 +69,8 @@ struct ParseTables {
     uint8_t type_p[64];      // index: 6-bit peek  -> len | value << 3
     uint32_t scan[64];       // scan position n -> zz | premul << 8 | default intra q << 16 | 16 << 24
 };
-// dct entry: len (5 bits) | run << 5 (5 bits) | level << 10 (6 bits); level 0 = escape; len 0 = invalid
+// dct entry: len (5 bits) | run << 5 (5 bits) | level << 10 (6 bits); level 0 = escape, level 63 =
+// end_of_block; len 0 = invalid
 
 struct DecodeCounters {
     uint32_t total_slices;

@@ -44,6 +44,10 @@ void build_parse_tables(ParseTables* t)
             expand(t->dct_lo, 10, c.code & ((1 << (c.len - 6)) - 1), c.len - 6, [&] { return e; });
     }
     expand(t->dct_hi, 8, kDctEscapeCode, kDctEscapeLen, [&] { return (uint16_t)kDctEscapeLen; });  // level 0 = escape
+    // the two codes starting with 1 (not in the first position of a non-intra block, which the
+    // parser handles before its loop): "10" = end_of_block (level 63 marks it), "11s" = (0, +-1)
+    expand(t->dct_hi, 8, 0x2, 2, [&] { return (uint16_t)(2 | (63 << 10)); });
+    expand(t->dct_hi, 8, 0x3, 2, [&] { return (uint16_t)(2 | (0 << 5) | (1 << 10)); });
 
     for (const VlcCode& c : kMbaCodes)
         expand(t->mba, 11, c.code, c.len, [&] { return (uint16_t)(c.len | (c.value << 4)); });

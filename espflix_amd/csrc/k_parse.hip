@@ -13,6 +13,12 @@
 //   entry = (dequantised value * IDCT pre-multiplier) << 6 | raster position,
 // i.e. exactly the non-zero b[zz] of player.cpp:1121; the dense 64-int block never exists in
 // memory.  k_recon turns these into pixels.
+//
+// The kernel is bound by the serial symbol chain of the longest slices (I pictures), i.e. by
+// instructions per symbol, so the symbol loop is kept minimal: the bit reader is a bit POSITION
+// into a per-lane LDS ring (one 32-bit window per symbol, no refill state), every DCT code
+// including "10"/"11s" resolves through one table look-up, and global memory is touched only
+// by the coefficient store and by wave-synchronous ring top-ups.
 #include <hip/hip_runtime.h>
 
 #include "efx_internal.h"
@@ -22,68 +28,87 @@ namespace efx {
 
 namespace {
 
-struct BitReader {
-    const uint32_t* p;  // next aligned dword
-    uint64_t w;         // MSB-aligned window
-    int cnt;            // valid bits in w
+constexpr int kRingDwords = 32;  // per-lane bitstream ring in LDS (128 bytes)
+constexpr int kRingLow = 8;      // top up when any lane of the wave has fewer dwords than this ahead
 
-    __device__ inline void refill()
+// Bit reader.  Each lane owns a ring of kRingDwords big-endian dwords of ITS slice in LDS, laid
+// out ring[k][lane] (a wave's accesses hit 64 different banks).  Global memory is read in
+// WAVE-SYNCHRONOUS top-ups: when any lane runs low every lane refills its ring to the brim with
+// independent loads, so the HBM/L2 latency is paid once per ~100 symbols.
+struct BitReader {
+    const uint32_t* gp;  // dword 0 of this lane's slice (aligned down); global address space
+    uint32_t* ring;      // &ring[0][lane]; dword k lives at ring[(k % kRingDwords) * 64]
+    uint32_t pos;        // bit position relative to gp
+    uint32_t wr;         // dwords copied global -> ring so far
+
+    __device__ inline void topup()
     {
-        if (cnt <= 32) {
-            uint32_t d = __builtin_bswap32(*p++);
-            w |= (uint64_t)d << (32 - cnt);
-            cnt += 32;
+        if (__any((int)(wr - (pos >> 5)) < kRingLow)) {
+            const uint32_t n = kRingDwords - (wr - (pos >> 5));
+            for (uint32_t base = 0; base < (uint32_t)kRingDwords; base += 8) {
+                if (!__any(base < n))
+                    break;
+                // eight independent loads in flight, then eight UNCONDITIONAL ring writes (lanes
+                // that need fewer dwords aim the surplus at a scratch row): no load is left
+                // pending on any path, so the symbol loop carries no vmcnt wait
+                uint32_t v[8];
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++)
+                    v[j] = gp[wr + ((base + j < n) ? base + j : 0)];
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) {
+                    uint32_t slot = (base + j < n) ? (wr + base + j) % kRingDwords : (uint32_t)kRingDwords;
+                    ring[slot * 64] = __builtin_bswap32(v[j]);
+                }
+            }
+            wr += n;
         }
     }
-    __device__ inline void init(const uint8_t* ptr)
+    __device__ inline void init(const uint8_t* __restrict__ es, uint32_t off, uint32_t* ring_lane)
     {
-        uintptr_t a = (uintptr_t)ptr;
-        int mis = (int)(a & 3);
-        p = (const uint32_t*)(a - mis);
-        w = 0;
-        cnt = 0;
-        refill();
-        w <<= mis * 8;
-        cnt -= mis * 8;
-        refill();
+        uint32_t mis = off & 3;  // the ES buffer itself is 256-byte aligned
+        gp = reinterpret_cast<const uint32_t*>(es + (off - mis));
+        ring = ring_lane;
+        pos = mis * 8;
+        wr = 0;
+        topup();
     }
-    __device__ inline uint32_t peek(int n) const { return (uint32_t)(w >> (64 - n)); }  // 1 <= n <= 32
-    __device__ inline void skip(int n)
+    // the next 32 bits of the stream, MSB first
+    __device__ inline uint32_t window() const
     {
-        w <<= n;
-        cnt -= n;
+        uint32_t i = pos >> 5;
+        uint32_t hi = ring[(i % kRingDwords) * 64];
+        uint32_t lo = ring[((i + 1) % kRingDwords) * 64];
+        return (uint32_t)((((((uint64_t)hi) << 32) | lo) << (pos & 31)) >> 32);
     }
-    __device__ inline uint32_t get(int n)
-    {
-        uint32_t v = peek(n);
-        skip(n);
-        return v;
-    }
+    __device__ inline void advance(uint32_t n) { pos += n; }
 };
 
 struct SharedTables {
     ParseTables t;
+    uint32_t ring[4][kRingDwords + 1][64];  // [wave][dword][lane]; row kRingDwords is scratch
 };
 
-// motion_vector(), player.cpp:891-910
+// motion_vector(), player.cpp:891-910.  At most 11 + 6 bits: one window.
 __device__ inline int decode_motion(BitReader& br, const uint16_t* tab, int pred, int r_size, bool& ok)
 {
-    br.refill();
-    uint32_t e = tab[br.peek(11)];
-    int len = e & 15;
+    uint32_t win = br.window();
+    uint32_t e = tab[win >> 21];
+    uint32_t len = e & 15;
     if (!len) {
         ok = false;
         return pred;
     }
-    br.skip(len);
     int code = (int)(e >> 4) - 16;
     int d = code;
     if (code != 0 && r_size != 0) {
         int a = code < 0 ? -code : code;
-        d = ((a - 1) << r_size) + (int)br.get(r_size) + 1;
+        d = ((a - 1) << r_size) + (int)((win << len) >> (32 - r_size)) + 1;
+        len += r_size;
         if (code < 0)
             d = -d;
     }
+    br.advance(len);
     int scale = 1 << r_size;
     int m = pred + d;
     if (m > (scale << 4) - 1)
@@ -123,14 +148,16 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
     const int full_pel = (d.pic_code_flags >> 18) & 1;
     const int r_size = (d.pic_code_flags >> 19) & 7;
     const bool custom_q = (d.pic_code_flags >> 22) & 1;
-    const uint32_t* qtab = custom_q ? qtab_custom + ((size_t)d.stream * max_pictures + pic) * 64 : nullptr;
+    const size_t qoff = ((size_t)d.stream * max_pictures + pic) * 64;
 
     MbRec* recs = mbrecs + ((size_t)d.stream * max_pictures + pic) * kMbCount;
     uint32_t coef_idx = d.es_off * kCoefsPerEsByte;
-    const uint32_t coef_end = (d.es_off + d.es_len) * kCoefsPerEsByte;
+    // An entry costs at least 3 bits of slice data, so a slice never outgrows its own region of
+    // kCoefsPerEsByte entries per byte; a damaged slice that runs on is parked on its last slot.
+    const uint32_t coef_last = (d.es_off + d.es_len) * kCoefsPerEsByte - 1;
 
     BitReader br;
-    br.init(es + d.es_off);
+    br.init(es, d.es_off, &sh.ring[threadIdx.x >> 6][0][threadIdx.x & 63]);
 
     uint32_t st = 0;
     uint32_t n_coefs = 0, n_mbs = 0;
@@ -139,16 +166,22 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
     int mb_addr = (code - 1) * kMbW - 1;  // mb_y = code-2, mb_x = mb_width-1
     int dc_y = 128, dc_cr = 128, dc_cb = 128;
     int mv_h = 0, mv_v = 0;
-    int qscale = (int)br.get(5);
-    br.refill();
-    while (br.get(1)) {
-        br.skip(8);
-        br.refill();
+    int qscale;
+    {
+        uint32_t win = br.window();
+        qscale = (int)(win >> 27);
+        br.advance(5);
+        while (br.window() >> 31) {  // extra_bit_slice = 1: skip it and 8 bits of information
+            br.advance(9);
+            br.topup();
+        }
+        br.advance(1);
     }
 
     for (int mb = 0;; mb++) {
-        br.refill();
-        if (br.peek(23) == 0)  // slice_done(), player.cpp:1238-1249
+        br.topup();
+        uint32_t win = br.window();
+        if ((win >> 9) == 0)  // slice_done(): 23 zero bits, player.cpp:1238-1249
             break;
 
         // macroblock_address_increment with stuffing (34) and escape (35), player.cpp:1267-1275
@@ -156,25 +189,28 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
         uint32_t e;
         int v;
         bool ok = true;
-        do {
-            br.refill();
-            e = sh.t.mba[br.peek(11)];
+        for (;;) {
+            e = sh.t.mba[win >> 21];
             if (!(e & 15)) {
                 ok = false;
                 break;
             }
-            br.skip(e & 15);
+            br.advance(e & 15);
             v = (int)(e >> 4);
-        } while (v == 34);
+            if (v != 34)
+                break;
+            br.topup();
+            win = br.window();
+        }
         while (ok && v == 35) {
             inc += 33;
-            br.refill();
-            e = sh.t.mba[br.peek(11)];
+            br.topup();
+            e = sh.t.mba[br.window() >> 21];
             if (!(e & 15)) {
                 ok = false;
                 break;
             }
-            br.skip(e & 15);
+            br.advance(e & 15);
             v = (int)(e >> 4);
         }
         if (!ok) {
@@ -210,33 +246,36 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
             break;
         }
 
-        // macroblock_type, player.cpp:1292-1296
-        br.refill();
+        // macroblock_type (+ quantiser_scale), player.cpp:1292-1296: at most 6 + 5 bits
+        win = br.window();
         int type;
+        uint32_t used;
         if (i_picture) {
-            uint32_t pk = br.peek(2);
-            if (pk & 2) {
+            if (win >> 31) {
                 type = 1;
-                br.skip(1);
-            } else if (pk == 1) {
+                used = 1;
+            } else if ((win >> 30) == 1) {
                 type = 17;
-                br.skip(2);
+                used = 2;
             } else {
                 st |= EFX_STREAM_BAD_VLC;
                 break;
             }
         } else {
-            uint32_t t = sh.t.type_p[br.peek(6)];
+            uint32_t t = sh.t.type_p[win >> 26];
             if (!(t & 7)) {
                 st |= EFX_STREAM_BAD_VLC;
                 break;
             }
-            br.skip(t & 7);
+            used = t & 7;
             type = (int)(t >> 3);
         }
         const bool intra = type & 1;
-        if (type & 0x10)
-            qscale = (int)br.get(5);
+        if (type & 0x10) {
+            qscale = (int)((win << used) >> 27);
+            used += 5;
+        }
+        br.advance(used);
 
         MbRec rec;
         rec.coef_base = coef_idx;
@@ -261,13 +300,12 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
 
         int cbp = intra ? 63 : 0;
         if (type & 0x02) {
-            br.refill();
-            uint32_t c = sh.t.cbp[br.peek(9)];
+            uint32_t c = sh.t.cbp[br.window() >> 23];
             if (!(c & 15)) {
                 st |= EFX_STREAM_BAD_VLC;
                 break;
             }
-            br.skip(c & 15);
+            br.advance(c & 15);
             cbp = (int)(c >> 4);
         }
 
@@ -278,12 +316,13 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                 continue;
             const uint32_t blk_start = coef_idx;
             int n = 0;
-            br.refill();
+            br.topup();
+            win = br.window();
             if (intra) {
-                // DC size + differential, player.cpp:1010-1068 (table B-5a / B-5b)
+                // DC size + differential, player.cpp:1010-1068 (table B-5a / B-5b): <= 10 + 11 bits
                 int size, len, pred;
                 if (blk < 4) {
-                    uint32_t pb = br.peek(9);
+                    uint32_t pb = win >> 23;
                     int ones = __clz((int)~(pb << 23));
                     if (ones == 0) {
                         size = 1 + (int)((pb >> 7) & 1);
@@ -297,7 +336,7 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                     }
                     pred = dc_y;
                 } else {
-                    uint32_t pb = br.peek(10);
+                    uint32_t pb = win >> 22;
                     int ones = __clz((int)~(pb << 22));
                     if (ones == 0) {
                         size = (int)((pb >> 8) & 1);
@@ -308,10 +347,9 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                     }
                     pred = (blk == 4) ? dc_cr : dc_cb;
                 }
-                br.skip(len);
                 if (size) {
-                    br.refill();
-                    int delta = (int)br.get(size);
+                    int delta = (int)((win << len) >> (32 - size));
+                    len += size;
                     if (delta & (1 << (size - 1)))
                         pred += delta;
                     else
@@ -323,55 +361,69 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                     else
                         dc_y = pred;
                 }
-                if (coef_idx < coef_end)
-                    coefs[coef_idx] = ((uint32_t)pred << 8) << 6;  // b[0] = dc << 8, zz = 0
+                br.advance(len);
+                coefs[min(coef_idx, coef_last)] = ((uint32_t)pred << 8) << 6;  // b[0] = dc << 8, zz = 0
                 coef_idx++;
                 n = 1;
+                win = br.window();
             }
 
-            bool dropped = false;
-            for (;;) {  // run/level pairs, player.cpp:1070-1122
-                br.refill();
-                uint32_t pk = br.peek(16);
-                int run, level;
-                if (pk & 0x8000) {
-                    if (n && !(pk & 0x4000)) {  // "10": end_of_block (not possible as first code)
-                        br.skip(2);
-                        break;
-                    }
-                    // "1s" as first coefficient of a non-intra block, "11s" otherwise: (0, +-1)
-                    br.skip(n ? 2 : 1);
-                    run = 0;
-                    level = br.get(1) ? -1 : 1;
-                } else {
+            // run/level pairs, player.cpp:1070-1122
+            int level = 0, run = 0;
+            bool have = false, dropped = false;
+            if (!intra && (win >> 31)) {
+                // first coefficient of a non-intra block: "1s" is (0, +-1); end_of_block cannot come first
+                level = ((win >> 30) & 1) ? -1 : 1;
+                br.advance(2);
+                have = true;
+            }
+            for (;;) {
+                if (!have) {
+                    br.topup();
+                    win = br.window();
+                    uint32_t pk = win >> 16;
                     uint32_t ent = (pk >= 0x0400) ? sh.t.dct_hi[pk >> 8] : sh.t.dct_lo[pk & 0x3FF];
-                    int len = ent & 31;
-                    if (!len) {
+                    uint32_t len = ent & 31;
+                    run = (ent >> 5) & 31;
+                    level = (int)(ent >> 10);
+                    if (len == 0) {
                         bad = true;
                         break;
                     }
-                    br.skip(len);
-                    run = (ent >> 5) & 31;
-                    level = (int)(ent >> 10);
+                    if (level == 63) {  // "10": end_of_block
+                        br.advance(2);
+                        break;
+                    }
                     if (level == 0) {  // escape: 6-bit run, 8- or 16-bit level (player.cpp:1092-1099)
-                        run = (int)br.get(6);
-                        br.refill();
-                        level = (int)br.get(8);
-                        if (level == 0)
-                            level = (int)br.get(8);
-                        else if (level == 128)
-                            level = (int)br.get(8) - 256;
-                        else if (level > 128)
+                        run = (int)((win << 6) >> 26);
+                        level = (int)((win << 12) >> 24);
+                        len = 20;
+                        if ((level & 0x7F) == 0) {
+                            int ext = (int)((win << 20) >> 24);
+                            level = level ? ext - 256 : ext;
+                            len = 28;
+                        } else if (level > 128)
                             level -= 256;
-                    } else if (br.get(1))
-                        level = -level;
+                    } else {
+                        if ((win << len) >> 31)
+                            level = -level;
+                        len++;
+                    }
+                    br.advance(len);
                 }
+                have = false;
                 n += run;
+                run = 0;
                 if (n >= 64) {  // player.cpp:1106-1107: the block is abandoned, nothing is stored
                     dropped = true;
                     break;
                 }
-                uint32_t t = qtab ? qtab[n] : sh.t.scan[n];
+                // LDS look-up (volatile: keeps the compiler from fusing it with the global re-read
+                // below into one flat load, which would put a vmcnt(0) wait into every iteration);
+                // only streams with loaded quantiser matrices take the global path
+                uint32_t t = *reinterpret_cast<volatile uint32_t*>(&sh.t.scan[n]);
+                if (custom_q)
+                    t = qtab_custom[qoff + n];
                 n++;
                 int q = intra ? (int)((t >> 16) & 0xFF) : (int)(t >> 24);
                 // reconstruction, player.cpp:1110-1121
@@ -384,8 +436,7 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                     val -= (val > 0) ? 1 : -1;
                 val = val > 2047 ? 2047 : (val < -2048 ? -2048 : val);
                 val *= (int)((t >> 8) & 0xFF);
-                if (coef_idx < coef_end)
-                    coefs[coef_idx] = ((uint32_t)val << 6) | (t & 0x3F);
+                coefs[min(coef_idx, coef_last)] = ((uint32_t)val << 6) | (t & 0x3F);
                 coef_idx++;
             }
             if (bad)
@@ -393,7 +444,6 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
             if (dropped) {
                 st |= EFX_STREAM_COEF_OVERRUN;
                 coef_idx = blk_start;  // forget the partial block
-                rec.flags |= (uint8_t)(4u << blk);
             } else {
                 rec.cnt[blk] = (uint8_t)(coef_idx - blk_start);
                 n_coefs += coef_idx - blk_start;
@@ -405,9 +455,11 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
             st |= EFX_STREAM_BAD_VLC;
             break;
         }
+        if (coef_idx > coef_last) {
+            st |= EFX_STREAM_BAD_VLC;  // ran past this slice's bytes without finding its end
+            break;
+        }
     }
-    if (coef_idx > coef_end)
-        st |= EFX_STREAM_BAD_VLC;
     if (st)
         atomicOr(&status[d.stream], st);
     atomicAdd(&counters->coefficients, (unsigned long long)n_coefs);
