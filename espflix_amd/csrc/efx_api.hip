@@ -22,7 +22,7 @@ __global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, c
                              SliceDesc*);
 __global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const ParseTables*, const uint32_t*, MbRec*,
                         uint32_t*, uint32_t*, int, int);
-__global__ void k_recon(const MbRec*, const uint32_t*, uint8_t*, const uint32_t*, int, int, int, int, int);
+__global__ void k_recon(const MbRec*, const uint32_t*, uint8_t*, int, int, int, int, int, int);
 __global__ void k_frame_hash(const uint8_t*, int, uint64_t*);
 __global__ void k_fill(uint32_t*, uint32_t, size_t);
 __global__ void k_composite(const uint8_t*, int, int, int, const VideoTables*, int, uint16_t*);
@@ -42,23 +42,34 @@ struct efx_ctx {
     int n_streams = 0;  // streams in the current upload
     size_t es_used = 0;
     bool uploaded = false, decoded = false, results_valid = false;
-    int epoch = 0;
 
     // device buffers
     uint8_t* d_es = nullptr;
     uint64_t* d_stream_off = nullptr;
     PicInfo* d_pics = nullptr;
     SliceTmp* d_slices_tmp = nullptr;
-    uint32_t* d_pic_count = nullptr;
-    uint32_t* d_status = nullptr;
     uint32_t* d_qtab = nullptr;
     ParseTables* d_tables = nullptr;
     uint32_t* d_slice_base = nullptr;
-    DecodeCounters* d_counters = nullptr;
     SliceDesc* d_descs = nullptr;
-    MbRec* d_mbrecs = nullptr;
-    uint32_t* d_coefs = nullptr;
     uint8_t* d_frames = nullptr;
+    // Two sets of parse -> recon hand-over buffers: efx_decode() number n parses into slot n & 1
+    // on the parse stream while the recon stream is still reconstructing call n - 1 from the
+    // other slot, so back-to-back decodes overlap the two (differently bound) halves.
+    struct Slot {
+        uint32_t* d_pic_count = nullptr;
+        uint32_t* d_status = nullptr;
+        DecodeCounters* d_counters = nullptr;
+        MbRec* d_mbrecs = nullptr;
+        uint32_t* d_coefs = nullptr;
+        hipEvent_t parse_done = nullptr, recon_done = nullptr;
+        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // timing: parse start, index end, parse end, recon end, recon start
+        int epoch = 0;
+        bool timed = false;
+    } slot[2];
+    int cur = 0;        // slot of the most recent efx_decode
+    uint64_t calls = 0;
+    hipStream_t parse_stream = nullptr;
     VideoTables* d_video[2] = {nullptr, nullptr};  // [0] PAL, [1] NTSC
     uint64_t* d_hash = nullptr;
 
@@ -70,8 +81,6 @@ struct efx_ctx {
     DecodeCounters h_counters{};
 
     bool timing = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    efx_timing last_timing{};
 };
 
 namespace {
@@ -202,15 +211,24 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     A(dalloc(&ctx->d_stream_off, n + 1));
     A(dalloc(&ctx->d_pics, n * P));
     A(dalloc(&ctx->d_slices_tmp, n * P * kMaxSlicesPerPicture));
-    A(dalloc(&ctx->d_pic_count, n));
-    A(dalloc(&ctx->d_status, n));
     A(dalloc(&ctx->d_qtab, n * P * 64));
     A(dalloc(&ctx->d_tables, 1));
     A(dalloc(&ctx->d_slice_base, n * P + 1));
-    A(dalloc(&ctx->d_counters, 1));
     A(dalloc(&ctx->d_descs, n * P * kMaxSlicesPerPicture));
-    A(dalloc(&ctx->d_mbrecs, n * P * kMbCount));
-    A(dalloc(&ctx->d_coefs, ctx->es_cap * kCoefsPerEsByte));
+    for (auto& sl : ctx->slot) {
+        A(dalloc(&sl.d_pic_count, n));
+        A(dalloc(&sl.d_status, n));
+        A(dalloc(&sl.d_counters, 1));
+        A(dalloc(&sl.d_mbrecs, n * P * kMbCount));
+        A(dalloc(&sl.d_coefs, ctx->es_cap * kCoefsPerEsByte));
+    }
+    {
+        // the parse kernel is a few thousand long-running waves: give it the higher priority so its
+        // workgroups are placed as soon as the reconstruction kernels of the previous call free a slot
+        int lo = 0, hi = 0;
+        A(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        A(hipStreamCreateWithPriority(&ctx->parse_stream, hipStreamNonBlocking, hi));
+    }
     A(dalloc(&ctx->d_frames, n * D * kFrameBytes));
     A(dalloc(&ctx->d_video[0], 1));
     A(dalloc(&ctx->d_video[1], 1));
@@ -230,10 +248,14 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         A(hipMemcpy(ctx->d_video[ntsc], &vt, sizeof(vt), hipMemcpyHostToDevice));
     }
     A(hipMemset(ctx->d_frames, 0, n * D * kFrameBytes));
-    A(hipMemset(ctx->d_mbrecs, 0, n * P * kMbCount * sizeof(MbRec)));
     A(hipMemset(ctx->d_es, 0, ctx->es_cap));
-    for (auto& ev : ctx->ev)
-        A(hipEventCreate(&ev));
+    for (auto& sl : ctx->slot) {
+        A(hipMemset(sl.d_mbrecs, 0, n * P * kMbCount * sizeof(MbRec)));
+        A(hipEventCreateWithFlags(&sl.parse_done, hipEventDisableTiming));
+        A(hipEventCreateWithFlags(&sl.recon_done, hipEventDisableTiming));
+        for (auto& ev : sl.ev)
+            A(hipEventCreate(&ev));
+    }
     if (e != hipSuccess)
         return bail(EFX_ERR_DEVICE);
     *out = ctx;
@@ -244,19 +266,32 @@ void efx_destroy(efx_ctx* ctx)
 {
     if (!ctx)
         return;
+    if (ctx->parse_stream)
+        (void)hipStreamSynchronize(ctx->parse_stream);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
-    void* bufs[] = {ctx->d_es,         ctx->d_stream_off, ctx->d_pics,     ctx->d_slices_tmp, ctx->d_pic_count, ctx->d_status,
-                    ctx->d_qtab,       ctx->d_tables,     ctx->d_slice_base, ctx->d_counters, ctx->d_descs,     ctx->d_mbrecs,
-                    ctx->d_coefs,      ctx->d_frames,     ctx->d_video[0], ctx->d_video[1],   ctx->d_hash};
+    void* bufs[] = {ctx->d_es,   ctx->d_stream_off, ctx->d_pics,  ctx->d_slices_tmp, ctx->d_qtab,     ctx->d_tables,
+                    ctx->d_slice_base, ctx->d_descs, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_hash};
     for (void* b : bufs)
         if (b)
             (void)hipFree(b);
+    for (auto& sl : ctx->slot) {
+        void* sb[] = {sl.d_pic_count, sl.d_status, sl.d_counters, sl.d_mbrecs, sl.d_coefs};
+        for (void* b : sb)
+            if (b)
+                (void)hipFree(b);
+        if (sl.parse_done)
+            (void)hipEventDestroy(sl.parse_done);
+        if (sl.recon_done)
+            (void)hipEventDestroy(sl.recon_done);
+        for (auto& ev : sl.ev)
+            if (ev)
+                (void)hipEventDestroy(ev);
+    }
     if (ctx->h_es)
         (void)hipHostFree(ctx->h_es);
-    for (auto& ev : ctx->ev)
-        if (ev)
-            (void)hipEventDestroy(ev);
+    if (ctx->parse_stream)
+        (void)hipStreamDestroy(ctx->parse_stream);
     if (ctx->own_stream && ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -268,7 +303,8 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
         return fail(ctx, EFX_ERR_ARG, "efx_upload_streams: bad argument");
     if (n_streams > ctx->cfg.max_streams)
         return fail(ctx, EFX_ERR_CAPACITY, "efx_upload_streams: more streams than max_streams");
-    EFX_HIP(hipStreamSynchronize(ctx->stream));  // the staging buffer may still be in flight
+    EFX_HIP(hipStreamSynchronize(ctx->parse_stream));  // the bitstream buffer may still be in use
+    EFX_HIP(hipStreamSynchronize(ctx->stream));
     static const uint8_t tail[kEsTailBytes] = {0, 0, 0, 1, 0xB7, 0, 0, 1, 0xB7};
     ctx->h_stream_off.assign((size_t)n_streams + 1, 0);
     ctx->pts.assign((size_t)n_streams, {});
@@ -350,32 +386,45 @@ int efx_decode(efx_ctx* ctx)
     if (!ctx->uploaded)
         return fail(ctx, EFX_ERR_STATE, "efx_decode: no streams uploaded");
     const int n = ctx->n_streams, P = ctx->cfg.max_pictures, D = ctx->cfg.ring_depth;
-    hipStream_t st = ctx->stream;
+    hipStream_t sp = ctx->parse_stream, sr = ctx->stream;
+    ctx->cur = (int)(ctx->calls++ & 1);
+    efx_ctx::Slot& sl = ctx->slot[ctx->cur];
+
+    // ---- parse half (parse stream): index -> slice list -> VLC parse + dequantisation ---------------
+    EFX_HIP(hipStreamWaitEvent(sp, sl.recon_done, 0));  // the call two back has released this slot
     // macroblock records carry the epoch that wrote them; recycle the tag space by clearing
-    if (++ctx->epoch > 255) {
-        EFX_HIP(hipMemsetAsync(ctx->d_mbrecs, 0, (size_t)ctx->cfg.max_streams * P * kMbCount * sizeof(MbRec), st));
-        ctx->epoch = 1;
+    if (++sl.epoch > 255) {
+        EFX_HIP(hipMemsetAsync(sl.d_mbrecs, 0, (size_t)ctx->cfg.max_streams * P * kMbCount * sizeof(MbRec), sp));
+        sl.epoch = 1;
     }
-    if (ctx->timing)
-        EFX_HIP(hipEventRecord(ctx->ev[0], st));
-    hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, st, ctx->d_es, ctx->d_stream_off, P, ctx->d_pics, ctx->d_slices_tmp,
-                       ctx->d_pic_count, ctx->d_status, ctx->d_qtab, ctx->d_tables->scan);
-    hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, st, ctx->d_pics, ctx->d_pic_count, n, P, ctx->d_slice_base,
-                       ctx->d_counters);
-    hipLaunchKernelGGL(k_slice_emit, dim3((n * P + 255) / 256), dim3(256), 0, st, ctx->d_pics, ctx->d_slices_tmp,
-                       ctx->d_pic_count, ctx->d_stream_off, ctx->d_slice_base, n, P, ctx->d_descs);
-    if (ctx->timing)
-        EFX_HIP(hipEventRecord(ctx->ev[1], st));
+    sl.timed = ctx->timing;
+    if (sl.timed)
+        EFX_HIP(hipEventRecord(sl.ev[0], sp));
+    hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, sp, ctx->d_es, ctx->d_stream_off, P, ctx->d_pics, ctx->d_slices_tmp,
+                       sl.d_pic_count, sl.d_status, ctx->d_qtab, ctx->d_tables->scan);
+    hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, ctx->d_pics, sl.d_pic_count, n, P, ctx->d_slice_base,
+                       sl.d_counters);
+    hipLaunchKernelGGL(k_slice_emit, dim3((n * P + 255) / 256), dim3(256), 0, sp, ctx->d_pics, ctx->d_slices_tmp,
+                       sl.d_pic_count, ctx->d_stream_off, ctx->d_slice_base, n, P, ctx->d_descs);
+    if (sl.timed)
+        EFX_HIP(hipEventRecord(sl.ev[1], sp));
     const int max_slices = n * P * kMaxSlicesPerPicture;
-    hipLaunchKernelGGL(k_parse, dim3((max_slices + 255) / 256), dim3(256), 0, st, ctx->d_es, ctx->d_descs, ctx->d_counters,
-                       ctx->d_tables, ctx->d_qtab, ctx->d_mbrecs, ctx->d_coefs, ctx->d_status, P, ctx->epoch);
-    if (ctx->timing)
-        EFX_HIP(hipEventRecord(ctx->ev[2], st));
+    hipLaunchKernelGGL(k_parse, dim3((max_slices + 255) / 256), dim3(256), 0, sp, ctx->d_es, ctx->d_descs, sl.d_counters,
+                       ctx->d_tables, ctx->d_qtab, sl.d_mbrecs, sl.d_coefs, sl.d_status, P, sl.epoch);
+    if (sl.timed)
+        EFX_HIP(hipEventRecord(sl.ev[2], sp));
+    EFX_HIP(hipEventRecord(sl.parse_done, sp));
+
+    // ---- reconstruction half (context stream): one launch per picture index ------------------------------
+    EFX_HIP(hipStreamWaitEvent(sr, sl.parse_done, 0));
+    if (sl.timed)
+        EFX_HIP(hipEventRecord(sl.ev[4], sr));
     for (int p = 0; p < P; p++)
-        hipLaunchKernelGGL(k_recon, dim3(n * kMbCount), dim3(64), 0, st, ctx->d_mbrecs, ctx->d_coefs, ctx->d_frames,
-                           ctx->d_pic_count, n, P, D, p, ctx->epoch);
-    if (ctx->timing)
-        EFX_HIP(hipEventRecord(ctx->ev[3], st));
+        hipLaunchKernelGGL(k_recon, dim3(n, kMbCount), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs, ctx->d_frames, P, D, p,
+                           (p + 1) % D, p % D, sl.epoch);
+    if (sl.timed)
+        EFX_HIP(hipEventRecord(sl.ev[3], sr));
+    EFX_HIP(hipEventRecord(sl.recon_done, sr));
     EFX_HIP(hipGetLastError());
     ctx->decoded = true;
     ctx->results_valid = false;
@@ -386,6 +435,7 @@ int efx_sync(efx_ctx* ctx)
 {
     if (!ctx)
         return EFX_ERR_ARG;
+    EFX_HIP(hipStreamSynchronize(ctx->parse_stream));
     EFX_HIP(hipStreamSynchronize(ctx->stream));
     return EFX_OK;
 }
@@ -396,12 +446,14 @@ static int fetch_results(efx_ctx* ctx)
         return fail(ctx, EFX_ERR_STATE, "no decode has run");
     if (ctx->results_valid)
         return EFX_OK;
+    EFX_HIP(hipStreamSynchronize(ctx->parse_stream));
     EFX_HIP(hipStreamSynchronize(ctx->stream));
+    const efx_ctx::Slot& sl = ctx->slot[ctx->cur];
     ctx->h_pic_count.resize(ctx->n_streams);
     ctx->h_status.resize(ctx->n_streams);
-    EFX_HIP(hipMemcpy(ctx->h_pic_count.data(), ctx->d_pic_count, ctx->n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    EFX_HIP(hipMemcpy(ctx->h_status.data(), ctx->d_status, ctx->n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    EFX_HIP(hipMemcpy(&ctx->h_counters, ctx->d_counters, sizeof(DecodeCounters), hipMemcpyDeviceToHost));
+    EFX_HIP(hipMemcpy(ctx->h_pic_count.data(), sl.d_pic_count, ctx->n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    EFX_HIP(hipMemcpy(ctx->h_status.data(), sl.d_status, ctx->n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    EFX_HIP(hipMemcpy(&ctx->h_counters, sl.d_counters, sizeof(DecodeCounters), hipMemcpyDeviceToHost));
     ctx->results_valid = true;
     return EFX_OK;
 }
@@ -545,12 +597,13 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out)
     if (r)
         return r;
     efx_timing t{};
-    if (ctx->timing) {
-        EFX_HIP(hipEventSynchronize(ctx->ev[3]));
-        EFX_HIP(hipEventElapsedTime(&t.index_ms, ctx->ev[0], ctx->ev[1]));
-        EFX_HIP(hipEventElapsedTime(&t.parse_ms, ctx->ev[1], ctx->ev[2]));
-        EFX_HIP(hipEventElapsedTime(&t.recon_ms, ctx->ev[2], ctx->ev[3]));
-        EFX_HIP(hipEventElapsedTime(&t.total_ms, ctx->ev[0], ctx->ev[3]));
+    const efx_ctx::Slot& sl = ctx->slot[ctx->cur];
+    if (sl.timed) {
+        EFX_HIP(hipEventSynchronize(sl.ev[3]));
+        EFX_HIP(hipEventElapsedTime(&t.index_ms, sl.ev[0], sl.ev[1]));
+        EFX_HIP(hipEventElapsedTime(&t.parse_ms, sl.ev[1], sl.ev[2]));
+        EFX_HIP(hipEventElapsedTime(&t.recon_ms, sl.ev[4], sl.ev[3]));
+        EFX_HIP(hipEventElapsedTime(&t.total_ms, sl.ev[0], sl.ev[3]));
     }
     for (int i = 0; i < ctx->n_streams; i++)
         t.pictures += ctx->h_pic_count[i];

@@ -127,6 +127,9 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                                                uint32_t* __restrict__ coefs, uint32_t* __restrict__ status,
                                                int max_pictures, int epoch)
 {
+    // This kernel is a few thousand long, latency-bound waves and runs next to the (many, short)
+    // reconstruction waves of the previous decode call: ask the SIMD arbiter to favour it.
+    __builtin_amdgcn_s_setprio(3);
     __shared__ SharedTables sh;
     {
         // stage the look-up tables: sizeof(ParseTables) is a multiple of 4

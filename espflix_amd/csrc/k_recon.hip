@@ -17,8 +17,6 @@
 //     player.cpp:183-236) and issues one 8-byte store into the 16-line strip layout
 //     (Frame, src/video.h:36-44).
 //
-// blockIdx = mb * n_streams + stream: all macroblocks of a stream land on XCD (stream % 8), so
-// the partial 64-byte lines written by neighbouring macroblocks merge in one L2.
 #include <hip/hip_runtime.h>
 
 #include "efx_internal.h"
@@ -29,7 +27,7 @@ namespace efx {
 namespace {
 
 constexpr int kBlkPitch = 72;   // ints per block in LDS (64 + 8 pad)
-constexpr int kLumaPitch = 24;  // bytes per staged luma row (5 dwords used)
+constexpr int kLumaPitch = 32;  // bytes per staged luma row (5 dwords used; 16-byte aligned rows)
 constexpr int kChromaPitch = 16;
 
 // one 8-point pass of the reference's scaled integer IDCT (player.cpp:938-995)
@@ -85,67 +83,74 @@ __device__ inline uint32_t avg4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) 
 
 }  // namespace
 
+// grid = (streams, 264): blockIdx.x = stream, blockIdx.y = macroblock.  The linear workgroup id is
+// y * streams + x, so with a stream count that is a multiple of 8 all macroblocks of a stream are
+// dispatched to XCD (stream % 8) and the partial 64-byte lines written by neighbouring
+// macroblocks merge in one L2.  cur_slot / ref_slot are the ring slots of this picture index.
 __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, const uint32_t* __restrict__ coefs,
-                                              uint8_t* __restrict__ frames, const uint32_t* __restrict__ pic_count,
-                                              int n_streams, int max_pictures, int ring_depth, int pic, int epoch)
+                                              uint8_t* __restrict__ frames, int max_pictures, int ring_depth, int pic,
+                                              int cur_slot, int ref_slot, int epoch)
 {
     __shared__ int cf[6 * kBlkPitch];
     __shared__ uint32_t luma_tile[17 * kLumaPitch / 4];
     __shared__ uint32_t chroma_tile[2 * 9 * kChromaPitch / 4];
+    __shared__ int zflag[8];  // per block: 1 if an entry sits at raster position 0
 
     const int lane = threadIdx.x;
-    const int s = blockIdx.x % n_streams;
-    const int mb = blockIdx.x / n_streams;
-    if ((uint32_t)pic >= pic_count[s])
-        return;
+    const int s = blockIdx.x;
+    const int mb = blockIdx.y;
 
     const MbRec rec = mbrecs[((size_t)s * max_pictures + pic) * kMbCount + mb];
     if (rec.epoch != (uint8_t)epoch)
-        return;  // macroblock not covered by any slice: the ring slot keeps its old content
+        return;  // macroblock not covered by any slice (or picture absent): the slot keeps its content
 
-    const int mb_x = mb % kMbW, mb_y = mb / kMbW;
-    uint8_t* cur = frames + ((size_t)s * ring_depth + (pic + 1) % ring_depth) * kFrameBytes;
-    const uint8_t* ref = frames + ((size_t)s * ring_depth + pic % ring_depth) * kFrameBytes;
+    const int mb_y = mb / kMbW, mb_x = mb - mb_y * kMbW;
+    uint8_t* cur = frames + ((size_t)s * ring_depth + cur_slot) * kFrameBytes;
+    const uint8_t* ref = frames + ((size_t)s * ring_depth + ref_slot) * kFrameBytes;
     const bool intra = rec.flags & 1;
 
-    int pre[7];  // exclusive prefix of the per-block entry counts
-    pre[0] = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-        pre[k + 1] = pre[k] + rec.cnt[k];
-    const int total = pre[6];
+    int pre1 = rec.cnt[0], pre2 = pre1 + rec.cnt[1], pre3 = pre2 + rec.cnt[2], pre4 = pre3 + rec.cnt[3],
+        pre5 = pre4 + rec.cnt[4];
+    const int total = pre5 + rec.cnt[5];
 
     // luma / chroma fetch geometry, predict() player.cpp:870-889
     const int X = (mb_x << 5) + rec.mvx, Y = (mb_y << 5) + rec.mvy;
     const int CX = X >> 1, CY = Y >> 1;  // chroma uses the floor of the halved POSITION
     const int x0 = X >> 1, y0 = Y >> 1, cx0 = CX >> 1, cy0 = CY >> 1;
 
+    // ---- issue the coefficient loads first (independent of the reference windows) --------------------
+    uint32_t ce = 0;
+    if (lane < total)
+        ce = coefs[rec.coef_base + lane];
+
     if (!intra) {
-        // ---- stage the reference windows ---------------------------------------------------
+        // ---- stage the reference windows in LDS --------------------------------------------------------
         const bool inside = x0 >= 0 && y0 >= 0 && x0 + 16 + (X & 1) <= EFX_FRAME_WIDTH &&
                             y0 + 16 + (Y & 1) <= EFX_FRAME_HEIGHT && cx0 >= 0 && cy0 >= 0 &&
                             cx0 + 8 + (CX & 1) <= EFX_FRAME_WIDTH / 2 && cy0 + 8 + (CY & 1) <= EFX_FRAME_HEIGHT / 2;
         if (inside) {
-            // every pixel that reaches the output is inside the picture: aligned dword loads.
-            // Rows / dwords beyond the needed window are clamped to stay inside the frame buffer;
-            // their values are never used.
-            const int xa = x0 & ~3, cxa = cx0 & ~3;
-            for (int i = lane; i < 17 * 5 + 2 * 9 * 3; i += 64) {
-                if (i < 85) {
-                    int r = i / 5, c = i - r * 5;
-                    int yy = min(y0 + r, EFX_FRAME_HEIGHT - 1);
-                    int xx = min(xa + 4 * c, EFX_FRAME_STRIDE - 4);
-                    luma_tile[r * (kLumaPitch / 4) + c] = *reinterpret_cast<const uint32_t*>(ref + luma_row_off(yy) + xx);
-                } else {
-                    int j = i - 85;
-                    int plane = 1 + j / 27;
-                    j -= (plane - 1) * 27;
-                    int r = j / 3, c = j - r * 3;
-                    int yy = min(cy0 + r, EFX_FRAME_HEIGHT / 2 - 1);
-                    int xx = min(cxa + 4 * c, EFX_FRAME_WIDTH / 2 - 4);
-                    chroma_tile[((plane - 1) * 9 + r) * (kChromaPitch / 4) + c] =
-                        *reinterpret_cast<const uint32_t*>(ref + chroma_row_off(plane, yy) + xx);
-                }
+            // Every pixel that reaches the output is inside the picture.  One lane per window row:
+            // lanes 0..16 fetch the 20 luma bytes (16 + 4) of a row, lanes 32..49 the 12 bytes of a
+            // chroma row, from 4-byte aligned addresses (the reference's _src_align copy,
+            // player.cpp:739-759).  Rows past the needed window are clamped into the frame.
+            if (lane < 17) {
+                const uint8_t* p = ref + luma_row_off(min(y0 + lane, EFX_FRAME_HEIGHT - 1)) + (x0 & ~3);
+                uint4 a = *reinterpret_cast<const uint4*>(p);
+                uint32_t b = *reinterpret_cast<const uint32_t*>(p + 16);
+                uint32_t* t = luma_tile + lane * (kLumaPitch / 4);
+                *reinterpret_cast<uint4*>(t) = a;
+                t[4] = b;
+            } else if (lane >= 32 && lane < 50) {
+                const int j = lane - 32, plane = j >= 9 ? 2 : 1, r = j >= 9 ? j - 9 : j;
+                const uint8_t* p = ref + chroma_row_off(plane, min(cy0 + r, EFX_FRAME_HEIGHT / 2 - 1));
+                const int cxa = cx0 & ~3;  // dwords beyond the row end are never used: keep them inside the row
+                uint32_t a = *reinterpret_cast<const uint32_t*>(p + cxa);
+                uint32_t b = *reinterpret_cast<const uint32_t*>(p + min(cxa + 4, EFX_FRAME_WIDTH / 2 - 4));
+                uint32_t c = *reinterpret_cast<const uint32_t*>(p + min(cxa + 8, EFX_FRAME_WIDTH / 2 - 4));
+                uint32_t* t = chroma_tile + j * (kChromaPitch / 4);
+                t[0] = a;
+                t[1] = b;
+                t[2] = c;
             }
         } else {
             // vector points outside the picture (undefined in the reference): clamp per pixel
@@ -172,51 +177,51 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     const int blk = lane >> 3, sub = lane & 7;  // lanes 0..47: (block, column) then (block, row)
     const bool worker = lane < 48;
     int my_cnt = 0;
-    if (worker) {
-        my_cnt = rec.cnt[blk];
-        if (my_cnt > 0) {
+    if (total > 0) {  // wave-uniform: macroblocks without coefficients skip the whole residual path
+        if (worker) {
+            my_cnt = rec.cnt[blk];
+            if (my_cnt > 0) {
 #pragma unroll
-            for (int j = 0; j < 9; j++)
-                cf[blk * kBlkPitch + sub * 9 + j] = 0;
+                for (int j = 0; j < 9; j++)
+                    cf[blk * kBlkPitch + sub * 9 + j] = 0;
+            }
         }
-    }
-    __syncthreads();
-    for (int i = lane; i < total; i += 64) {
-        uint32_t e = coefs[rec.coef_base + i];
-        int b = (i >= pre[1]) + (i >= pre[2]) + (i >= pre[3]) + (i >= pre[4]) + (i >= pre[5]);
-        cf[b * kBlkPitch + (e & 63)] = (int)e >> 6;
+        if (lane < 8)
+            zflag[lane] = 0;
+        __syncthreads();
+        for (int i = lane; i < total; i += 64) {
+            uint32_t e = (i < 64) ? ce : coefs[rec.coef_base + i];
+            int b = (i >= pre1) + (i >= pre2) + (i >= pre3) + (i >= pre4) + (i >= pre5);
+            cf[b * kBlkPitch + (e & 63)] = (int)e >> 6;
+            if ((e & 63) == 0)
+                zflag[b] = 1;
+        }
     }
     __syncthreads();
 
     // A block whose only coefficient sits at scan position 0 takes the reference's "n == 1"
     // shortcut (player.cpp:1133-1140): dc = b[0] >> 8 (floor), no IDCT; for intra blocks the
     // byte is replicated WITHOUT the 0..248 clamp (copy_block_dc, player.cpp:1175-1187).
-    bool dc_only = false;
-    int dc = 0;
-    if (worker && my_cnt == 1) {
-        uint32_t e = coefs[rec.coef_base + pre[blk]];
-        if ((e & 63) == 0) {
-            dc_only = true;
-            dc = ((int)e >> 6) >> 8;
-        }
-    }
-    const bool full = worker && my_cnt > 0 && !dc_only;
+    const bool dc_only = my_cnt == 1 && zflag[blk] != 0;
+    const bool full = my_cnt > 0 && !dc_only;
 
     // ---- column pass ---------------------------------------------------------------------------
-    if (full) {
-        int* c = cf + blk * kBlkPitch + sub;
-        int v0 = c[0], v1 = c[8], v2 = c[16], v3 = c[24], v4 = c[32], v5 = c[40], v6 = c[48], v7 = c[56];
-        idct8(v0, v1, v2, v3, v4, v5, v6, v7);
-        c[0] = v0;
-        c[8] = v1;
-        c[16] = v2;
-        c[24] = v3;
-        c[32] = v4;
-        c[40] = v5;
-        c[48] = v6;
-        c[56] = v7;
+    if (total > 0) {
+        if (full) {
+            int* c = cf + blk * kBlkPitch + sub;
+            int v0 = c[0], v1 = c[8], v2 = c[16], v3 = c[24], v4 = c[32], v5 = c[40], v6 = c[48], v7 = c[56];
+            idct8(v0, v1, v2, v3, v4, v5, v6, v7);
+            c[0] = v0;
+            c[8] = v1;
+            c[16] = v2;
+            c[24] = v3;
+            c[32] = v4;
+            c[40] = v5;
+            c[48] = v6;
+            c[56] = v7;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     if (!worker)
         return;
@@ -237,15 +242,15 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         r6 = (r6 + 128) >> 8;
         r7 = (r7 + 128) >> 8;
     } else if (dc_only)
-        r0 = r1 = r2 = r3 = r4 = r5 = r6 = r7 = dc;
+        r0 = r1 = r2 = r3 = r4 = r5 = r6 = r7 = cf[blk * kBlkPitch] >> 8;
 
     // destination of this lane's 8 pixels (block(), player.cpp:1124-1131)
     const int row = sub;
     int dst_off;
     if (blk < 4)
-        dst_off = luma_row_off(mb_y * 16 + (blk >> 1) * 8 + row) + mb_x * 16 + (blk & 1) * 8;
+        dst_off = mb_y * kStripBytes + ((blk >> 1) * 8 + row) * kStride + mb_x * 16 + (blk & 1) * 8;
     else
-        dst_off = chroma_row_off(blk - 3, mb_y * 8 + row) + mb_x * 8;
+        dst_off = mb_y * kStripBytes + ((blk - 4) * 8 + row) * kStride + EFX_FRAME_WIDTH + mb_x * 8;
     uint2* dst = reinterpret_cast<uint2*>(cur + dst_off);
 
     if (intra) {
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             return;  // block abandoned by the parser: nothing is stored (player.cpp:1106-1107)
         uint32_t lo, hi;
         if (dc_only) {
-            uint32_t w = (uint32_t)dc;
+            uint32_t w = (uint32_t)r0;
             w |= w << 8;
             w |= w << 16;
             lo = hi = w;
@@ -288,28 +293,28 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         const int w0 = col >> 2, sh = col & 3;
         // 12 bytes starting at the dword holding `col`, for this row and the next
         uint32_t a0 = t[w0], a1 = t[w0 + 1], a2 = t[w0 + 2];
-        uint32_t b0 = t[pitch + w0], b1 = t[pitch + w0 + 1], b2 = t[pitch + w0 + 2];
-        // pixels col..col+7 and col+1..col+8
+        // pixels col..col+7; pixel col+8 is byte `sh` of the third dword
         uint32_t A_lo = __builtin_amdgcn_alignbit(a1, a0, sh * 8), A_hi = __builtin_amdgcn_alignbit(a2, a1, sh * 8);
-        uint32_t B_lo = __builtin_amdgcn_alignbit(b1, b0, sh * 8), B_hi = __builtin_amdgcn_alignbit(b2, b1, sh * 8);
-        // pixel col + 8 is byte `sh` of the third dword
-        uint32_t A9, B9;
-        A9 = (a2 >> (sh * 8)) & 0xFF;
-        B9 = (b2 >> (sh * 8)) & 0xFF;
-        uint32_t A1_lo = (A_lo >> 8) | (A_hi << 24), A1_hi = (A_hi >> 8) | (A9 << 24);
-        uint32_t B1_lo = (B_lo >> 8) | (B_hi << 24), B1_hi = (B_hi >> 8) | (B9 << 24);
-        if (!hx && !hy) {
-            p_lo = A_lo;
-            p_hi = A_hi;
-        } else if (hx && !hy) {
-            p_lo = avg_up(A_lo, A1_lo);
-            p_hi = avg_up(A_hi, A1_hi);
-        } else if (!hx) {
-            p_lo = avg_up(A_lo, B_lo);
-            p_hi = avg_up(A_hi, B_hi);
+        if (!hy) {
+            if (!hx) {
+                p_lo = A_lo;
+                p_hi = A_hi;
+            } else {
+                uint32_t A9 = (a2 >> (sh * 8)) & 0xFF;
+                p_lo = avg_up(A_lo, (A_lo >> 8) | (A_hi << 24));
+                p_hi = avg_up(A_hi, (A_hi >> 8) | (A9 << 24));
+            }
         } else {
-            p_lo = avg4(A_lo, A1_lo, B_lo, B1_lo);
-            p_hi = avg4(A_hi, A1_hi, B_hi, B1_hi);
+            uint32_t b0 = t[pitch + w0], b1 = t[pitch + w0 + 1], b2 = t[pitch + w0 + 2];
+            uint32_t B_lo = __builtin_amdgcn_alignbit(b1, b0, sh * 8), B_hi = __builtin_amdgcn_alignbit(b2, b1, sh * 8);
+            if (!hx) {
+                p_lo = avg_up(A_lo, B_lo);
+                p_hi = avg_up(A_hi, B_hi);
+            } else {
+                uint32_t A9 = (a2 >> (sh * 8)) & 0xFF, B9 = (b2 >> (sh * 8)) & 0xFF;
+                p_lo = avg4(A_lo, (A_lo >> 8) | (A_hi << 24), B_lo, (B_lo >> 8) | (B_hi << 24));
+                p_hi = avg4(A_hi, (A_hi >> 8) | (A9 << 24), B_hi, (B_hi >> 8) | (B9 << 24));
+            }
         }
     }
 
