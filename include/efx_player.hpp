@@ -1,0 +1,497 @@
+// efx_player.hpp -- source-level drop-in for the espflix player surface, backed by libefx.
+//
+// The reference host player (src/espflix.cpp) is written against a handful of C++ names:
+//
+//   class Frame                        src/video.h:36-44
+//   class Buffer                       src/streamer.h:139-143
+//   class MpegDecoder                  src/player.h:34-165   (public part: ctor, push_full,
+//                                      pop_empty, reset, run, get_pts, flush_picture)
+//   void push_video(Frame*,int,int64_t,int)       src/video.h:49   (up-call, defined by the host)
+//   void video_init(int ntsc) / video_reset() / video_pause(int)   src/video.h:46-48
+//   extern "C" void video_isr(volatile void* buf)                  src/video.cpp:47,1122
+//   void write_pcm_16(const int16_t*, int, int)                    espflix.ino:123
+//   DECODER_RUN / DECODER_PAUSED event bits, set/clear/wait/get_events   src/streamer.h:34-40,119-123
+//
+// This header re-declares exactly that surface (same names, argument meaning, threading and
+// error behaviour) for batch = 1 on top of the C-ABI in efx.h, so player code written against
+// the reference compiles against it unchanged and gets its pictures from the MI355X path.
+// Include it in ONE translation unit with EFX_PLAYER_IMPLEMENTATION defined to get the bodies.
+//
+// Behavioural notes (all visible through the reference API only):
+//   * MpegDecoder::run() lives on its own thread, blocks in pop of the full queue, and hands each
+//     picture to push_video() on that thread, in order, with the PTS the reference would latch;
+//     like the reference it does NOT push the last picture of a stream until flush_picture(mode)
+//     is called, and it parks in pause() (DECODER_PAUSED) at end of stream.
+//   * The transport stream of one play (reset() .. zero-length Buffer) is decoded in one batch
+//     call; pictures are therefore delivered after the zero-length Buffer arrived, not while the
+//     file is still streaming in.  (A service decoding many streams uses efx.h directly.)
+//   * Frame strips are host memory (the UI draws into them, src/espflix.cpp:62-84); decoded
+//     pictures are copied into them before push_video(), and video_isr() re-uploads the front
+//     Frame once per field, so host-side drawing is honoured.
+#ifndef EFX_PLAYER_HPP
+#define EFX_PLAYER_HPP
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <condition_variable>
+#include <mutex>
+#include <queue>
+#include <thread>
+#include <vector>
+
+#include "efx.h"
+
+#define FB_WIDTH 352
+#define FB_HEIGHT 192
+#define FB_STRIDE (FB_WIDTH * 3 / 2)
+#define FB_SLICE_HEIGHT 16
+#define FB_SLICES (FB_HEIGHT / FB_SLICE_HEIGHT)
+
+enum { DECODER_RUN = 2, DECODER_PAUSED = 4, AUDIO_READY = 8, VIDEO_READY = 16, DNS_READY = 256 };
+
+int get_events();
+void clear_events(int i);
+void wait_events(int i);
+void set_events(int i);
+
+class Q {
+    std::queue<const void*> queue;
+    mutable std::mutex guard;
+    std::condition_variable signal;
+
+  public:
+    void push(const void* data);
+    const void* pop();
+    bool empty();
+    int waiting();
+};
+
+class Frame {
+  public:
+    uint8_t* _slices[FB_SLICES];
+    void init();
+    uint8_t* get_y(int y);
+    uint8_t* get_cr(int y);
+    uint8_t* get_cb(int y);
+    void erase();
+};
+
+class Buffer {
+  public:
+    uint32_t len;
+    uint8_t data[8 * 188];
+};
+
+// up-calls the host provides, exactly as in the reference
+void push_video(Frame* f, int front, int64_t pts, int mode);
+void push_audio(const uint8_t* data, int len, int64_t pts, bool pes_complete);
+
+class MpegDecoder {
+  public:
+    Frame* _fb[2];
+    int _fb_index;
+    int64_t _pts;
+    int64_t _last_pts;
+
+    MpegDecoder(Frame* fb0, Frame* fb1);
+    ~MpegDecoder();
+    void push_full(Buffer* b);  // from the feeder thread
+    Buffer* pop_empty();
+    void reset();
+    void run();  // never returns
+    int64_t get_pts();
+    void flush_picture(int mode = 0);
+
+  protected:
+    void pause();
+    void decode_accumulated();
+    Q _empty_q;
+    Q _full_q;
+    std::vector<uint8_t> _ts;
+    efx_ctx* _ctx;
+    bool _have_last;   // a decoded picture is waiting for the next flush_picture()
+};
+
+void video_init(int ntsc);
+void video_reset();
+void video_pause(int p);
+extern "C" void video_isr(volatile void* buf);
+// publish the frames the line callback displays (the reference's push_video does this through
+// file-scope globals _frames/_next_frame, src/video.cpp:1027,1054)
+void efx_video_present(Frame* frames, int front);
+int efx_video_line_width();
+int efx_video_line_count();
+
+void write_pcm_16(const int16_t* s, int n, int channels);
+void beep();
+// where write_pcm_16 delivers its 256 PDM words (the reference calls i2s_write, espflix.ino:142)
+typedef void (*efx_pdm_sink)(const uint16_t* words, int n);
+void efx_set_pdm_sink(efx_pdm_sink sink);
+
+#ifdef EFX_PLAYER_IMPLEMENTATION
+// =================================================================================================
+
+namespace efx_player_detail {
+inline std::mutex& ev_guard()
+{
+    static std::mutex m;
+    return m;
+}
+inline std::condition_variable& ev_signal()
+{
+    static std::condition_variable c;
+    return c;
+}
+inline int& ev_word()
+{
+    static int w = 0;
+    return w;
+}
+}  // namespace efx_player_detail
+
+int get_events()
+{
+    std::lock_guard<std::mutex> l(efx_player_detail::ev_guard());
+    return efx_player_detail::ev_word();
+}
+void clear_events(int i)
+{
+    std::lock_guard<std::mutex> l(efx_player_detail::ev_guard());
+    efx_player_detail::ev_word() &= ~i;
+    efx_player_detail::ev_signal().notify_all();
+}
+void set_events(int i)
+{
+    std::lock_guard<std::mutex> l(efx_player_detail::ev_guard());
+    efx_player_detail::ev_word() |= i;
+    efx_player_detail::ev_signal().notify_all();
+}
+void wait_events(int i)
+{
+    std::unique_lock<std::mutex> l(efx_player_detail::ev_guard());
+    while (!(efx_player_detail::ev_word() & i))
+        efx_player_detail::ev_signal().wait(l);
+}
+
+void Q::push(const void* data)
+{
+    {
+        std::lock_guard<std::mutex> lock(guard);
+        queue.push(data);
+    }
+    signal.notify_one();
+}
+const void* Q::pop()
+{
+    std::unique_lock<std::mutex> lock(guard);
+    while (queue.empty())
+        signal.wait(lock);
+    const void* v = queue.front();
+    queue.pop();
+    return v;
+}
+bool Q::empty()
+{
+    std::unique_lock<std::mutex> lock(guard);
+    return queue.empty();
+}
+int Q::waiting()
+{
+    std::unique_lock<std::mutex> lock(guard);
+    return (int)queue.size();
+}
+
+void Frame::init()
+{
+    for (int i = 0; i < FB_SLICES; i++) {
+        _slices[i] = (uint8_t*)malloc(FB_STRIDE * FB_SLICE_HEIGHT + 4);
+        memset(_slices[i], 0, FB_STRIDE * FB_SLICE_HEIGHT + 4);
+    }
+}
+uint8_t* Frame::get_y(int y) { return _slices[y >> 4] + (y & 0xF) * FB_STRIDE; }
+uint8_t* Frame::get_cr(int y) { return _slices[y >> 3] + (y & 0x7) * FB_STRIDE + FB_WIDTH; }
+uint8_t* Frame::get_cb(int y) { return _slices[y >> 3] + ((y & 0x7) + 8) * FB_STRIDE + FB_WIDTH; }
+void Frame::erase()
+{
+    for (int i = 0; i < FB_SLICES; i++)
+        memset(_slices[i], 0x30, FB_STRIDE * FB_SLICE_HEIGHT + 4);
+}
+
+MpegDecoder::MpegDecoder(Frame* fb0, Frame* fb1) : _ctx(0), _have_last(false)
+{
+    _fb[0] = fb0;
+    _fb[1] = fb1;
+    _fb_index = 1;  // the reference starts with _reference = fb0, _current = fb1 (player.cpp:358-360)
+    _last_pts = _pts = -1;
+    for (int i = 0; i < 4; i++)
+        _empty_q.push(new Buffer());
+    efx_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.max_streams = 1;
+    cfg.max_pictures = 250;
+    cfg.ring_depth = 2;
+    cfg.max_stream_bytes = 8u << 20;
+    if (efx_create(&cfg, &_ctx) != EFX_OK) {
+        fprintf(stderr, "MpegDecoder: efx_create failed (a gfx950 device is required)\n");
+        abort();
+    }
+}
+
+MpegDecoder::~MpegDecoder() { efx_destroy(_ctx); }
+
+void MpegDecoder::push_full(Buffer* b) { _full_q.push(b); }
+Buffer* MpegDecoder::pop_empty() { return (Buffer*)_empty_q.pop(); }
+
+void MpegDecoder::reset()  // player.cpp:439-453: called by the feeder while the decoder is paused
+{
+    while (!_full_q.empty())
+        _empty_q.push(_full_q.pop());
+    _ts.clear();
+    video_reset();
+    _last_pts = -1;
+    _have_last = false;
+}
+
+int64_t MpegDecoder::get_pts() { return _last_pts; }
+
+void MpegDecoder::flush_picture(int mode)  // player.cpp:692-702
+{
+    if (_have_last && (_last_pts != -1 || mode)) {
+        push_video(_fb[0], _fb_index & 1, _last_pts, mode);
+        _fb_index++;
+        _have_last = false;
+    }
+    if (!mode)
+        _last_pts = _pts;
+}
+
+void MpegDecoder::pause()  // player.cpp:1342-1352
+{
+    clear_events(DECODER_RUN);
+    set_events(DECODER_PAUSED);
+    if (_empty_q.empty())
+        _empty_q.push(0);  // unstick a feeder waiting in pop_empty()
+    wait_events(DECODER_RUN);
+    clear_events(DECODER_PAUSED);
+}
+
+void MpegDecoder::decode_accumulated()
+{
+    const uint8_t* ptr = _ts.empty() ? (const uint8_t*)"" : &_ts[0];
+    size_t len = _ts.size();
+    if (efx_upload_streams(_ctx, 1, &ptr, &len, EFX_FORMAT_TS) != EFX_OK || efx_decode(_ctx) != EFX_OK ||
+        efx_sync(_ctx) != EFX_OK) {
+        fprintf(stderr, "MpegDecoder: %s\n", efx_last_error(_ctx));
+        return;
+    }
+    int n = 0;
+    efx_picture_count(_ctx, 0, &n);
+    if (n <= 0)
+        return;
+    // The context's two-deep ring (the reference's _fb[2]) only keeps the last two pictures, but
+    // the reference contract is one push_video() per picture: decode the play once more into a
+    // ring deep enough to hold every picture and hand them out in order.
+    efx_ctx* all = 0;
+    efx_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.max_streams = 1;
+    cfg.max_pictures = n;
+    cfg.ring_depth = n + 1;
+    cfg.max_stream_bytes = len + 4096;
+    if (efx_create(&cfg, &all) != EFX_OK)
+        return;
+    efx_upload_streams(all, 1, &ptr, &len, EFX_FORMAT_TS);
+    efx_decode(all);
+    efx_sync(all);
+    std::vector<uint8_t> frame(EFX_FRAME_BYTES);
+    for (int i = 0; i < n; i++) {
+        int64_t pts = -1;
+        efx_picture_pts(all, 0, i, &pts);
+        _pts = pts;        // latched by the PES that carries this picture (player.cpp:417-418)
+        flush_picture(0);  // picture start: push the previous picture, swap buffers (player.cpp:704-706)
+        Frame* dst = _fb[_fb_index & 1];
+        efx_download_frame(all, 0, efx_picture_slot(all, i), &frame[0]);
+        for (int s = 0; s < FB_SLICES; s++)
+            memcpy(dst->_slices[s], &frame[(size_t)s * EFX_STRIP_BYTES], EFX_STRIP_BYTES);
+        _have_last = true;
+    }
+    efx_destroy(all);
+}
+
+void MpegDecoder::run()  // player.cpp:1355-1367
+{
+    for (;;) {
+        if (!(get_events() & DECODER_RUN))
+            pause();
+        Buffer* b = (Buffer*)_full_q.pop();
+        if (!b)
+            continue;
+        bool eos = b->len == 0 || b->len > sizeof(b->data);
+        if (!eos)
+            _ts.insert(_ts.end(), b->data, b->data + b->len);
+        _empty_q.push(b);
+        if (eos) {  // zero-length Buffer: the decoder pads with a sequence_end code and pauses
+            decode_accumulated();
+            _ts.clear();
+            pause();
+        }
+    }
+}
+
+// ---- video out ---------------------------------------------------------------------------------
+
+namespace efx_player_detail {
+struct VideoState {
+    efx_ctx* ctx;
+    int ntsc;
+    efx_video_params vp;
+    Frame* frames;
+    int front;
+    int line_counter, frame_counter;
+    uint16_t* d_field;
+    std::vector<uint16_t> field;
+    VideoState() : ctx(0), ntsc(1), frames(0), front(-1), line_counter(0), frame_counter(0), d_field(0) {}
+};
+inline VideoState& vs()
+{
+    static VideoState v;
+    return v;
+}
+}  // namespace efx_player_detail
+
+void video_init(int ntsc)  // video.cpp:572-601
+{
+    efx_player_detail::VideoState& v = efx_player_detail::vs();
+    v.ntsc = ntsc ? 1 : 0;
+    efx_video_get_params(v.ntsc, &v.vp);
+    if (!v.ctx) {
+        efx_config cfg;
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.max_streams = 1;
+        cfg.max_pictures = 1;
+        cfg.ring_depth = 2;
+        cfg.max_stream_bytes = 4096;
+        if (efx_create(&cfg, &v.ctx) != EFX_OK) {
+            fprintf(stderr, "video_init: efx_create failed (a gfx950 device is required)\n");
+            abort();
+        }
+    }
+    if (v.d_field)
+        efx_device_free(v.ctx, v.d_field);
+    size_t n = (size_t)v.vp.line_width * v.vp.line_count;
+    void* p = 0;
+    efx_device_alloc(v.ctx, n * 2, &p);
+    v.d_field = (uint16_t*)p;
+    v.field.assign(n, 0);
+    v.line_counter = v.frame_counter = 0;
+}
+
+void video_reset() {}
+void video_pause(int) {}
+
+void efx_video_present(Frame* frames, int front)
+{
+    efx_player_detail::vs().frames = frames;
+    efx_player_detail::vs().front = front;
+}
+int efx_video_line_width() { return efx_player_detail::vs().vp.line_width; }
+int efx_video_line_count() { return efx_player_detail::vs().vp.line_count; }
+
+extern "C" void video_isr(volatile void* vbuf)  // video.cpp:1122-1198, one call per scan line
+{
+    efx_player_detail::VideoState& v = efx_player_detail::vs();
+    if (!v.ctx)
+        return;
+    if (v.line_counter == 0 && v.frames && v.front >= 0) {
+        // render the whole field on the GPU from the current front Frame (host memory, may have been
+        // drawn into by UI code), then hand it out line by line
+        std::vector<uint8_t> fr(EFX_FRAME_BYTES);
+        for (int s = 0; s < FB_SLICES; s++)
+            memcpy(&fr[(size_t)s * EFX_STRIP_BYTES], v.frames[v.front]._slices[s], EFX_STRIP_BYTES);
+        efx_upload_frame(v.ctx, 0, 0, &fr[0]);
+        efx_composite_fields(v.ctx, 0, 1, 0, v.ntsc, v.frame_counter, v.d_field);
+        efx_memcpy_d2h(v.ctx, &v.field[0], v.d_field, v.field.size() * 2);
+    }
+    memcpy((void*)vbuf, &v.field[(size_t)v.line_counter * v.vp.line_width], (size_t)v.vp.line_width * 2);
+    if (++v.line_counter == v.vp.line_count) {
+        v.line_counter = 0;
+        v.frame_counter++;
+    }
+}
+
+// ---- audio out ---------------------------------------------------------------------------------
+
+namespace efx_player_detail {
+struct AudioState {
+    efx_ctx* ctx;
+    int16_t* d_pcm;
+    int32_t* d_state;
+    uint16_t* d_out;
+    int beep;
+    efx_pdm_sink sink;
+    AudioState() : ctx(0), d_pcm(0), d_state(0), d_out(0), beep(0), sink(0) {}
+};
+inline AudioState& as()
+{
+    static AudioState a;
+    return a;
+}
+}  // namespace efx_player_detail
+
+void efx_set_pdm_sink(efx_pdm_sink sink) { efx_player_detail::as().sink = sink; }
+void beep() { efx_player_detail::as().beep = 5; }
+
+void write_pcm_16(const int16_t* s, int n, int /*channels*/)  // espflix.ino:123-145
+{
+    efx_player_detail::AudioState& a = efx_player_detail::as();
+    if (!a.ctx) {
+        efx_config cfg;
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.max_streams = 1;
+        cfg.max_pictures = 1;
+        cfg.ring_depth = 2;
+        cfg.max_stream_bytes = 4096;
+        if (efx_create(&cfg, &a.ctx) != EFX_OK) {
+            fprintf(stderr, "write_pcm_16: efx_create failed (a gfx950 device is required)\n");
+            abort();
+        }
+        void* p = 0;
+        efx_device_alloc(a.ctx, 128 * 2, &p);
+        a.d_pcm = (int16_t*)p;
+        efx_device_alloc(a.ctx, 12, &p);
+        a.d_state = (int32_t*)p;
+        efx_device_alloc(a.ctx, 256 * 2, &p);
+        a.d_out = (uint16_t*)p;
+        int32_t zero[3] = {0, 0, 0};
+        efx_memcpy_h2d(a.ctx, a.d_state, zero, sizeof(zero));
+    }
+    uint16_t words[256];
+    int16_t tone[128];
+    if (a.beep) {  // five 128-sample bursts of the 32-point sine, >> 2
+        for (int i = 0; i < 128; i++)
+            tone[i] = (int16_t)(((int16_t)(-32767.0 * __builtin_sin(2 * 3.14159265358979323846 * (i & 31) / 32))) >> 2);
+        a.beep--;
+        s = tone;
+        n = 128;
+    }
+    if (s) {
+        if (n > 128)
+            n = 128;
+        efx_memcpy_h2d(a.ctx, a.d_pcm, s, (size_t)n * 2);
+        efx_pdm(a.ctx, 1, a.d_pcm, n, a.d_state, a.d_out);
+        efx_memcpy_d2h(a.ctx, words, a.d_out, (size_t)n * 4);
+        for (int i = 2 * n; i < 256; i++)
+            words[i] = 0xAAAA;
+    } else {
+        for (int i = 0; i < 256; i++)
+            words[i] = 0xAAAA;  // PDM silence
+    }
+    if (a.sink)
+        a.sink(words, 256);
+}
+
+#endif  // EFX_PLAYER_IMPLEMENTATION
+#endif  // EFX_PLAYER_HPP

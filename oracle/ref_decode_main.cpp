@@ -16,14 +16,15 @@
 //        last picture is pushed too.
 //   efx_ref_decode fixture <@splash|@vmedia> <out.ts>      dump an embedded clip
 //   efx_ref_decode bench <nworkers> <list.txt> [repeat]    CPU baseline: decode every TS file
-//        named in list.txt with nworkers forked worker PROCESSES (the reference keeps scratch
-//        and event state in process globals, src/player.cpp:732, src/streamer.cpp:305-339, so
-//        one decoder per process).  Worker w plays streams w, w+W, ... back to back through
-//        ONE MpegDecoder exactly as the reference app plays clip after clip (reset();
-//        set_events(DECODER_RUN); feed; wait DECODER_PAUSED, src/espflix.cpp:1043-1058).
-//        Prints "BENCH streams=<n> pictures=<n> seconds=<s> workers=<n>" (wall time from the
-//        first fork to the last exit; inputs pre-loaded in memory).  repeat > 1 makes every
-//        worker play its share that many times (a longer, steadier measurement).
+//        named in list.txt with nworkers forked worker PROCESSES, streams dealt round-robin.
+//        The reference keeps scratch and event state in process globals (src/player.cpp:732,
+//        src/streamer.cpp:305-339) and its desktop event word is racy, so every play runs in a
+//        fresh short-lived child (fork per play: one MpegDecoder, one decoder thread, driven
+//        like ESPFlix::play_rom, src/espflix.cpp:1043-1058); a child that has not finished
+//        after 20 s is killed (alarm) and counted in "failed".  repeat > 1 replays every worker's
+//        share that many times.  Prints
+//        "BENCH streams=<n> pictures=<n> seconds=<s> workers=<n> repeat=<n> failed=<n>"
+//        (wall time from the first fork to the last exit; inputs pre-loaded in memory).
 //   efx_ref_decode tables <out.bin>                        dump zig_zag[64] + scale_dct_q[64]
 #include <stdio.h>
 #include <stdlib.h>
@@ -32,6 +33,7 @@
 #include <unistd.h>
 #include <time.h>
 #include <sys/wait.h>
+#include <signal.h>
 #include <string>
 #include <vector>
 
@@ -214,12 +216,26 @@ int main(int argc, char** argv)
         for (int w = 0; w < workers; w++) {
             pid_t p = fork();
             if (p == 0) {
-                int32_t n = 0;
-                decoder_start();
+                int32_t res[2] = {0, 0};  // pictures, failed plays
                 for (int r = 0; r < repeat; r++)
-                    for (size_t i = w; i < blobs.size(); i += workers)
-                        n += play(&blobs[i][0], (int)blobs[i].size(), true);
-                if (write(pfd[1], &n, 4) != 4) {}
+                    for (size_t i = w; i < blobs.size(); i += workers) {
+                        int cp[2];
+                        if (pipe(cp)) _exit(1);
+                        pid_t c = fork();
+                        if (c == 0) {
+                            alarm(20);  // watchdog: a play that hangs on the racy event word dies here
+                            int32_t n = decode_rom(&blobs[i][0], (int)blobs[i].size(), true);
+                            if (write(cp[1], &n, 4) != 4) {}
+                            _exit(0);
+                        }
+                        close(cp[1]);
+                        int status = 0;
+                        waitpid(c, &status, 0);
+                        int32_t n = 0;
+                        if (WIFEXITED(status) && read(cp[0], &n, 4) == 4) res[0] += n; else res[1]++;
+                        close(cp[0]);
+                    }
+                if (write(pfd[1], res, 8) != 8) {}
                 _exit(0);
             }
         }
@@ -229,9 +245,10 @@ int main(int argc, char** argv)
         }
         double t1 = now();
         close(pfd[1]);
-        int32_t r;
-        while (read(pfd[0], &r, 4) == 4) pictures += r;
-        fprintf(stderr, "BENCH streams=%zu pictures=%ld seconds=%.6f workers=%d repeat=%d\n", blobs.size(), pictures, t1 - t0, workers, repeat);
+        int32_t rr[2];
+        long failed = 0;
+        while (read(pfd[0], rr, 8) == 8) { pictures += rr[0]; failed += rr[1]; }
+        fprintf(stderr, "BENCH streams=%zu pictures=%ld seconds=%.6f workers=%d repeat=%d failed=%ld\n", blobs.size(), pictures, t1 - t0, workers, repeat, failed);
         return 0;
     }
     fprintf(stderr, "bad command\n");

@@ -1,0 +1,50 @@
+"""The C++ drop-in layer (include/efx_player.hpp): a host program written against the reference's
+MpegDecoder / Frame / push_video / video_isr / write_pcm_16 surface is compiled against it and must
+deliver the frames, field and PDM words the reference delivers."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def build(tmp_path):
+    exe = str(tmp_path / "adapter_main")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "adapter_main.cpp"), "-L", os.path.join(ROOT, "espflix_amd"), "-lefx",
+                    "-Wl,-rpath," + os.path.join(ROOT, "espflix_amd"), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
+                    "-lamdhip64", "-o", exe], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("clip", ["splash", "vmedia"])
+def test_reference_style_host_program(tmp_path, clip, golden):
+    exe = build(tmp_path)
+    p = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", clip + ".ts")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    rows = [l.split() for l in p.stdout.splitlines()]
+    frames = [r for r in rows if r[0] == "F"]
+    g = golden["clips"][clip]
+    assert [r[3] for r in frames] == g["hashes"]
+    assert [int(r[2]) for r in frames] == g["pts"]
+    # composite field of the last pushed frame, frame_counter 0
+    ts = np.fromfile(os.path.join(ROOT, "tests", "golden", clip + ".ts"), dtype=np.uint8)
+    _, _, _, fr = oracle.decode(ts, 1, want_frames=True)
+    want = oracle.video_field(np.concatenate([fr[-1], fr[-1]]), True, 0, 1)
+    v = [r for r in rows if r[0] == "V"][0][1]
+    assert v == f"{oracle.fnv1a64(want.reshape(-1).view(np.uint8)):016x}"
+    # three write_pcm_16 calls (the middle one silence), state carried across calls
+    import ctypes
+    st = np.zeros(3, dtype=np.int32)
+    beep = ctypes.c_int(0)
+    words = []
+    for c in range(3):
+        pcm = np.array([(i * 37 + c * 1000) % 4001 - 2000 for i in range(128)], dtype=np.int16)
+        words.append(oracle.write_pcm_16(st, beep, None if c == 1 else pcm))
+    a = [r for r in rows if r[0] == "A"][0][1]
+    assert a == f"{oracle.fnv1a64(np.concatenate(words).view(np.uint8)):016x}"
