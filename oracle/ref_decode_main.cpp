@@ -16,13 +16,14 @@
 //        last picture is pushed too.
 //   efx_ref_decode fixture <@splash|@vmedia> <out.ts>      dump an embedded clip
 //   efx_ref_decode bench <nworkers> <list.txt> [repeat]    CPU baseline: decode every TS file
-//        named in list.txt with nworkers forked worker PROCESSES, streams dealt round-robin.
-//        The reference keeps scratch and event state in process globals (src/player.cpp:732,
-//        src/streamer.cpp:305-339) and its desktop event word is racy, so every play runs in a
-//        fresh short-lived child (fork per play: one MpegDecoder, one decoder thread, driven
-//        like ESPFlix::play_rom, src/espflix.cpp:1043-1058); a child that has not finished
-//        after 20 s is killed (alarm) and counted in "failed".  repeat > 1 replays every worker's
-//        share that many times.  Prints
+//        named in list.txt with nworkers forked worker PROCESSES (the reference keeps scratch
+//        and event state in process globals, src/player.cpp:732, src/streamer.cpp:305-339: one
+//        decoder per process), streams dealt round-robin.  Each worker drives ONE MpegDecoder
+//        through ONE play: its streams (x repeat) are fed back to back as a single transport
+//        stream -- every stream opens with a sequence header and an I picture, so the decoder
+//        simply keeps going, as it does across GOPs of a long file -- and a single zero-length
+//        Buffer ends it.  That avoids the reference's racy pause/resume hand-shake between
+//        plays and measures decoding, not process creation.  Prints
 //        "BENCH streams=<n> pictures=<n> seconds=<s> workers=<n> repeat=<n> failed=<n>"
 //        (wall time from the first fork to the last exit; inputs pre-loaded in memory).
 //   efx_ref_decode tables <out.bin>                        dump zig_zag[64] + scale_dct_q[64]
@@ -216,37 +217,48 @@ int main(int argc, char** argv)
         for (int w = 0; w < workers; w++) {
             pid_t p = fork();
             if (p == 0) {
-                int32_t res[2] = {0, 0};  // pictures, failed plays
+                alarm(600);  // watchdog
+                g_fb[0].init();
+                g_fb[1].init();
+                g_dec = new MpegDecoder(&g_fb[0], &g_fb[1]);
+                g_dec->reset();
+                set_events(DECODER_RUN);
+                start_thread(decoder_thread, 0);
                 for (int r = 0; r < repeat; r++)
                     for (size_t i = w; i < blobs.size(); i += workers) {
-                        int cp[2];
-                        if (pipe(cp)) _exit(1);
-                        pid_t c = fork();
-                        if (c == 0) {
-                            alarm(20);  // watchdog: a play that hangs on the racy event word dies here
-                            int32_t n = decode_rom(&blobs[i][0], (int)blobs[i].size(), true);
-                            if (write(cp[1], &n, 4) != 4) {}
-                            _exit(0);
+                        const uint8_t* src = &blobs[i][0];
+                        size_t left = blobs[i].size();
+                        while (left) {
+                            Buffer* b = g_dec->pop_empty();
+                            size_t n = left < sizeof(b->data) ? left : sizeof(b->data);
+                            memcpy(b->data, src, n);
+                            b->len = (uint32_t)n;
+                            g_dec->push_full(b);
+                            src += n;
+                            left -= n;
                         }
-                        close(cp[1]);
-                        int status = 0;
-                        waitpid(c, &status, 0);
-                        int32_t n = 0;
-                        if (WIFEXITED(status) && read(cp[0], &n, 4) == 4) res[0] += n; else res[1]++;
-                        close(cp[0]);
                     }
+                Buffer* b = g_dec->pop_empty();
+                b->len = 0;
+                g_dec->push_full(b);
+                while (!(get_events() & DECODER_PAUSED))
+                    usleep(50);
+                g_dec->flush_picture(1);
+                int32_t res[2] = {g_frames, 0};
                 if (write(pfd[1], res, 8) != 8) {}
                 _exit(0);
             }
         }
+        int crashed = 0;
         for (int w = 0; w < workers; w++) {
             int status;
             wait(&status);
+            if (!WIFEXITED(status)) crashed++;
         }
         double t1 = now();
         close(pfd[1]);
         int32_t rr[2];
-        long failed = 0;
+        long failed = crashed;
         while (read(pfd[0], rr, 8) == 8) { pictures += rr[0]; failed += rr[1]; }
         fprintf(stderr, "BENCH streams=%zu pictures=%ld seconds=%.6f workers=%d repeat=%d failed=%ld\n", blobs.size(), pictures, t1 - t0, workers, repeat, failed);
         return 0;
