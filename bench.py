@@ -38,12 +38,29 @@ def algorithmic_bytes(es_bytes: int, n_i: int, n_p: int) -> int:
     return es_bytes + n_i * FRAME_BYTES + n_p * 2 * FRAME_BYTES
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: CPU count, affinity mask and cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(batch, n_streams: int, n_pictures: int, budget_streams: int):
     """Time the reference decoder on this host over the first `budget_streams` streams."""
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     n = min(n_streams, budget_streams)
     ref = os.path.join(ROOT, "oracle", "_ref", "efx_ref_decode")
-    sample = f"first {n} of the {n_streams} streams x {n_pictures} pictures, TS-wrapped (PID 0x100), {cores} worker processes"
+    sample = (f"first {n} of the {n_streams} streams x {n_pictures} pictures, TS-wrapped (PID 0x100), {cores} worker "
+              f"processes = usable host cores (os.cpu_count() {os.cpu_count()}, cgroup/affinity limit {cores})")
     if os.path.exists(ref):
         with tempfile.TemporaryDirectory() as td:
             lst = os.path.join(td, "list.txt")
@@ -53,7 +70,7 @@ def cpu_baseline(batch, n_streams: int, n_pictures: int, budget_streams: int):
                     batch.ts(i).tofile(path)
                     f.write(path + "\n")
             # aim at ~5 s of wall time on all cores (the reference does ~2-4 k frames/s/core)
-            repeat = max(1, int(4.0 * cores * 1500 / (n * n_pictures)))
+            repeat = max(1, int(5.0 * cores * 3000 / (n * n_pictures)))
             try:
                 p = subprocess.run([ref, "bench", str(cores), lst, str(repeat)], stderr=subprocess.PIPE,
                                    stdout=subprocess.DEVNULL, text=True, timeout=150)
@@ -115,7 +132,7 @@ def main():
     from espflix_amd import dist as edist
     first, S = edist.shard(rank, world, args.streams)
     P = args.pictures
-    threads = max(1, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    threads = max(1, usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     t_gen = time.perf_counter()
     batch = gen.Batch(first, S, P, 12, 0, threads)
     streams = batch.all_es()
