@@ -34,7 +34,7 @@ STREAM_MB_OVERRUN = 16
 STREAM_COEF_OVERRUN = 32
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libefx.so")
+LIB_PATH = os.environ.get("EFX_LIB") or os.path.join(_HERE, "libefx.so")  # EFX_LIB: development builds
 
 
 class EfxError(RuntimeError):

@@ -16,17 +16,20 @@
 namespace efx {
 // kernels (k_index.hip, k_parse.hip, k_recon.hip, k_video.hip)
 __global__ void k_index(const uint8_t*, const uint64_t*, int, PicInfo*, SliceTmp*, uint32_t*, uint32_t*, uint32_t*,
-                        const uint32_t*);
-__global__ void k_slice_scan(const PicInfo*, const uint32_t*, int, int, uint32_t*, DecodeCounters*);
-__global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, const uint64_t*, const uint32_t*, int, int,
-                             SliceDesc*);
-__global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const ParseTables*, const uint32_t*, MbRec*,
-                        uint32_t*, uint32_t*, int, int);
-__global__ void k_recon(const MbRec*, const uint32_t*, uint8_t*, int, int, int, int, int, int);
+                        const uint32_t*, uint32_t*);
+__global__ void k_slice_scan(uint32_t*, uint32_t*, DecodeCounters*);
+__global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, const uint64_t*, const uint32_t*, uint32_t*,
+                             int, int, SliceDesc*);
+__global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const ParseTables*, MbRec*, uint32_t*, uint32_t*,
+                        int, int);
+__global__ void k_recon(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, int, int, int);
 __global__ void k_frame_hash(const uint8_t*, int, uint64_t*);
 __global__ void k_fill(uint32_t*, uint32_t, size_t);
 __global__ void k_composite(const uint8_t*, int, int, int, const VideoTables*, int, uint16_t*);
 __global__ void k_pdm(const int16_t*, int, int, int32_t*, uint16_t*);
+#ifdef EFX_PARSE_PROFILE
+__global__ void k_parse_set_prof(uint32_t*);
+#endif
 }  // namespace efx
 
 using namespace efx;
@@ -50,7 +53,8 @@ struct efx_ctx {
     SliceTmp* d_slices_tmp = nullptr;
     uint32_t* d_qtab = nullptr;
     ParseTables* d_tables = nullptr;
-    uint32_t* d_slice_base = nullptr;
+    uint32_t* d_slice_base = nullptr;  // per length class: first descriptor index
+    uint32_t* d_hist = nullptr;        // per length class: slice count, then emit cursor
     SliceDesc* d_descs = nullptr;
     uint8_t* d_frames = nullptr;
     // Two sets of parse -> recon hand-over buffers: efx_decode() number n parses into slot n & 1
@@ -213,7 +217,8 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     A(dalloc(&ctx->d_slices_tmp, n * P * kMaxSlicesPerPicture));
     A(dalloc(&ctx->d_qtab, n * P * 64));
     A(dalloc(&ctx->d_tables, 1));
-    A(dalloc(&ctx->d_slice_base, n * P + 1));
+    A(dalloc(&ctx->d_slice_base, (size_t)kSliceBins));
+    A(dalloc(&ctx->d_hist, (size_t)kSliceBins));
     A(dalloc(&ctx->d_descs, n * P * kMaxSlicesPerPicture));
     for (auto& sl : ctx->slot) {
         A(dalloc(&sl.d_pic_count, n));
@@ -249,6 +254,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     }
     A(hipMemset(ctx->d_frames, 0, n * D * kFrameBytes));
     A(hipMemset(ctx->d_es, 0, ctx->es_cap));
+    A(hipMemset(ctx->d_hist, 0, kSliceBins * sizeof(uint32_t)));
     for (auto& sl : ctx->slot) {
         A(hipMemset(sl.d_mbrecs, 0, n * P * kMbCount * sizeof(MbRec)));
         A(hipEventCreateWithFlags(&sl.parse_done, hipEventDisableTiming));
@@ -271,7 +277,7 @@ void efx_destroy(efx_ctx* ctx)
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     void* bufs[] = {ctx->d_es,   ctx->d_stream_off, ctx->d_pics,  ctx->d_slices_tmp, ctx->d_qtab,     ctx->d_tables,
-                    ctx->d_slice_base, ctx->d_descs, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_hash};
+                    ctx->d_slice_base, ctx->d_descs, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_hash, ctx->d_hist};
     for (void* b : bufs)
         if (b)
             (void)hipFree(b);
@@ -400,17 +406,17 @@ int efx_decode(efx_ctx* ctx)
     sl.timed = ctx->timing;
     if (sl.timed)
         EFX_HIP(hipEventRecord(sl.ev[0], sp));
+    EFX_HIP(hipMemsetAsync(ctx->d_hist, 0, kSliceBins * sizeof(uint32_t), sp));  // k_slice_emit left its cursors there
     hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, sp, ctx->d_es, ctx->d_stream_off, P, ctx->d_pics, ctx->d_slices_tmp,
-                       sl.d_pic_count, sl.d_status, ctx->d_qtab, ctx->d_tables->scan);
-    hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, ctx->d_pics, sl.d_pic_count, n, P, ctx->d_slice_base,
-                       sl.d_counters);
+                       sl.d_pic_count, sl.d_status, ctx->d_qtab, ctx->d_tables->scan, ctx->d_hist);
+    hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, ctx->d_hist, ctx->d_slice_base, sl.d_counters);
     hipLaunchKernelGGL(k_slice_emit, dim3((n * P + 255) / 256), dim3(256), 0, sp, ctx->d_pics, ctx->d_slices_tmp,
-                       sl.d_pic_count, ctx->d_stream_off, ctx->d_slice_base, n, P, ctx->d_descs);
+                       sl.d_pic_count, ctx->d_stream_off, ctx->d_slice_base, ctx->d_hist, n, P, ctx->d_descs);
     if (sl.timed)
         EFX_HIP(hipEventRecord(sl.ev[1], sp));
     const int max_slices = n * P * kMaxSlicesPerPicture;
     hipLaunchKernelGGL(k_parse, dim3((max_slices + 255) / 256), dim3(256), 0, sp, ctx->d_es, ctx->d_descs, sl.d_counters,
-                       ctx->d_tables, ctx->d_qtab, sl.d_mbrecs, sl.d_coefs, sl.d_status, P, sl.epoch);
+                       ctx->d_tables, sl.d_mbrecs, sl.d_coefs, sl.d_status, P, sl.epoch);
     if (sl.timed)
         EFX_HIP(hipEventRecord(sl.ev[2], sp));
     EFX_HIP(hipEventRecord(sl.parse_done, sp));
@@ -420,8 +426,8 @@ int efx_decode(efx_ctx* ctx)
     if (sl.timed)
         EFX_HIP(hipEventRecord(sl.ev[4], sr));
     for (int p = 0; p < P; p++)
-        hipLaunchKernelGGL(k_recon, dim3(n, kMbCount), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs, ctx->d_frames, P, D, p,
-                           (p + 1) % D, p % D, sl.epoch);
+        hipLaunchKernelGGL(k_recon, dim3(n, kMbCount), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs, ctx->d_tables->scan,
+                           ctx->d_qtab, ctx->d_frames, P, D, p, (p + 1) % D, p % D, sl.epoch);
     if (sl.timed)
         EFX_HIP(hipEventRecord(sl.ev[3], sr));
     EFX_HIP(hipEventRecord(sl.recon_done, sr));
@@ -613,6 +619,16 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out)
     *out = t;
     return EFX_OK;
 }
+
+#ifdef EFX_PARSE_PROFILE
+// development aid (libefx_prof.so only): per-slice {cycles, loop iterations, coefficients, bytes}
+int efx_debug_parse_profile(efx_ctx* ctx, uint32_t* dptr)
+{
+    hipLaunchKernelGGL(k_parse_set_prof, dim3(1), dim3(1), 0, ctx->parse_stream, dptr);
+    EFX_HIP(hipStreamSynchronize(ctx->parse_stream));
+    return EFX_OK;
+}
+#endif
 
 int efx_device_alloc(efx_ctx* ctx, size_t bytes, void** dptr)
 {

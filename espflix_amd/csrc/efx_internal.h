@@ -17,6 +17,7 @@ constexpr int kMbW = 22, kMbH = 12, kMbCount = 264;
 constexpr int kStride = 528, kStripBytes = 8448, kFrameBytes = 101376;
 constexpr int kMaxSlicesPerPicture = 16;   // slice start codes kept per picture
 constexpr int kMaxUnitsPerStream = 4096;   // start codes indexed per stream per decode
+constexpr int kSliceBins = 4096;            // 256 slice-length classes x 16 sub-lists (k_index.hip)
 constexpr int kCoefsPerEsByte = 3;         // a coefficient costs >= 3 bits (2 + EOB for singletons)
 constexpr int kEsTailBytes = 9;            // 00 | 00 00 01 B7 | 00 00 01 B7   (player.cpp:456,472)
 constexpr int kEsGuardBytes = 512;         // zero guard after the last stream (parse lanes read 128 B ahead)
@@ -50,14 +51,14 @@ struct SliceDesc {
 struct MbRec {
     uint32_t coef_base;  // absolute index of the first coefficient entry
     uint8_t cnt[6];      // entries per block (intra: including the DC entry)
-    uint8_t flags;       // bit0 intra, bit1 skipped (copy co-located), bits 2-7 block dropped mask
+    uint8_t flags;       // bit0 intra, bit1 skipped (copy co-located), bits 2-6 quantiser_scale, bit7 loaded matrices
     uint8_t epoch;       // decode epoch that wrote the record (0 = never)
     int16_t mvx, mvy;    // half-pel luma displacement after full_pel scaling
 };
 static_assert(sizeof(MbRec) == 16, "MbRec must be 16 bytes");
 
-// coefficient entry: (dequantised value * IDCT pre-multiplier) << 6 | raster position
-// (the reference's b[zz] = v * scale_dct_q[zz], player.cpp:1121)
+// coefficient entry: signed level << 6 | scan position (intra DC: DC value << 6); k_recon
+// dequantises and pre-multiplies (the reference's b[zz] = v * scale_dct_q[zz], player.cpp:1110-1121)
 
 // flat VLC look-up tables (built on the host from mpeg1_codebook.h, staged in LDS by k_parse)
 struct ParseTables {

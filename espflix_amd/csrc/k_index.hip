@@ -33,6 +33,17 @@ __device__ inline uint32_t wave_excl_scan(uint32_t v, uint32_t* total)
     return x - v;
 }
 
+// Slices are handed to k_parse sorted by decreasing byte length (a proxy for their symbol count):
+// the 64 lanes of a parse wave then run slices of similar length in lock step, and the longest
+// slices -- the kernel's critical path -- start first.  Counting sort: 256 length classes of
+// 32 bytes x 16 sub-lists (by stream) to spread the atomics.
+__device__ inline uint32_t slice_bin(uint32_t len, int stream)
+{
+    uint32_t cls = len >> 5;
+    cls = cls > 255 ? 255 : cls;
+    return ((255 - cls) << 4) | ((uint32_t)stream & 15);
+}
+
 __device__ inline uint32_t load_bits(const uint8_t* p, uint32_t bitpos, int n)  // n <= 24, MSB first
 {
     const uint8_t* q = p + (bitpos >> 3);
@@ -46,7 +57,7 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
                                               int max_pictures, PicInfo* __restrict__ pics,
                                               SliceTmp* __restrict__ slices_tmp, uint32_t* __restrict__ pic_count,
                                               uint32_t* __restrict__ status, uint32_t* __restrict__ qtab,
-                                              const uint32_t* __restrict__ scan_tab)
+                                              const uint32_t* __restrict__ scan_tab, uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t u_off[kMaxUnitsPerStream];
     __shared__ uint32_t u_info[kMaxUnitsPerStream];
@@ -177,6 +188,7 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
                         t.len_code = ((next - u_off[i]) << 8) | code;
                         myslices[slice_total++] = t;
                         nsl++;
+                        atomicAdd(&hist[slice_bin(next - u_off[i], s)], 1u);
                     } else
                         st |= EFX_STREAM_TRUNCATED;
                 }
@@ -209,29 +221,21 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
     }
 }
 
-// Exclusive prefix sum of slice counts over (picture, stream) pairs in picture-major order, so
-// that the slices of one picture index are contiguous: a parse wave then holds 64 slices of the
-// same picture type.  Single workgroup.
-__global__ __launch_bounds__(1024) void k_slice_scan(const PicInfo* __restrict__ pics,
-                                                     const uint32_t* __restrict__ pic_count, int n_streams,
-                                                     int max_pictures, uint32_t* __restrict__ slice_base,
+// Exclusive prefix sum of the length-class histogram (longest class first); the histogram is
+// cleared on the way and reused by k_slice_emit as the per-class cursor.  Single workgroup.
+__global__ __launch_bounds__(1024) void k_slice_scan(uint32_t* __restrict__ hist, uint32_t* __restrict__ bin_base,
                                                      DecodeCounters* __restrict__ counters)
 {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n = n_streams * max_pictures;
     if (tid == 0)
         carry = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
+    for (int base = 0; base < kSliceBins; base += 1024) {
         int i = base + tid;
-        uint32_t v = 0;
-        if (i < n) {
-            int p = i / n_streams, s = i - p * n_streams;
-            if ((uint32_t)p < pic_count[s])
-                v = pics[(size_t)s * max_pictures + p].n_slices;
-        }
+        uint32_t v = hist[i];
+        hist[i] = 0;
         uint32_t tot;
         uint32_t ex = wave_excl_scan(v, &tot);
         if (lane == 63)
@@ -240,8 +244,7 @@ __global__ __launch_bounds__(1024) void k_slice_scan(const PicInfo* __restrict__
         uint32_t off = carry;
         for (int k = 0; k < wv; k++)
             off += wave_tot[k];
-        if (i < n)
-            slice_base[i] = off + ex;
+        bin_base[i] = off + ex;
         __syncthreads();
         if (tid == 1023)
             carry = off + ex + v;
@@ -251,7 +254,6 @@ __global__ __launch_bounds__(1024) void k_slice_scan(const PicInfo* __restrict__
         counters->total_slices = carry;
         counters->coefficients = 0;
         counters->macroblocks = 0;
-        slice_base[n] = carry;
     }
 }
 
@@ -259,8 +261,8 @@ __global__ __launch_bounds__(256) void k_slice_emit(const PicInfo* __restrict__ 
                                                     const SliceTmp* __restrict__ slices_tmp,
                                                     const uint32_t* __restrict__ pic_count,
                                                     const uint64_t* __restrict__ stream_off,
-                                                    const uint32_t* __restrict__ slice_base, int n_streams,
-                                                    int max_pictures, SliceDesc* __restrict__ descs)
+                                                    const uint32_t* __restrict__ bin_base, uint32_t* __restrict__ cursor,
+                                                    int n_streams, int max_pictures, SliceDesc* __restrict__ descs)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_streams * max_pictures)
@@ -270,7 +272,6 @@ __global__ __launch_bounds__(256) void k_slice_emit(const PicInfo* __restrict__ 
         return;
     PicInfo pi = pics[(size_t)s * max_pictures + p];
     const SliceTmp* src = slices_tmp + (size_t)s * max_pictures * kMaxSlicesPerPicture + pi.first_slice;
-    SliceDesc* dst = descs + slice_base[i];
     uint32_t base = (uint32_t)stream_off[s];
     for (int k = 0; k < pi.n_slices; k++) {
         SliceTmp t = src[k];
@@ -281,7 +282,8 @@ __global__ __launch_bounds__(256) void k_slice_emit(const PicInfo* __restrict__ 
         d.pic_code_flags = (uint32_t)p | ((t.len_code & 0xFF) << 8) | ((uint32_t)pi.type << 16) |
                            ((uint32_t)pi.full_pel << 18) | ((uint32_t)pi.r_size << 19) | ((uint32_t)pi.custom_q << 22);
         d.reserved[0] = d.reserved[1] = 0;
-        dst[k] = d;
+        uint32_t bin = slice_bin(d.es_len, s);
+        descs[bin_base[bin] + atomicAdd(&cursor[bin], 1u)] = d;
     }
 }
 

@@ -10,21 +10,29 @@
 //
 // Output per macroblock: a 16-byte MbRec (type, motion vector, per-block coefficient counts)
 // and the macroblock's coefficients as compact 32-bit entries
-//   entry = (dequantised value * IDCT pre-multiplier) << 6 | raster position,
-// i.e. exactly the non-zero b[zz] of player.cpp:1121; the dense 64-int block never exists in
-// memory.  k_recon turns these into pixels.
+//   entry = signed level << 6 | scan position      (intra DC: DC value << 6 | 0),
+// the dense 64-int block never exists in memory.  Dequantisation (player.cpp:1110-1121) happens
+// in k_recon, where one lane handles one coefficient: in this kernel only ~1/4 of the lanes do
+// useful work per instruction (lock-step slices), so every instruction moved out of the symbol
+// loop is paid for four times over.
 //
 // The kernel is bound by the serial symbol chain of the longest slices (I pictures), i.e. by
 // instructions per symbol, so the symbol loop is kept minimal: the bit reader is a bit POSITION
 // into a per-lane LDS ring (one 32-bit window per symbol, no refill state), every DCT code
-// including "10"/"11s" resolves through one table look-up, and global memory is touched only
-// by the coefficient store and by wave-synchronous ring top-ups.
+// including "10"/"11s" resolves through one table look-up, each symbol is stored one iteration
+// late (in the shadow of the next look-up), and global memory is touched only by that store and
+// by wave-synchronous ring top-ups.
 #include <hip/hip_runtime.h>
 
 #include "efx_internal.h"
 #include "efx.h"
 
 namespace efx {
+
+#ifdef EFX_PARSE_PROFILE
+__device__ uint32_t* g_parse_prof = nullptr;  // development aid: per-slice timing records
+__global__ void k_parse_set_prof(uint32_t* p) { g_parse_prof = p; }
+#endif
 
 namespace {
 
@@ -122,11 +130,17 @@ __device__ inline int decode_motion(BitReader& br, const uint16_t* tab, int pred
 
 __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, const SliceDesc* __restrict__ descs,
                                                DecodeCounters* __restrict__ counters,
-                                               const ParseTables* __restrict__ gtab,
-                                               const uint32_t* __restrict__ qtab_custom, MbRec* __restrict__ mbrecs,
+                                               const ParseTables* __restrict__ gtab, MbRec* __restrict__ mbrecs,
                                                uint32_t* __restrict__ coefs, uint32_t* __restrict__ status,
                                                int max_pictures, int epoch)
 {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool mine = gid < counters->total_slices;
+    SliceDesc d = {};
+    if (mine)
+        d = descs[gid];
+    if (!__syncthreads_or(mine))
+        return;  // no slice in the whole block: leave before staging tables
     // This kernel is a few thousand long, latency-bound waves and runs next to the (many, short)
     // reconstruction waves of the previous decode call: ask the SIMD arbiter to favour it.
     __builtin_amdgcn_s_setprio(3);
@@ -138,20 +152,16 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
         for (int i = threadIdx.x; i < (int)(sizeof(ParseTables) / 4); i += blockDim.x)
             dst[i] = src[i];
     }
+    const uint32_t pic = d.pic_code_flags & 0xFF;
     __syncthreads();
-
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= counters->total_slices)
+    if (!mine)
         return;
 
-    const SliceDesc d = descs[gid];
-    const uint32_t pic = d.pic_code_flags & 0xFF;
     const int code = (d.pic_code_flags >> 8) & 0xFF;
     const bool i_picture = ((d.pic_code_flags >> 16) & 3) == 1;
     const int full_pel = (d.pic_code_flags >> 18) & 1;
     const int r_size = (d.pic_code_flags >> 19) & 7;
-    const bool custom_q = (d.pic_code_flags >> 22) & 1;
-    const size_t qoff = ((size_t)d.stream * max_pictures + pic) * 64;
+    const bool custom_q = (d.pic_code_flags >> 22) & 1;  // recorded per macroblock for k_recon's dequantiser
 
     MbRec* recs = mbrecs + ((size_t)d.stream * max_pictures + pic) * kMbCount;
     uint32_t coef_idx = d.es_off * kCoefsPerEsByte;
@@ -161,6 +171,10 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
 
     BitReader br;
     br.init(es, d.es_off, &sh.ring[threadIdx.x >> 6][0][threadIdx.x & 63]);
+#ifdef EFX_PARSE_PROFILE
+    const unsigned long long prof_t0 = __builtin_readcyclecounter();
+    uint32_t prof_iters = 0, prof_mbs = 0;
+#endif
 
     uint32_t st = 0;
     uint32_t n_coefs = 0, n_mbs = 0;
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
         MbRec rec;
         rec.coef_base = coef_idx;
         rec.epoch = (uint8_t)epoch;
-        rec.flags = intra ? 1 : 0;
+        rec.flags = (uint8_t)((intra ? 1 : 0) | (qscale << 2) | (custom_q ? 0x80 : 0));
         if (intra) {
             mv_h = mv_v = 0;  // player.cpp:1300
         } else {
@@ -365,82 +379,77 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                         dc_y = pred;
                 }
                 br.advance(len);
-                coefs[min(coef_idx, coef_last)] = ((uint32_t)pred << 8) << 6;  // b[0] = dc << 8, zz = 0
+                coefs[min(coef_idx, coef_last)] = (uint32_t)pred << 6;  // DC value, scan position 0
                 coef_idx++;
                 n = 1;
                 win = br.window();
             }
 
-            // run/level pairs, player.cpp:1070-1122
-            int level = 0, run = 0;
-            bool have = false, dropped = false;
+            // run/level pairs, player.cpp:1070-1122.  Software pipeline of depth one: the symbol
+            // decoded in iteration i (scan position pend_n, signed level pend_level) is dequantised
+            // and stored in iteration i+1, in the shadow of that iteration's table look-up, so the
+            // serial chain per symbol is only  window -> table -> length -> position.
+            int pend_n = -1, pend_level = 0;
+            bool dropped = false;
             if (!intra && (win >> 31)) {
                 // first coefficient of a non-intra block: "1s" is (0, +-1); end_of_block cannot come first
-                level = ((win >> 30) & 1) ? -1 : 1;
+                pend_level = ((win >> 30) & 1) ? -1 : 1;
+                pend_n = 0;
+                n = 1;
                 br.advance(2);
-                have = true;
             }
             for (;;) {
-                if (!have) {
-                    br.topup();
-                    win = br.window();
-                    uint32_t pk = win >> 16;
-                    uint32_t ent = (pk >= 0x0400) ? sh.t.dct_hi[pk >> 8] : sh.t.dct_lo[pk & 0x3FF];
-                    uint32_t len = ent & 31;
-                    run = (ent >> 5) & 31;
-                    level = (int)(ent >> 10);
-                    if (len == 0) {
-                        bad = true;
-                        break;
-                    }
-                    if (level == 63) {  // "10": end_of_block
-                        br.advance(2);
-                        break;
-                    }
-                    if (level == 0) {  // escape: 6-bit run, 8- or 16-bit level (player.cpp:1092-1099)
-                        run = (int)((win << 6) >> 26);
-                        level = (int)((win << 12) >> 24);
-                        len = 20;
-                        if ((level & 0x7F) == 0) {
-                            int ext = (int)((win << 20) >> 24);
-                            level = level ? ext - 256 : ext;
-                            len = 28;
-                        } else if (level > 128)
-                            level -= 256;
-                    } else {
-                        if ((win << len) >> 31)
-                            level = -level;
-                        len++;
-                    }
-                    br.advance(len);
+#ifdef EFX_PARSE_PROFILE
+                if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1)
+                    prof_iters++;
+#endif
+                br.topup();
+                win = br.window();
+                const uint32_t pk = win >> 16;
+                const uint32_t ent = (pk >= 0x0400) ? sh.t.dct_hi[pk >> 8] : sh.t.dct_lo[pk & 0x3FF];
+
+                if (pend_n >= 0) {  // emit the previous symbol: (signed level, scan position)
+#ifndef EFX_EXP_NOSTORE
+                    coefs[min(coef_idx, coef_last)] = ((uint32_t)pend_level << 6) | (uint32_t)pend_n;
+#endif
+                    coef_idx++;
+                    pend_n = -1;
                 }
-                have = false;
+
+                uint32_t len = ent & 31;
+                int run = (ent >> 5) & 31;
+                int level = (int)(ent >> 10);
+                if (len == 0) {
+                    bad = true;
+                    break;
+                }
+                if (level == 63) {  // "10": end_of_block
+                    br.advance(2);
+                    break;
+                }
+                if (level == 0) {  // escape: 6-bit run, 8- or 16-bit level (player.cpp:1092-1099)
+                    run = (int)((win << 6) >> 26);
+                    level = (int)((win << 12) >> 24);
+                    len = 20;
+                    if ((level & 0x7F) == 0) {
+                        int ext = (int)((win << 20) >> 24);
+                        level = level ? ext - 256 : ext;
+                        len = 28;
+                    } else if (level > 128)
+                        level -= 256;
+                } else {
+                    if ((win << len) >> 31)
+                        level = -level;
+                    len++;
+                }
+                br.advance(len);
                 n += run;
-                run = 0;
                 if (n >= 64) {  // player.cpp:1106-1107: the block is abandoned, nothing is stored
                     dropped = true;
                     break;
                 }
-                // LDS look-up (volatile: keeps the compiler from fusing it with the global re-read
-                // below into one flat load, which would put a vmcnt(0) wait into every iteration);
-                // only streams with loaded quantiser matrices take the global path
-                uint32_t t = *reinterpret_cast<volatile uint32_t*>(&sh.t.scan[n]);
-                if (custom_q)
-                    t = qtab_custom[qoff + n];
-                n++;
-                int q = intra ? (int)((t >> 16) & 0xFF) : (int)(t >> 24);
-                // reconstruction, player.cpp:1110-1121
-                int val = level << 1;
-                if (!intra)
-                    val += (val < 0) ? -1 : 1;
-                val = val * qscale * q;
-                val = (val + ((val >> 31) & 15)) >> 4;  // division by 16 truncating toward zero
-                if ((val & 1) == 0)
-                    val -= (val > 0) ? 1 : -1;
-                val = val > 2047 ? 2047 : (val < -2048 ? -2048 : val);
-                val *= (int)((t >> 8) & 0xFF);
-                coefs[min(coef_idx, coef_last)] = ((uint32_t)val << 6) | (t & 0x3F);
-                coef_idx++;
+                pend_n = n++;
+                pend_level = level;
             }
             if (bad)
                 break;
@@ -463,6 +472,21 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
             break;
         }
     }
+#ifdef EFX_PARSE_PROFILE
+    {
+        // per-lane record: [gid] = {cycles, coef-loop iterations this lane led, own symbols, bytes}
+        unsigned long long t1 = __builtin_readcyclecounter();
+        uint32_t* prof = coefs + (size_t)counters->total_slices * 0;  // placeholder, see below
+        (void)prof;
+        if (g_parse_prof) {
+            g_parse_prof[gid * 4 + 0] = (uint32_t)(t1 - prof_t0);
+            g_parse_prof[gid * 4 + 1] = prof_iters;
+            g_parse_prof[gid * 4 + 2] = n_coefs;
+            g_parse_prof[gid * 4 + 3] = d.es_len | (i_picture ? 0x80000000u : 0);
+        }
+        (void)prof_mbs;
+    }
+#endif
     if (st)
         atomicOr(&status[d.stream], st);
     atomicAdd(&counters->coefficients, (unsigned long long)n_coefs);

@@ -88,8 +88,10 @@ __device__ inline uint32_t avg4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) 
 // dispatched to XCD (stream % 8) and the partial 64-byte lines written by neighbouring
 // macroblocks merge in one L2.  cur_slot / ref_slot are the ring slots of this picture index.
 __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, const uint32_t* __restrict__ coefs,
-                                              uint8_t* __restrict__ frames, int max_pictures, int ring_depth, int pic,
-                                              int cur_slot, int ref_slot, int epoch)
+                                              const uint32_t* __restrict__ scan_tab,
+                                              const uint32_t* __restrict__ qtab_custom, uint8_t* __restrict__ frames,
+                                              int max_pictures, int ring_depth, int pic, int cur_slot, int ref_slot,
+                                              int epoch)
 {
     __shared__ int cf[6 * kBlkPitch];
     __shared__ uint32_t luma_tile[17 * kLumaPitch / 4];
@@ -189,11 +191,33 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         if (lane < 8)
             zflag[lane] = 0;
         __syncthreads();
+        // one lane per coefficient: dequantise (player.cpp:1110-1121) and drop it into its block.
+        // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
+        const int qscale = (rec.flags >> 2) & 31;
+        const uint32_t* qt = (rec.flags & 0x80) ? qtab_custom + ((size_t)s * max_pictures + pic) * 64 : scan_tab;
         for (int i = lane; i < total; i += 64) {
             uint32_t e = (i < 64) ? ce : coefs[rec.coef_base + i];
             int b = (i >= pre1) + (i >= pre2) + (i >= pre3) + (i >= pre4) + (i >= pre5);
-            cf[b * kBlkPitch + (e & 63)] = (int)e >> 6;
-            if ((e & 63) == 0)
+            int n = e & 63, level = (int)e >> 6;
+            int first = b == 0 ? 0 : (b == 1 ? pre1 : (b == 2 ? pre2 : (b == 3 ? pre3 : (b == 4 ? pre4 : pre5))));
+            uint32_t t = qt[n];
+            int val;
+            if (intra && i == first)
+                val = level << 8;  // b[0] = dc << 8 (player.cpp:1065)
+            else {
+                int q = intra ? (int)((t >> 16) & 0xFF) : (int)(t >> 24);
+                val = level << 1;
+                if (!intra)
+                    val += (val < 0) ? -1 : 1;
+                val = val * qscale * q;
+                val = (val + ((val >> 31) & 15)) >> 4;  // division by 16 truncating toward zero
+                if ((val & 1) == 0)
+                    val -= (val > 0) ? 1 : -1;
+                val = val > 2047 ? 2047 : (val < -2048 ? -2048 : val);
+                val *= (int)((t >> 8) & 0xFF);
+            }
+            cf[b * kBlkPitch + (t & 63)] = val;
+            if (n == 0)
                 zflag[b] = 1;
         }
     }
