@@ -16,10 +16,10 @@
 namespace efx {
 // kernels (k_index.hip, k_parse.hip, k_recon.hip, k_video.hip)
 __global__ void k_index(const uint8_t*, const uint64_t*, int, PicInfo*, SliceTmp*, uint32_t*, uint32_t*, uint32_t*,
-                        const uint32_t*, uint32_t*);
-__global__ void k_slice_scan(uint32_t*, uint32_t*, DecodeCounters*);
-__global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, const uint64_t*, const uint32_t*, uint32_t*,
-                             int, int, SliceDesc*);
+                        const uint32_t*);
+__global__ void k_slice_scan(const PicInfo*, const uint32_t*, int, int, uint32_t*, DecodeCounters*);
+__global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, const uint64_t*, const uint32_t*, int, int,
+                             SliceDesc*);
 __global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const ParseTables*, MbRec*, uint32_t*, uint32_t*,
                         int, int);
 __global__ void k_recon(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, int, int, int);
@@ -53,8 +53,7 @@ struct efx_ctx {
     SliceTmp* d_slices_tmp = nullptr;
     uint32_t* d_qtab = nullptr;
     ParseTables* d_tables = nullptr;
-    uint32_t* d_slice_base = nullptr;  // per length class: first descriptor index
-    uint32_t* d_hist = nullptr;        // per length class: slice count, then emit cursor
+    uint32_t* d_slice_base = nullptr;
     SliceDesc* d_descs = nullptr;
     uint8_t* d_frames = nullptr;
     // Two sets of parse -> recon hand-over buffers: efx_decode() number n parses into slot n & 1
@@ -217,8 +216,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     A(dalloc(&ctx->d_slices_tmp, n * P * kMaxSlicesPerPicture));
     A(dalloc(&ctx->d_qtab, n * P * 64));
     A(dalloc(&ctx->d_tables, 1));
-    A(dalloc(&ctx->d_slice_base, (size_t)kSliceBins));
-    A(dalloc(&ctx->d_hist, (size_t)kSliceBins));
+    A(dalloc(&ctx->d_slice_base, n * P + 1));
     A(dalloc(&ctx->d_descs, n * P * kMaxSlicesPerPicture));
     for (auto& sl : ctx->slot) {
         A(dalloc(&sl.d_pic_count, n));
@@ -254,7 +252,6 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     }
     A(hipMemset(ctx->d_frames, 0, n * D * kFrameBytes));
     A(hipMemset(ctx->d_es, 0, ctx->es_cap));
-    A(hipMemset(ctx->d_hist, 0, kSliceBins * sizeof(uint32_t)));
     for (auto& sl : ctx->slot) {
         A(hipMemset(sl.d_mbrecs, 0, n * P * kMbCount * sizeof(MbRec)));
         A(hipEventCreateWithFlags(&sl.parse_done, hipEventDisableTiming));
@@ -277,7 +274,7 @@ void efx_destroy(efx_ctx* ctx)
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     void* bufs[] = {ctx->d_es,   ctx->d_stream_off, ctx->d_pics,  ctx->d_slices_tmp, ctx->d_qtab,     ctx->d_tables,
-                    ctx->d_slice_base, ctx->d_descs, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_hash, ctx->d_hist};
+                    ctx->d_slice_base, ctx->d_descs, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_hash};
     for (void* b : bufs)
         if (b)
             (void)hipFree(b);
@@ -406,12 +403,12 @@ int efx_decode(efx_ctx* ctx)
     sl.timed = ctx->timing;
     if (sl.timed)
         EFX_HIP(hipEventRecord(sl.ev[0], sp));
-    EFX_HIP(hipMemsetAsync(ctx->d_hist, 0, kSliceBins * sizeof(uint32_t), sp));  // k_slice_emit left its cursors there
     hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, sp, ctx->d_es, ctx->d_stream_off, P, ctx->d_pics, ctx->d_slices_tmp,
-                       sl.d_pic_count, sl.d_status, ctx->d_qtab, ctx->d_tables->scan, ctx->d_hist);
-    hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, ctx->d_hist, ctx->d_slice_base, sl.d_counters);
-    hipLaunchKernelGGL(k_slice_emit, dim3((n * P + 255) / 256), dim3(256), 0, sp, ctx->d_pics, ctx->d_slices_tmp,
-                       sl.d_pic_count, ctx->d_stream_off, ctx->d_slice_base, ctx->d_hist, n, P, ctx->d_descs);
+                       sl.d_pic_count, sl.d_status, ctx->d_qtab, ctx->d_tables->scan);
+    hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, ctx->d_pics, sl.d_pic_count, n, P, ctx->d_slice_base,
+                       sl.d_counters);
+    hipLaunchKernelGGL(k_slice_emit, dim3((n * P * kMaxSlicesPerPicture + 255) / 256), dim3(256), 0, sp, ctx->d_pics,
+                       ctx->d_slices_tmp, sl.d_pic_count, ctx->d_stream_off, ctx->d_slice_base, n, P, ctx->d_descs);
     if (sl.timed)
         EFX_HIP(hipEventRecord(sl.ev[1], sp));
     const int max_slices = n * P * kMaxSlicesPerPicture;

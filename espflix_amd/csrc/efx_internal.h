@@ -17,7 +17,6 @@ constexpr int kMbW = 22, kMbH = 12, kMbCount = 264;
 constexpr int kStride = 528, kStripBytes = 8448, kFrameBytes = 101376;
 constexpr int kMaxSlicesPerPicture = 16;   // slice start codes kept per picture
 constexpr int kMaxUnitsPerStream = 4096;   // start codes indexed per stream per decode
-constexpr int kSliceBins = 4096;            // 256 slice-length classes x 16 sub-lists (k_index.hip)
 constexpr int kCoefsPerEsByte = 3;         // a coefficient costs >= 3 bits (2 + EOB for singletons)
 constexpr int kEsTailBytes = 9;            // 00 | 00 00 01 B7 | 00 00 01 B7   (player.cpp:456,472)
 constexpr int kEsGuardBytes = 512;         // zero guard after the last stream (parse lanes read 128 B ahead)

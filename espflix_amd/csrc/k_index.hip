@@ -6,7 +6,7 @@
 // (0x01..0xAF) to the slice decoder together with the picture state in force.
 //
 // k_index: ONE WAVE PER STREAM.  Lanes read 16 contiguous bytes each (1 KiB per wave load,
-// 4 loads in flight), test 16 byte positions, and append hits to an LDS unit list in stream
+// four loads in flight per lane), test 16 byte positions, and append hits to an LDS unit list in stream
 // order via a wave prefix sum.  Header fields of all units are then pre-parsed lane-parallel
 // and one lane walks the (short) unit list to apply the reference's sequential state rules.
 #include <hip/hip_runtime.h>
@@ -33,17 +33,6 @@ __device__ inline uint32_t wave_excl_scan(uint32_t v, uint32_t* total)
     return x - v;
 }
 
-// Slices are handed to k_parse sorted by decreasing byte length (a proxy for their symbol count):
-// the 64 lanes of a parse wave then run slices of similar length in lock step, and the longest
-// slices -- the kernel's critical path -- start first.  Counting sort: 256 length classes of
-// 32 bytes x 16 sub-lists (by stream) to spread the atomics.
-__device__ inline uint32_t slice_bin(uint32_t len, int stream)
-{
-    uint32_t cls = len >> 5;
-    cls = cls > 255 ? 255 : cls;
-    return ((255 - cls) << 4) | ((uint32_t)stream & 15);
-}
-
 __device__ inline uint32_t load_bits(const uint8_t* p, uint32_t bitpos, int n)  // n <= 24, MSB first
 {
     const uint8_t* q = p + (bitpos >> 3);
@@ -57,7 +46,7 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
                                               int max_pictures, PicInfo* __restrict__ pics,
                                               SliceTmp* __restrict__ slices_tmp, uint32_t* __restrict__ pic_count,
                                               uint32_t* __restrict__ status, uint32_t* __restrict__ qtab,
-                                              const uint32_t* __restrict__ scan_tab, uint32_t* __restrict__ hist)
+                                              const uint32_t* __restrict__ scan_tab)
 {
     __shared__ uint32_t u_off[kMaxUnitsPerStream];
     __shared__ uint32_t u_info[kMaxUnitsPerStream];
@@ -70,41 +59,55 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
 
     // ---- 1. start-code scan -------------------------------------------------------------
     uint32_t n_units = 0;
-    for (uint32_t chunk = 0; chunk < len; chunk += 64 * 16) {
-        uint32_t pos = chunk + lane * 16;
-        uint32_t w[5] = {0, 0, 0, 0, 0};
-        if (pos < len) {
-            uint4 d = *reinterpret_cast<const uint4*>(base + pos);
-            w[0] = d.x;
-            w[1] = d.y;
-            w[2] = d.z;
-            w[3] = d.w;
-            w[4] = *reinterpret_cast<const uint32_t*>(base + pos + 16);  // guard bytes make this safe
-        }
-        uint32_t mask = 0;
+    constexpr int kUnroll = 4;  // 4 KiB per wave iteration: four 16-byte loads per lane in flight
+    for (uint32_t chunk = 0; chunk < len; chunk += 64 * 16 * kUnroll) {
+        uint32_t wv[kUnroll][5];
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            // bytes i, i+1, i+2 as a little-endian 24-bit value must be 0x010000
-            uint32_t lo = w[i >> 2], hi = w[(i >> 2) + 1];
-            uint32_t v = (i & 3) ? __builtin_amdgcn_alignbyte(hi, lo, i & 3) : lo;
-            if ((v & 0xFFFFFF) == 0x010000)
-                mask |= 1u << i;
+        for (int u = 0; u < kUnroll; u++) {
+            const uint32_t pos = chunk + u * 1024 + lane * 16;
+            // reads past the stream end stay inside the ES buffer (next stream / guard) and are masked below
+            const uint8_t* p = base + (pos < len ? pos : 0);
+            uint4 d = *reinterpret_cast<const uint4*>(p);
+            wv[u][0] = d.x;
+            wv[u][1] = d.y;
+            wv[u][2] = d.z;
+            wv[u][3] = d.w;
+            wv[u][4] = *reinterpret_cast<const uint32_t*>(p + 16);
         }
-        uint32_t cnt = __popc(mask);
-        if (__ballot(cnt != 0)) {
-            uint32_t total;
-            uint32_t idx = n_units + wave_excl_scan(cnt, &total);
-            while (mask) {
-                int i = __ffs(mask) - 1;
-                mask &= mask - 1;
-                if (idx < kMaxUnitsPerStream) {
-                    uint32_t lo = w[(i + 3) >> 2];
-                    u_off[idx] = pos + i + 4;
-                    u_info[idx] = (lo >> (((i + 3) & 3) * 8)) & 0xFF;
-                }
-                idx++;
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            const uint32_t pos = chunk + u * 1024 + lane * 16;
+            const bool live = pos < len;
+            uint32_t* w = wv[u];
+            if (pos + 16 >= len)
+                w[4] = 0;  // never look into the next stream
+            uint32_t mask = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                // bytes i, i+1, i+2 as a little-endian 24-bit value must be 0x010000
+                uint32_t lo = w[i >> 2], hi = w[(i >> 2) + 1];
+                uint32_t v = (i & 3) ? __builtin_amdgcn_alignbyte(hi, lo, i & 3) : lo;
+                if ((v & 0xFFFFFF) == 0x010000)
+                    mask |= 1u << i;
             }
-            n_units += total;
+            if (!live)
+                mask = 0;
+            uint32_t cnt = __popc(mask);
+            if (__ballot(cnt != 0)) {
+                uint32_t total;
+                uint32_t idx = n_units + wave_excl_scan(cnt, &total);
+                while (mask) {
+                    int i = __ffs(mask) - 1;
+                    mask &= mask - 1;
+                    if (idx < kMaxUnitsPerStream) {
+                        uint32_t lo = w[(i + 3) >> 2];
+                        u_off[idx] = pos + i + 4;
+                        u_info[idx] = (lo >> (((i + 3) & 3) * 8)) & 0xFF;
+                    }
+                    idx++;
+                }
+                n_units += total;
+            }
         }
     }
     uint32_t st = 0;
@@ -188,7 +191,6 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
                         t.len_code = ((next - u_off[i]) << 8) | code;
                         myslices[slice_total++] = t;
                         nsl++;
-                        atomicAdd(&hist[slice_bin(next - u_off[i], s)], 1u);
                     } else
                         st |= EFX_STREAM_TRUNCATED;
                 }
@@ -221,21 +223,29 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
     }
 }
 
-// Exclusive prefix sum of the length-class histogram (longest class first); the histogram is
-// cleared on the way and reused by k_slice_emit as the per-class cursor.  Single workgroup.
-__global__ __launch_bounds__(1024) void k_slice_scan(uint32_t* __restrict__ hist, uint32_t* __restrict__ bin_base,
+// Exclusive prefix sum of slice counts over (picture, stream) pairs in picture-major order, so
+// that the slices of one picture index are contiguous: a parse wave then holds 64 slices of the
+// same picture type.  Single workgroup.
+__global__ __launch_bounds__(1024) void k_slice_scan(const PicInfo* __restrict__ pics,
+                                                     const uint32_t* __restrict__ pic_count, int n_streams,
+                                                     int max_pictures, uint32_t* __restrict__ slice_base,
                                                      DecodeCounters* __restrict__ counters)
 {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = n_streams * max_pictures;
     if (tid == 0)
         carry = 0;
     __syncthreads();
-    for (int base = 0; base < kSliceBins; base += 1024) {
+    for (int base = 0; base < n; base += 1024) {
         int i = base + tid;
-        uint32_t v = hist[i];
-        hist[i] = 0;
+        uint32_t v = 0;
+        if (i < n) {
+            int p = i / n_streams, s = i - p * n_streams;
+            if ((uint32_t)p < pic_count[s])
+                v = pics[(size_t)s * max_pictures + p].n_slices;
+        }
         uint32_t tot;
         uint32_t ex = wave_excl_scan(v, &tot);
         if (lane == 63)
@@ -244,7 +254,8 @@ __global__ __launch_bounds__(1024) void k_slice_scan(uint32_t* __restrict__ hist
         uint32_t off = carry;
         for (int k = 0; k < wv; k++)
             off += wave_tot[k];
-        bin_base[i] = off + ex;
+        if (i < n)
+            slice_base[i] = off + ex;
         __syncthreads();
         if (tid == 1023)
             carry = off + ex + v;
@@ -254,37 +265,37 @@ __global__ __launch_bounds__(1024) void k_slice_scan(uint32_t* __restrict__ hist
         counters->total_slices = carry;
         counters->coefficients = 0;
         counters->macroblocks = 0;
+        slice_base[n] = carry;
     }
 }
 
+// one thread per (picture, stream, slice slot)
 __global__ __launch_bounds__(256) void k_slice_emit(const PicInfo* __restrict__ pics,
                                                     const SliceTmp* __restrict__ slices_tmp,
                                                     const uint32_t* __restrict__ pic_count,
                                                     const uint64_t* __restrict__ stream_off,
-                                                    const uint32_t* __restrict__ bin_base, uint32_t* __restrict__ cursor,
-                                                    int n_streams, int max_pictures, SliceDesc* __restrict__ descs)
+                                                    const uint32_t* __restrict__ slice_base, int n_streams,
+                                                    int max_pictures, SliceDesc* __restrict__ descs)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int k = t % kMaxSlicesPerPicture, i = t / kMaxSlicesPerPicture;
     if (i >= n_streams * max_pictures)
         return;
     int p = i / n_streams, s = i - p * n_streams;
     if ((uint32_t)p >= pic_count[s])
         return;
     PicInfo pi = pics[(size_t)s * max_pictures + p];
-    const SliceTmp* src = slices_tmp + (size_t)s * max_pictures * kMaxSlicesPerPicture + pi.first_slice;
-    uint32_t base = (uint32_t)stream_off[s];
-    for (int k = 0; k < pi.n_slices; k++) {
-        SliceTmp t = src[k];
-        SliceDesc d;
-        d.es_off = base + t.off;
-        d.es_len = t.len_code >> 8;
-        d.stream = (uint32_t)s;
-        d.pic_code_flags = (uint32_t)p | ((t.len_code & 0xFF) << 8) | ((uint32_t)pi.type << 16) |
-                           ((uint32_t)pi.full_pel << 18) | ((uint32_t)pi.r_size << 19) | ((uint32_t)pi.custom_q << 22);
-        d.reserved[0] = d.reserved[1] = 0;
-        uint32_t bin = slice_bin(d.es_len, s);
-        descs[bin_base[bin] + atomicAdd(&cursor[bin], 1u)] = d;
-    }
+    if (k >= pi.n_slices)
+        return;
+    SliceTmp st = slices_tmp[(size_t)s * max_pictures * kMaxSlicesPerPicture + pi.first_slice + k];
+    SliceDesc d;
+    d.es_off = (uint32_t)stream_off[s] + st.off;
+    d.es_len = st.len_code >> 8;
+    d.stream = (uint32_t)s;
+    d.pic_code_flags = (uint32_t)p | ((st.len_code & 0xFF) << 8) | ((uint32_t)pi.type << 16) | ((uint32_t)pi.full_pel << 18) |
+                       ((uint32_t)pi.r_size << 19) | ((uint32_t)pi.custom_q << 22);
+    d.reserved[0] = d.reserved[1] = 0;
+    descs[slice_base[i] + k] = d;
 }
 
 }  // namespace efx
