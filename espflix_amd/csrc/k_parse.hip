@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                 continue;
             const uint32_t blk_start = coef_idx;
             int n = 0;
+            int dc_value = 0;
             br.topup();
             win = br.window();
             if (intra) {
@@ -379,26 +380,32 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                         dc_y = pred;
                 }
                 br.advance(len);
-                coefs[min(coef_idx, coef_last)] = (uint32_t)pred << 6;  // DC value, scan position 0
-                coef_idx++;
+                dc_value = pred;
                 n = 1;
                 win = br.window();
             }
 
-            // run/level pairs, player.cpp:1070-1122.  Software pipeline of depth one: the symbol
-            // decoded in iteration i (scan position pend_n, signed level pend_level) is dequantised
-            // and stored in iteration i+1, in the shadow of that iteration's table look-up, so the
-            // serial chain per symbol is only  window -> table -> length -> position.
-            int pend_n = -1, pend_level = 0;
-            bool dropped = false;
-            if (!intra && (win >> 31)) {
-                // first coefficient of a non-intra block: "1s" is (0, +-1); end_of_block cannot come first
-                pend_level = ((win >> 30) & 1) ? -1 : 1;
-                pend_n = 0;
-                n = 1;
-                br.advance(2);
+            // run/level pairs, player.cpp:1070-1122.  Software pipeline of depth one: the symbol decoded
+            // in iteration i (pend_level at scan position pend_n) is stored in iteration i+1, in the
+            // shadow of that iteration's table look-up, so the serial chain per symbol is only
+            // window -> table -> length -> position.  The body is BRANCH-FREE (selects, one
+            // unconditional store): a lone wave issues a dependent instruction only every ~8 cycles,
+            // and only a single basic block lets the scheduler interleave the off-chain work
+            // (escape decode, sign, store address) with the chain.
+            //   intra:      the pipeline is seeded with the DC entry (value at scan position 0);
+            //   non-intra:  with "1s" = (0, +-1) if the block opens with a 1 bit (end_of_block cannot
+            //               come first), otherwise empty -- the first store then lands on a slot that
+            //               the next real entry overwrites (coef_idx is not advanced).
+            uint32_t pend_valid = intra ? 1u : (win >> 31);
+            int pend_level = intra ? dc_value : (((win >> 30) & 1) ? -1 : 1);
+            int pend_n = 0;
+            if (!intra) {
+                n = (int)pend_valid;
+                br.advance(pend_valid << 1);
             }
-            for (;;) {
+            bool dropped = false;
+            uint32_t cont;
+            do {
 #ifdef EFX_PARSE_PROFILE
                 if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1)
                     prof_iters++;
@@ -408,49 +415,33 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                 const uint32_t pk = win >> 16;
                 const uint32_t ent = (pk >= 0x0400) ? sh.t.dct_hi[pk >> 8] : sh.t.dct_lo[pk & 0x3FF];
 
-                if (pend_n >= 0) {  // emit the previous symbol: (signed level, scan position)
-#ifndef EFX_EXP_NOSTORE
-                    coefs[min(coef_idx, coef_last)] = ((uint32_t)pend_level << 6) | (uint32_t)pend_n;
-#endif
-                    coef_idx++;
-                    pend_n = -1;
-                }
+                // emit the previous symbol: (signed level, scan position)
+                coefs[min(coef_idx, coef_last)] = ((uint32_t)pend_level << 6) | (uint32_t)pend_n;
+                coef_idx += pend_valid;
 
-                uint32_t len = ent & 31;
-                int run = (ent >> 5) & 31;
-                int level = (int)(ent >> 10);
-                if (len == 0) {
-                    bad = true;
-                    break;
-                }
-                if (level == 63) {  // "10": end_of_block
-                    br.advance(2);
-                    break;
-                }
-                if (level == 0) {  // escape: 6-bit run, 8- or 16-bit level (player.cpp:1092-1099)
-                    run = (int)((win << 6) >> 26);
-                    level = (int)((win << 12) >> 24);
-                    len = 20;
-                    if ((level & 0x7F) == 0) {
-                        int ext = (int)((win << 20) >> 24);
-                        level = level ? ext - 256 : ext;
-                        len = 28;
-                    } else if (level > 128)
-                        level -= 256;
-                } else {
-                    if ((win << len) >> 31)
-                        level = -level;
-                    len++;
-                }
-                br.advance(len);
-                n += run;
-                if (n >= 64) {  // player.cpp:1106-1107: the block is abandoned, nothing is stored
-                    dropped = true;
-                    break;
-                }
-                pend_n = n++;
+                const uint32_t len_f = ent & 31, run_f = (ent >> 5) & 31, lev_f = ent >> 10;
+                const bool bad_now = len_f == 0;   // invalid code
+                const bool eob = lev_f == 63;      // "10": end_of_block
+                const bool esc = lev_f == 0;       // escape: 6-bit run, 8- or 16-bit level (player.cpp:1092-1099)
+                const int lvl_n = ((win << len_f) >> 31) ? -(int)lev_f : (int)lev_f;
+                const uint32_t lv8 = (win << 12) >> 24, ext = (win << 20) >> 24;
+                const bool two = (lv8 & 0x7F) == 0;
+                const int lvl_e = two ? (lv8 ? (int)ext - 256 : (int)ext) : (lv8 > 128 ? (int)lv8 - 256 : (int)lv8);
+                const int level = esc ? lvl_e : lvl_n;
+                const uint32_t run = esc ? (win << 6) >> 26 : run_f;
+                uint32_t len = esc ? (two ? 28u : 20u) : len_f + 1;
+                len = eob ? 2u : len;
+                br.advance(bad_now ? 0u : len);
+                const int n_new = n + (int)run;
+                const bool drop = !eob && !bad_now && n_new >= 64;  // player.cpp:1106-1107: block abandoned
+                cont = !(eob || bad_now || drop);
+                pend_valid = cont;
+                pend_n = n_new & 63;
                 pend_level = level;
-            }
+                n = n_new + 1;
+                bad |= bad_now;
+                dropped |= drop;
+            } while (cont);
             if (bad)
                 break;
             if (dropped) {
