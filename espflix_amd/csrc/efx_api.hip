@@ -232,7 +232,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         A(hipDeviceGetStreamPriorityRange(&lo, &hi));
         A(hipStreamCreateWithPriority(&ctx->parse_stream, hipStreamNonBlocking, hi));
     }
-    A(dalloc(&ctx->d_frames, n * D * kFrameBytes));
+    A(dalloc(&ctx->d_frames, n * D * kFrameBytes + 8192));  // slack: k_recon's window rows may over-read the last frame
     A(dalloc(&ctx->d_video[0], 1));
     A(dalloc(&ctx->d_video[1], 1));
     A(dalloc(&ctx->d_hash, n * D));

@@ -27,8 +27,7 @@ namespace efx {
 namespace {
 
 constexpr int kBlkPitch = 72;   // ints per block in LDS (64 + 8 pad)
-constexpr int kLumaPitch = 32;  // bytes per staged luma row (5 dwords used; 16-byte aligned rows)
-constexpr int kChromaPitch = 16;
+constexpr int kTilePitch = 32;  // bytes per staged window row (16-byte aligned rows)
 
 // one 8-point pass of the reference's scaled integer IDCT (player.cpp:938-995)
 __device__ inline void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v5, int& v6, int& v7)
@@ -94,85 +93,70 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
                                               int epoch)
 {
     __shared__ int cf[6 * kBlkPitch];
-    __shared__ uint32_t luma_tile[17 * kLumaPitch / 4];
-    __shared__ uint32_t chroma_tile[2 * 9 * kChromaPitch / 4];
+    // staged reference windows, one row of kTilePitch bytes per lane: rows 0..16 luma (20 bytes used),
+    // rows 17..25 "cr", rows 26..34 "cb" (12 bytes used)
+    __shared__ uint32_t tile[35 * kTilePitch / 4];
     __shared__ int zflag[8];  // per block: 1 if an entry sits at raster position 0
 
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
     const int mb = blockIdx.y;
 
-    const MbRec rec = mbrecs[((size_t)s * max_pictures + pic) * kMbCount + mb];
-    if (rec.epoch != (uint8_t)epoch)
+    // The record is wave-uniform: fetch it as one 16-byte word and keep every field in scalar
+    // registers (indexing the struct per lane would bounce it through memory).
+    const uint4 rw = *reinterpret_cast<const uint4*>(mbrecs + ((size_t)s * max_pictures + pic) * kMbCount + mb);
+    const uint32_t w_base = __builtin_amdgcn_readfirstlane(rw.x);
+    const uint32_t w_cnt = __builtin_amdgcn_readfirstlane(rw.y);   // cnt[0..3]
+    const uint32_t w_misc = __builtin_amdgcn_readfirstlane(rw.z);  // cnt[4] | cnt[5] << 8 | flags << 16 | epoch << 24
+    const uint32_t w_mv = __builtin_amdgcn_readfirstlane(rw.w);    // mvx | mvy << 16
+    if ((w_misc >> 24) != (uint32_t)(epoch & 0xFF))
         return;  // macroblock not covered by any slice (or picture absent): the slot keeps its content
+    struct {
+        uint32_t coef_base;
+        uint32_t flags;
+    } rec = {w_base, (w_misc >> 16) & 0xFF};
 
     const int mb_y = mb / kMbW, mb_x = mb - mb_y * kMbW;
     uint8_t* cur = frames + ((size_t)s * ring_depth + cur_slot) * kFrameBytes;
     const uint8_t* ref = frames + ((size_t)s * ring_depth + ref_slot) * kFrameBytes;
     const bool intra = rec.flags & 1;
 
-    int pre1 = rec.cnt[0], pre2 = pre1 + rec.cnt[1], pre3 = pre2 + rec.cnt[2], pre4 = pre3 + rec.cnt[3],
-        pre5 = pre4 + rec.cnt[4];
-    const int total = pre5 + rec.cnt[5];
+    const int pre1 = w_cnt & 0xFF, pre2 = pre1 + ((w_cnt >> 8) & 0xFF), pre3 = pre2 + ((w_cnt >> 16) & 0xFF),
+              pre4 = pre3 + (w_cnt >> 24), pre5 = pre4 + (w_misc & 0xFF);
+    const int total = pre5 + ((w_misc >> 8) & 0xFF);
 
     // luma / chroma fetch geometry, predict() player.cpp:870-889
-    const int X = (mb_x << 5) + rec.mvx, Y = (mb_y << 5) + rec.mvy;
+    const int X = (mb_x << 5) + (int16_t)(w_mv & 0xFFFF), Y = (mb_y << 5) + (int16_t)(w_mv >> 16);
     const int CX = X >> 1, CY = Y >> 1;  // chroma uses the floor of the halved POSITION
     const int x0 = X >> 1, y0 = Y >> 1, cx0 = CX >> 1, cy0 = CY >> 1;
 
-    // ---- issue the coefficient loads first (independent of the reference windows) --------------------
+    // ---- issue every global load up front: coefficients, then the reference window rows ------------
     uint32_t ce = 0;
     if (lane < total)
         ce = coefs[rec.coef_base + lane];
 
-    if (!intra) {
-        // ---- stage the reference windows in LDS --------------------------------------------------------
-        const bool inside = x0 >= 0 && y0 >= 0 && x0 + 16 + (X & 1) <= EFX_FRAME_WIDTH &&
-                            y0 + 16 + (Y & 1) <= EFX_FRAME_HEIGHT && cx0 >= 0 && cy0 >= 0 &&
-                            cx0 + 8 + (CX & 1) <= EFX_FRAME_WIDTH / 2 && cy0 + 8 + (CY & 1) <= EFX_FRAME_HEIGHT / 2;
-        if (inside) {
-            // Every pixel that reaches the output is inside the picture.  One lane per window row:
-            // lanes 0..16 fetch the 20 luma bytes (16 + 4) of a row, lanes 32..49 the 12 bytes of a
-            // chroma row, from 4-byte aligned addresses (the reference's _src_align copy,
-            // player.cpp:739-759).  Rows past the needed window are clamped into the frame.
-            if (lane < 17) {
-                const uint8_t* p = ref + luma_row_off(min(y0 + lane, EFX_FRAME_HEIGHT - 1)) + (x0 & ~3);
-                uint4 a = *reinterpret_cast<const uint4*>(p);
-                uint32_t b = *reinterpret_cast<const uint32_t*>(p + 16);
-                uint32_t* t = luma_tile + lane * (kLumaPitch / 4);
-                *reinterpret_cast<uint4*>(t) = a;
-                t[4] = b;
-            } else if (lane >= 32 && lane < 50) {
-                const int j = lane - 32, plane = j >= 9 ? 2 : 1, r = j >= 9 ? j - 9 : j;
-                const uint8_t* p = ref + chroma_row_off(plane, min(cy0 + r, EFX_FRAME_HEIGHT / 2 - 1));
-                const int cxa = cx0 & ~3;  // dwords beyond the row end are never used: keep them inside the row
-                uint32_t a = *reinterpret_cast<const uint32_t*>(p + cxa);
-                uint32_t b = *reinterpret_cast<const uint32_t*>(p + min(cxa + 4, EFX_FRAME_WIDTH / 2 - 4));
-                uint32_t c = *reinterpret_cast<const uint32_t*>(p + min(cxa + 8, EFX_FRAME_WIDTH / 2 - 4));
-                uint32_t* t = chroma_tile + j * (kChromaPitch / 4);
-                t[0] = a;
-                t[1] = b;
-                t[2] = c;
-            }
-        } else {
-            // vector points outside the picture (undefined in the reference): clamp per pixel
-            uint8_t* lt = reinterpret_cast<uint8_t*>(luma_tile);
-            uint8_t* ct = reinterpret_cast<uint8_t*>(chroma_tile);
-            for (int i = lane; i < 17 * 17 + 2 * 9 * 9; i += 64) {
-                if (i < 289) {
-                    int r = i / 17, c = i - r * 17;
-                    int yy = clampi(y0 + r, 0, EFX_FRAME_HEIGHT - 1), xx = clampi(x0 + c, 0, EFX_FRAME_WIDTH - 1);
-                    lt[r * kLumaPitch + (x0 & 3) + c] = ref[luma_row_off(yy) + xx];
-                } else {
-                    int j = i - 289;
-                    int plane = 1 + j / 81;
-                    j -= (plane - 1) * 81;
-                    int r = j / 9, c = j - r * 9;
-                    int yy = clampi(cy0 + r, 0, EFX_FRAME_HEIGHT / 2 - 1), xx = clampi(cx0 + c, 0, EFX_FRAME_WIDTH / 2 - 1);
-                    ct[((plane - 1) * 9 + r) * kChromaPitch + (cx0 & 3) + c] = ref[chroma_row_off(plane, yy) + xx];
-                }
-            }
+    const bool inside = x0 >= 0 && y0 >= 0 && x0 + 16 + (X & 1) <= EFX_FRAME_WIDTH &&
+                        y0 + 16 + (Y & 1) <= EFX_FRAME_HEIGHT && cx0 >= 0 && cy0 >= 0 &&
+                        cx0 + 8 + (CX & 1) <= EFX_FRAME_WIDTH / 2 && cy0 + 8 + (CY & 1) <= EFX_FRAME_HEIGHT / 2;
+    const bool stage = !intra && inside && lane < 35;
+    uint4 ta = make_uint4(0, 0, 0, 0);
+    uint32_t tb = 0;
+    if (stage) {
+        // Every pixel that reaches the output is inside the picture.  One lane per window row, 20
+        // bytes from a 4-byte aligned address (the reference's _src_align copy, player.cpp:739-759):
+        // lanes 0..16 luma rows y0.., lanes 17..25 / 26..34 the chroma rows cy0.. of the two planes.
+        // A frame is 192 consecutive rows of 528 bytes; chroma row c of plane p sits in frame row
+        // (c >> 3) * 16 + (c & 7) + 8 * (p - 1) at byte 352.  Rows / bytes beyond the needed window
+        // may fall outside the frame; they are never used (the frame pool ends with slack).
+        int off;
+        if (lane < 17)
+            off = (y0 + lane) * kStride + (x0 & ~3);
+        else {
+            const int j = lane - 17, p2 = j >= 9, c = cy0 + (p2 ? j - 9 : j);
+            off = (((c >> 3) << 4) + (c & 7) + (p2 ? 8 : 0)) * kStride + EFX_FRAME_WIDTH + (cx0 & ~3);
         }
+        ta = *reinterpret_cast<const uint4*>(ref + off);
+        tb = *reinterpret_cast<const uint32_t*>(ref + off + 16);
     }
 
     // ---- scatter the coefficient entries ----------------------------------------------------
@@ -181,7 +165,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     int my_cnt = 0;
     if (total > 0) {  // wave-uniform: macroblocks without coefficients skip the whole residual path
         if (worker) {
-            my_cnt = rec.cnt[blk];
+            my_cnt = (int)(((blk < 4 ? w_cnt : w_misc) >> ((blk & 3) * 8)) & 0xFF);
             if (my_cnt > 0) {
 #pragma unroll
                 for (int j = 0; j < 9; j++)
@@ -199,10 +183,9 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             uint32_t e = (i < 64) ? ce : coefs[rec.coef_base + i];
             int b = (i >= pre1) + (i >= pre2) + (i >= pre3) + (i >= pre4) + (i >= pre5);
             int n = e & 63, level = (int)e >> 6;
-            int first = b == 0 ? 0 : (b == 1 ? pre1 : (b == 2 ? pre2 : (b == 3 ? pre3 : (b == 4 ? pre4 : pre5))));
             uint32_t t = qt[n];
             int val;
-            if (intra && i == first)
+            if (intra && n == 0)  // scan position 0 of an intra block is its DC entry (AC starts at 1)
                 val = level << 8;  // b[0] = dc << 8 (player.cpp:1065)
             else {
                 int q = intra ? (int)((t >> 16) & 0xFF) : (int)(t >> 24);
@@ -219,6 +202,28 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             cf[b * kBlkPitch + (t & 63)] = val;
             if (n == 0)
                 zflag[b] = 1;
+        }
+    }
+    if (stage) {
+        uint32_t* t = tile + lane * (kTilePitch / 4);
+        *reinterpret_cast<uint4*>(t) = ta;
+        t[4] = tb;
+    } else if (!intra && !inside) {
+        // vector points outside the picture (undefined in the reference): clamp per pixel
+        uint8_t* tt = reinterpret_cast<uint8_t*>(tile);
+        for (int i = lane; i < 17 * 17 + 2 * 9 * 9; i += 64) {
+            if (i < 289) {
+                int r = i / 17, c = i - r * 17;
+                int yy = clampi(y0 + r, 0, EFX_FRAME_HEIGHT - 1), xx = clampi(x0 + c, 0, EFX_FRAME_WIDTH - 1);
+                tt[r * kTilePitch + (x0 & 3) + c] = ref[luma_row_off(yy) + xx];
+            } else {
+                int j = i - 289;
+                int plane = 1 + j / 81;
+                j -= (plane - 1) * 81;
+                int r = j / 9, c = j - r * 9;
+                int yy = clampi(cy0 + r, 0, EFX_FRAME_HEIGHT / 2 - 1), xx = clampi(cx0 + c, 0, EFX_FRAME_WIDTH / 2 - 1);
+                tt[(17 + (plane - 1) * 9 + r) * kTilePitch + (cx0 & 3) + c] = ref[chroma_row_off(plane, yy) + xx];
+            }
         }
     }
     __syncthreads();
@@ -299,21 +304,11 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     // ---- prediction: the four half-pel cases of mocomp(), player.cpp:767-820 ----------------------
     uint32_t p_lo, p_hi;
     {
-        const uint32_t* t;
-        int pitch, col, hx, hy;
-        if (blk < 4) {
-            t = luma_tile + ((blk >> 1) * 8 + row) * (kLumaPitch / 4);
-            pitch = kLumaPitch / 4;
-            col = (x0 & 3) + (blk & 1) * 8;
-            hx = X & 1;
-            hy = Y & 1;
-        } else {
-            t = chroma_tile + ((blk - 4) * 9 + row) * (kChromaPitch / 4);
-            pitch = kChromaPitch / 4;
-            col = cx0 & 3;
-            hx = CX & 1;
-            hy = CY & 1;
-        }
+        const int pitch = kTilePitch / 4;
+        const bool luma = blk < 4;
+        const uint32_t* t = tile + (luma ? (blk >> 1) * 8 + row : 17 + (blk - 4) * 9 + row) * pitch;
+        const int col = luma ? (x0 & 3) + (blk & 1) * 8 : (cx0 & 3);
+        const int hx = (luma ? X : CX) & 1, hy = (luma ? Y : CY) & 1;
         const int w0 = col >> 2, sh = col & 3;
         // 12 bytes starting at the dword holding `col`, for this row and the next
         uint32_t a0 = t[w0], a1 = t[w0 + 1], a2 = t[w0 + 2];
