@@ -126,6 +126,83 @@ __device__ inline int decode_motion(BitReader& br, const uint16_t* tab, int pred
     return m;
 }
 
+// DC size + differential of an intra block, player.cpp:1010-1068 (tables B-5a / B-5b): at most
+// 10 + 11 bits, all inside one window.  Updates the predictor, returns the DC value and the bits used.
+__device__ inline int decode_dc(uint32_t win, int blk, int& dc_y, int& dc_cr, int& dc_cb, uint32_t& used)
+{
+    int size, len, pred;
+    if (blk < 4) {
+        uint32_t pb = win >> 23;
+        int ones = __clz((int)~(pb << 23));
+        if (ones == 0) {
+            size = 1 + (int)((pb >> 7) & 1);
+            len = 2;
+        } else if (ones == 1) {
+            size = (pb & 0x40) ? 3 : 0;
+            len = 3;
+        } else {
+            size = ones + 2;
+            len = ones + 1;
+        }
+        pred = dc_y;
+    } else {
+        uint32_t pb = win >> 22;
+        int ones = __clz((int)~(pb << 22));
+        if (ones == 0) {
+            size = (int)((pb >> 8) & 1);
+            len = 2;
+        } else {
+            size = ones + 1;
+            len = size < 10 ? size : 10;
+        }
+        pred = (blk == 4) ? dc_cr : dc_cb;
+    }
+    if (size) {
+        int delta = (int)((win << len) >> (32 - size));
+        len += size;
+        if (delta & (1 << (size - 1)))
+            pred += delta;
+        else
+            pred += (int)((~0u << size) | (uint32_t)(delta + 1));
+        if (blk == 4)
+            dc_cr = pred;
+        else if (blk == 5)
+            dc_cb = pred;
+        else
+            dc_y = pred;
+    }
+    used = (uint32_t)len;
+    return pred;
+}
+
+// One DCT run/level symbol from a 32-bit window and its table entry, BRANCH-FREE (selects only):
+// a lone wave issues a dependent instruction only every ~8 cycles, and only straight-line code
+// lets the scheduler interleave this off-chain work with the window -> table -> length chain.
+struct DctSymbol {
+    uint32_t len;  // bits consumed
+    uint32_t run;
+    int level;     // signed
+    bool eob, bad;
+};
+__device__ inline DctSymbol decode_symbol(uint32_t win, uint32_t ent)
+{
+    DctSymbol y;
+    const uint32_t len_f = ent & 31, run_f = (ent >> 5) & 31, lev_f = ent >> 10;
+    y.bad = len_f == 0;           // invalid code
+    y.eob = lev_f == 63;          // "10": end_of_block
+    const bool esc = lev_f == 0;  // escape: 6-bit run, 8- or 16-bit level (player.cpp:1092-1099)
+    const int lvl_n = ((win << len_f) >> 31) ? -(int)lev_f : (int)lev_f;
+    const uint32_t lv8 = (win << 12) >> 24, ext = (win << 20) >> 24;
+    const bool two = (lv8 & 0x7F) == 0;
+    const int lvl_e = two ? (lv8 ? (int)ext - 256 : (int)ext) : (lv8 > 128 ? (int)lv8 - 256 : (int)lv8);
+    y.level = esc ? lvl_e : lvl_n;
+    y.run = esc ? (win << 6) >> 26 : run_f;
+    uint32_t len = esc ? (two ? 28u : 20u) : len_f + 1;
+    len = y.eob ? 2u : len;
+    y.len = y.bad ? 0u : len;
+    return y;
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, const SliceDesc* __restrict__ descs,
@@ -294,10 +371,7 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
         }
         br.advance(used);
 
-        MbRec rec;
-        rec.coef_base = coef_idx;
-        rec.epoch = (uint8_t)epoch;
-        rec.flags = (uint8_t)((intra ? 1 : 0) | (qscale << 2) | (custom_q ? 0x80 : 0));
+        const uint32_t mb_coef_base = coef_idx;
         if (intra) {
             mv_h = mv_v = 0;  // player.cpp:1300
         } else {
@@ -312,8 +386,9 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
             } else
                 mv_h = mv_v = 0;
         }
-        rec.mvx = (int16_t)(full_pel ? mv_h << 1 : mv_h);  // predict(), player.cpp:878-881
-        rec.mvy = (int16_t)(full_pel ? mv_v << 1 : mv_v);
+        // predict(), player.cpp:878-881: full-pel vectors are doubled
+        const uint32_t rec_mv = ((uint32_t)(full_pel ? mv_h << 1 : mv_h) & 0xFFFF) | ((uint32_t)(full_pel ? mv_v << 1 : mv_v) << 16);
+        const uint32_t rec_flags = (uint32_t)((intra ? 1 : 0) | (qscale << 2) | (custom_q ? 0x80 : 0));
 
         int cbp = intra ? 63 : 0;
         if (type & 0x02) {
@@ -326,80 +401,33 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
             cbp = (int)(c >> 4);
         }
 
+        // ---- the coded blocks ---------------------------------------------------------------------
+        // Per block: [intra: DC] then run/level pairs up to end_of_block (player.cpp:1070-1122).  The
+        // symbol decoded in one iteration is stored in the NEXT iteration, in the shadow of that
+        // iteration's table look-up (software pipeline of depth one), so the serial chain per symbol
+        // is only  window -> table -> length -> position.  The pipeline is seeded with the intra DC
+        // entry, or with "1s" = (0, +-1) when a non-intra block opens with a 1 bit (end_of_block
+        // cannot come first); when it starts empty the first store lands on a slot that the next
+        // real entry overwrites (coef_idx is not advanced).
         bool bad = false;
+        uint32_t cnt_lo = 0, cnt_hi = 0;  // entries per block: blocks 0-3 / 4-5, one byte each
         for (int blk = 0; blk < 6; blk++) {
-            rec.cnt[blk] = 0;
             if (!(cbp & (0x20 >> blk)))
                 continue;
             const uint32_t blk_start = coef_idx;
-            int n = 0;
-            int dc_value = 0;
             br.topup();
             win = br.window();
+            uint32_t pend_valid;
+            int pend_level, pend_n = 0, n;
             if (intra) {
-                // DC size + differential, player.cpp:1010-1068 (table B-5a / B-5b): <= 10 + 11 bits
-                int size, len, pred;
-                if (blk < 4) {
-                    uint32_t pb = win >> 23;
-                    int ones = __clz((int)~(pb << 23));
-                    if (ones == 0) {
-                        size = 1 + (int)((pb >> 7) & 1);
-                        len = 2;
-                    } else if (ones == 1) {
-                        size = (pb & 0x40) ? 3 : 0;
-                        len = 3;
-                    } else {
-                        size = ones + 2;
-                        len = ones + 1;
-                    }
-                    pred = dc_y;
-                } else {
-                    uint32_t pb = win >> 22;
-                    int ones = __clz((int)~(pb << 22));
-                    if (ones == 0) {
-                        size = (int)((pb >> 8) & 1);
-                        len = 2;
-                    } else {
-                        size = ones + 1;
-                        len = size < 10 ? size : 10;
-                    }
-                    pred = (blk == 4) ? dc_cr : dc_cb;
-                }
-                if (size) {
-                    int delta = (int)((win << len) >> (32 - size));
-                    len += size;
-                    if (delta & (1 << (size - 1)))
-                        pred += delta;
-                    else
-                        pred += (int)((~0u << size) | (uint32_t)(delta + 1));
-                    if (blk == 4)
-                        dc_cr = pred;
-                    else if (blk == 5)
-                        dc_cb = pred;
-                    else
-                        dc_y = pred;
-                }
-                br.advance(len);
-                dc_value = pred;
+                uint32_t used;
+                pend_level = decode_dc(win, blk, dc_y, dc_cr, dc_cb, used);
+                br.advance(used);
+                pend_valid = 1;
                 n = 1;
-                win = br.window();
-            }
-
-            // run/level pairs, player.cpp:1070-1122.  Software pipeline of depth one: the symbol decoded
-            // in iteration i (pend_level at scan position pend_n) is stored in iteration i+1, in the
-            // shadow of that iteration's table look-up, so the serial chain per symbol is only
-            // window -> table -> length -> position.  The body is BRANCH-FREE (selects, one
-            // unconditional store): a lone wave issues a dependent instruction only every ~8 cycles,
-            // and only a single basic block lets the scheduler interleave the off-chain work
-            // (escape decode, sign, store address) with the chain.
-            //   intra:      the pipeline is seeded with the DC entry (value at scan position 0);
-            //   non-intra:  with "1s" = (0, +-1) if the block opens with a 1 bit (end_of_block cannot
-            //               come first), otherwise empty -- the first store then lands on a slot that
-            //               the next real entry overwrites (coef_idx is not advanced).
-            uint32_t pend_valid = intra ? 1u : (win >> 31);
-            int pend_level = intra ? dc_value : (((win >> 30) & 1) ? -1 : 1);
-            int pend_n = 0;
-            if (!intra) {
+            } else {
+                pend_valid = win >> 31;
+                pend_level = ((win >> 30) & 1) ? -1 : 1;
                 n = (int)pend_valid;
                 br.advance(pend_valid << 1);
             }
@@ -414,32 +442,18 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                 win = br.window();
                 const uint32_t pk = win >> 16;
                 const uint32_t ent = (pk >= 0x0400) ? sh.t.dct_hi[pk >> 8] : sh.t.dct_lo[pk & 0x3FF];
-
-                // emit the previous symbol: (signed level, scan position)
                 coefs[min(coef_idx, coef_last)] = ((uint32_t)pend_level << 6) | (uint32_t)pend_n;
                 coef_idx += pend_valid;
-
-                const uint32_t len_f = ent & 31, run_f = (ent >> 5) & 31, lev_f = ent >> 10;
-                const bool bad_now = len_f == 0;   // invalid code
-                const bool eob = lev_f == 63;      // "10": end_of_block
-                const bool esc = lev_f == 0;       // escape: 6-bit run, 8- or 16-bit level (player.cpp:1092-1099)
-                const int lvl_n = ((win << len_f) >> 31) ? -(int)lev_f : (int)lev_f;
-                const uint32_t lv8 = (win << 12) >> 24, ext = (win << 20) >> 24;
-                const bool two = (lv8 & 0x7F) == 0;
-                const int lvl_e = two ? (lv8 ? (int)ext - 256 : (int)ext) : (lv8 > 128 ? (int)lv8 - 256 : (int)lv8);
-                const int level = esc ? lvl_e : lvl_n;
-                const uint32_t run = esc ? (win << 6) >> 26 : run_f;
-                uint32_t len = esc ? (two ? 28u : 20u) : len_f + 1;
-                len = eob ? 2u : len;
-                br.advance(bad_now ? 0u : len);
-                const int n_new = n + (int)run;
-                const bool drop = !eob && !bad_now && n_new >= 64;  // player.cpp:1106-1107: block abandoned
-                cont = !(eob || bad_now || drop);
+                const DctSymbol y = decode_symbol(win, ent);
+                br.advance(y.len);
+                const int n_new = n + (int)y.run;
+                const bool drop = !y.eob && !y.bad && n_new >= 64;  // player.cpp:1106-1107: block abandoned
+                cont = !(y.eob || y.bad || drop);
                 pend_valid = cont;
                 pend_n = n_new & 63;
-                pend_level = level;
+                pend_level = y.level;
                 n = n_new + 1;
-                bad |= bad_now;
+                bad |= y.bad;
                 dropped |= drop;
             } while (cont);
             if (bad)
@@ -448,11 +462,17 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                 st |= EFX_STREAM_COEF_OVERRUN;
                 coef_idx = blk_start;  // forget the partial block
             } else {
-                rec.cnt[blk] = (uint8_t)(coef_idx - blk_start);
-                n_coefs += coef_idx - blk_start;
+                const uint32_t c = coef_idx - blk_start;
+                n_coefs += c;
+                if (blk < 4)
+                    cnt_lo |= c << (8 * blk);
+                else
+                    cnt_hi |= c << (8 * (blk - 4));
             }
         }
-        recs[mb_addr] = rec;
+        // MbRec: coef_base | cnt[0..3] | cnt[4] cnt[5] flags epoch | mvx mvy
+        *reinterpret_cast<uint4*>(&recs[mb_addr]) =
+            make_uint4(mb_coef_base, cnt_lo, cnt_hi | (rec_flags << 16) | ((uint32_t)(epoch & 0xFF) << 24), rec_mv);
         n_mbs++;
         if (bad) {
             st |= EFX_STREAM_BAD_VLC;
