@@ -145,8 +145,12 @@ __global__ __launch_bounds__(256) void k_composite(const uint8_t* __restrict__ f
             }
             o = make_uint4(w[0], w[1], w[2], w[3]);
         }
+        // the field is written once and never re-read by this kernel: stream it past the caches
         uint16_t* dst = out + ((size_t)s * v.line_count + i) * v.line_width + g * 8;
-        *reinterpret_cast<uint4*>(dst) = o;
+        __builtin_nontemporal_store(o.x, reinterpret_cast<uint32_t*>(dst) + 0);
+        __builtin_nontemporal_store(o.y, reinterpret_cast<uint32_t*>(dst) + 1);
+        __builtin_nontemporal_store(o.z, reinterpret_cast<uint32_t*>(dst) + 2);
+        __builtin_nontemporal_store(o.w, reinterpret_cast<uint32_t*>(dst) + 3);
     }
 }
 
