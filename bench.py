@@ -33,6 +33,18 @@ FRAME_BYTES = 101376
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def pmc_traffic(kernel, S, P):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE, separate runs, gfx950 correction applied by tools/summarize_profiles.py).  PMC
+    counters cannot be collected from inside this process, so the figure is the one measured
+    on this exact workload (1024 streams x GOP 12) and None for any other."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_summary.json")
+    if (S, P) != (1024, 12) or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["kernels"].get(kernel, {}).get("hbm_traffic_bytes")
+
+
 def algorithmic_bytes(es_bytes: int, n_i: int, n_p: int) -> int:
     """I picture = B + 101376, P picture = B + 202752."""
     return es_bytes + n_i * FRAME_BYTES + n_p * 2 * FRAME_BYTES
@@ -187,6 +199,7 @@ def main():
         launches = [1, 1, P]
         dur_s = stage_ms[k] / 1e3 / launches[k]
         achieved = alg / launches[k] / dur_s / 1e9
+        traffic = pmc_traffic(["efx::k_index", "efx::k_parse", "efx::k_recon"][k], S, P)
         out = {
             "metric": "MPEG-1 352x192 frames/s", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -197,7 +210,7 @@ def main():
                        "mean_bytes_per_picture": es_bytes / (S * P), "parallelism": f"stream-partition x{world}",
                        "ring_depth": 2},
             "roofline": {"bound": "hbm", "kernel": names[k], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg / launches[k], "avg_launch_ms": dur_s * 1e3,
                          "whole_step_achieved_GBs": alg / (elapsed / args.steps) / 1e9,
                          "stage_ms": dict(zip(names, [float(x) for x in stage_ms]))},

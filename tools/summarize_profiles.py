@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/) into the tracked summaries under profiles/.
+
+    python tools/summarize_profiles.py <tag> --stats DIR/PREFIX ... --pmc DIR ...
+
+Writes profiles/<tag>_kernel_stats_<name>.csv (verbatim rocprofv3 --stats table) and
+profiles/<tag>_pmc_summary.json: per kernel the mean of every counter over its dispatches.
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB-like units of 1024 B; on gfx950
+FETCH_SIZE counts 128-byte requests as 64 B (MI355X_MICROARCH.md, HBM section) -- calibrated
+here on k_frame_hash, which reads every ring frame exactly once -- so hbm_read_bytes = 2 x
+FETCH_SIZE x 1024; WRITE_SIZE is taken as reported (partial-line writes are counted as 32 B
+requests, which over-counts kernels that store narrow per-lane words).
+"""
+import argparse, collections, csv, json, os, shutil, sys
+
+ap = argparse.ArgumentParser()
+ap.add_argument("tag")
+ap.add_argument("--stats", nargs="*", default=[])
+ap.add_argument("--pmc", nargs="*", default=[])
+ap.add_argument("--note", default="")
+a = ap.parse_args()
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+
+for s in a.stats:
+    name = os.path.basename(s)
+    shutil.copy(s + "_kernel_stats.csv", os.path.join(out, f"{a.tag}_kernel_stats_{name}.csv"))
+
+summary = collections.defaultdict(dict)
+for d in a.pmc:
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in os.listdir(d):
+        if not f.endswith("counter_collection.csv"):
+            continue
+        for r in csv.DictReader(open(os.path.join(d, f))):
+            k = r["Kernel_Name"].split("(")[0]
+            if k.startswith("efx::"):
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in agg.items():
+        for c, v in cs.items():
+            summary[k][c] = sum(v) / len(v)
+            summary[k]["dispatches_" + c] = len(v)
+for k, cs in summary.items():
+    if "FETCH_SIZE" in cs:
+        cs["hbm_read_bytes"] = 2.0 * cs["FETCH_SIZE"] * 1024.0
+    if "WRITE_SIZE" in cs:
+        cs["hbm_write_bytes"] = cs["WRITE_SIZE"] * 1024.0
+    if "hbm_read_bytes" in cs and "hbm_write_bytes" in cs:
+        cs["hbm_traffic_bytes"] = cs["hbm_read_bytes"] + cs["hbm_write_bytes"]
+if summary:
+    json.dump({"note": a.note, "kernels": summary}, open(os.path.join(out, f"{a.tag}_pmc_summary.json"), "w"), indent=1,
+              sort_keys=True)
+    print(json.dumps(summary, indent=1, sort_keys=True))
