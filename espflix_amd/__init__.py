@@ -61,7 +61,8 @@ class _VideoParams(C.Structure):
 
 class _Timing(C.Structure):
     _fields_ = [("index_ms", C.c_float), ("parse_ms", C.c_float), ("recon_ms", C.c_float), ("total_ms", C.c_float),
-                ("pictures", C.c_uint64), ("slices", C.c_uint64), ("coefficients", C.c_uint64), ("es_bytes", C.c_uint64)]
+                ("pictures", C.c_uint64), ("slices", C.c_uint64), ("coefficients", C.c_uint64), ("es_bytes", C.c_uint64),
+                ("demux_ms", C.c_float), ("reserved", C.c_float), ("ts_bytes", C.c_uint64)]
 
 
 # every symbol include/efx.h declares: (name, restype, argtypes)
@@ -72,6 +73,7 @@ _SYMBOLS = {
     "efx_last_error": (C.c_char_p, [_P]),
     "efx_status_string": (C.c_char_p, [C.c_int]),
     "efx_upload_streams": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t), C.c_int]),
+    "efx_download_es": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "efx_reset": (C.c_int, [_P]),
     "efx_erase_frames": (C.c_int, [_P]),
     "efx_decode": (C.c_int, [_P]),
@@ -143,6 +145,8 @@ class Timing:
     slices: int
     coefficients: int
     es_bytes: int
+    demux_ms: float = 0.0
+    ts_bytes: int = 0
 
 
 class DeviceBuffer:
@@ -235,6 +239,14 @@ class Decoder:
         _check(self._ctx, self._lib.efx_stream_status(self._ctx, stream, C.byref(b)))
         return b.value
 
+    def es(self, stream: int) -> bytes:
+        """The elementary stream the decoder sees for `stream` (device-demultiplexed for TS input)."""
+        n = C.c_size_t()
+        _check(self._ctx, self._lib.efx_download_es(self._ctx, stream, None, 0, C.byref(n)))
+        buf = (C.c_uint8 * max(n.value, 1))()
+        _check(self._ctx, self._lib.efx_download_es(self._ctx, stream, buf, n.value, C.byref(n)))
+        return bytes(buf[: n.value])
+
     def picture_pts(self, stream: int, picture: int) -> int:
         p = C.c_int64()
         _check(self._ctx, self._lib.efx_picture_pts(self._ctx, stream, picture, C.byref(p)))
@@ -291,4 +303,5 @@ class Decoder:
     def timing(self) -> Timing:
         t = _Timing()
         _check(self._ctx, self._lib.efx_get_timing(self._ctx, C.byref(t)))
-        return Timing(t.index_ms, t.parse_ms, t.recon_ms, t.total_ms, t.pictures, t.slices, t.coefficients, t.es_bytes)
+        return Timing(t.index_ms, t.parse_ms, t.recon_ms, t.total_ms, t.pictures, t.slices, t.coefficients, t.es_bytes,
+                      t.demux_ms, t.ts_bytes)

@@ -14,9 +14,11 @@
 #include "efx_internal.h"
 
 namespace efx {
-// kernels (k_index.hip, k_parse.hip, k_recon.hip, k_video.hip)
+// kernels (k_demux.hip, k_index.hip, k_parse.hip, k_recon.hip, k_video.hip)
+__global__ void k_demux(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, uint8_t*, uint32_t*, PesEntry*,
+                        uint32_t*);
 __global__ void k_index(const uint8_t*, const uint64_t*, int, PicInfo*, SliceTmp*, uint32_t*, uint32_t*, uint32_t*,
-                        const uint32_t*);
+                        const uint32_t*, const PesEntry*, const uint32_t*, const uint32_t*, int64_t*);
 __global__ void k_slice_scan(const PicInfo*, const uint32_t*, int, int, uint32_t*, DecodeCounters*);
 __global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, const uint64_t*, const uint32_t*, int, int,
                              SliceDesc*);
@@ -56,6 +58,18 @@ struct efx_ctx {
     uint32_t* d_slice_base = nullptr;
     SliceDesc* d_descs = nullptr;
     uint8_t* d_frames = nullptr;
+    // transport-stream input (allocated on the first EFX_FORMAT_TS upload)
+    uint8_t* d_ts = nullptr;
+    uint32_t* d_ts_len = nullptr;    // per stream: TS bytes
+    uint32_t* d_pkt_base = nullptr;  // per stream: first entry of its PES list (= packets before it)
+    uint32_t* d_es_len = nullptr;    // per stream: demuxed ES bytes (without tail)
+    uint32_t* d_pes_count = nullptr;
+    PesEntry* d_pes = nullptr;
+    size_t pes_cap = 0;
+    bool ts_input = false;
+    hipEvent_t ev_demux[2] = {nullptr, nullptr};
+    float demux_ms = 0.f;
+    size_t ts_bytes = 0;
     // Two sets of parse -> recon hand-over buffers: efx_decode() number n parses into slot n & 1
     // on the parse stream while the recon stream is still reconstructing call n - 1 from the
     // other slot, so back-to-back decodes overlap the two (differently bound) halves.
@@ -65,6 +79,7 @@ struct efx_ctx {
         DecodeCounters* d_counters = nullptr;
         MbRec* d_mbrecs = nullptr;
         uint32_t* d_coefs = nullptr;
+        int64_t* d_pts = nullptr;  // per (stream, picture): PTS latched at the picture header (TS input)
         hipEvent_t parse_done = nullptr, recon_done = nullptr;
         hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // timing: parse start, index end, parse end, recon end, recon start
         int epoch = 0;
@@ -79,7 +94,8 @@ struct efx_ctx {
     // host staging / results
     uint8_t* h_es = nullptr;  // pinned
     std::vector<uint64_t> h_stream_off;
-    std::vector<std::vector<int64_t>> pts;  // per stream, per picture (TS input)
+    std::vector<int64_t> h_pts;  // per (stream, picture), TS input only
+    std::vector<uint32_t> h_es_len;  // per stream, ES input only
     std::vector<uint32_t> h_pic_count, h_status;
     DecodeCounters h_counters{};
 
@@ -111,47 +127,6 @@ template <typename T>
 hipError_t dalloc(T** p, size_t n)
 {
     return hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
-}
-
-// TS -> ES on the host: PID 0x100 payloads with the PES header skipped at the reference's fixed
-// offsets (MpegDecoder::more/demux, player.cpp:381-436,459-493).  pes_pts receives (ES offset of
-// the first payload byte, pts) for every PES that carries a PTS.
-void demux_ts(const uint8_t* ts, size_t len, std::vector<uint8_t>& es, std::vector<std::pair<size_t, int64_t>>& pes_pts)
-{
-    for (size_t pos = 0; pos + 188 <= len; pos += 188) {
-        const uint8_t* p = ts + pos;
-        if (p[0] != 0x47) {
-            es.push_back(0);  // "ts lost sync": the reference hands the bit reader a zero byte
-            continue;
-        }
-        int pid = ((p[1] << 8) + p[2]) & 0x1fff;
-        const uint8_t* pay = p + 4;
-        if (p[3] & 0x20)
-            pay = p + 5 + p[4];
-        if (!(p[3] & 0x10))
-            continue;
-        const uint8_t* end = p + 188;
-        int64_t pts = -1;
-        if (p[1] & 0x40) {
-            if (pay + 9 > end)
-                continue;
-            const uint8_t* q = pay + 6;
-            int flags = (q[0] << 8) | q[1];
-            pay = q + 3 + q[2];
-            q += 3;
-            if ((flags & 0x0080) && q + 5 <= end && (q[0] & 0xF0) == ((flags >> 2) & 0x30)) {
-                pts = ((int64_t)(q[0] & 0x0E)) << 29;
-                pts += (int64_t)((((q[1] << 8) | q[2]) >> 1) << 15);
-                pts += (((q[3] << 8) | q[4]) >> 1);
-            }
-        }
-        if (pid != 0x100)
-            continue;
-        if (pts != -1)
-            pes_pts.emplace_back(es.size(), pts);
-        if (pay < end)
-            es.insert(es.end(), pay, end);
-    }
 }
 
 }  // namespace
@@ -274,12 +249,16 @@ void efx_destroy(efx_ctx* ctx)
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     void* bufs[] = {ctx->d_es,   ctx->d_stream_off, ctx->d_pics,  ctx->d_slices_tmp, ctx->d_qtab,     ctx->d_tables,
-                    ctx->d_slice_base, ctx->d_descs, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_hash};
+                    ctx->d_slice_base, ctx->d_descs, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_hash,
+                    ctx->d_ts, ctx->d_ts_len, ctx->d_pkt_base, ctx->d_es_len, ctx->d_pes_count, ctx->d_pes};
+    for (auto& ev : ctx->ev_demux)
+        if (ev)
+            (void)hipEventDestroy(ev);
     for (void* b : bufs)
         if (b)
             (void)hipFree(b);
     for (auto& sl : ctx->slot) {
-        void* sb[] = {sl.d_pic_count, sl.d_status, sl.d_counters, sl.d_mbrecs, sl.d_coefs};
+        void* sb[] = {sl.d_pic_count, sl.d_status, sl.d_counters, sl.d_mbrecs, sl.d_coefs, sl.d_pts};
         for (void* b : sb)
             if (b)
                 (void)hipFree(b);
@@ -308,45 +287,55 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
         return fail(ctx, EFX_ERR_CAPACITY, "efx_upload_streams: more streams than max_streams");
     EFX_HIP(hipStreamSynchronize(ctx->parse_stream));  // the bitstream buffer may still be in use
     EFX_HIP(hipStreamSynchronize(ctx->stream));
+    const bool is_ts = format == EFX_FORMAT_TS;
+    const size_t n_max = (size_t)ctx->cfg.max_streams;
+    if (is_ts && !ctx->d_ts) {
+        // transport-stream staging: the TS of stream i occupies the same region of d_ts that its
+        // elementary stream will occupy in d_es (an ES is never longer than its TS)
+        ctx->pes_cap = ctx->es_cap / 188 + n_max;
+        hipError_t e = dalloc(&ctx->d_ts, ctx->es_cap);
+        if (e == hipSuccess) e = dalloc(&ctx->d_ts_len, n_max);
+        if (e == hipSuccess) e = dalloc(&ctx->d_pkt_base, n_max);
+        if (e == hipSuccess) e = dalloc(&ctx->d_es_len, n_max);
+        if (e == hipSuccess) e = dalloc(&ctx->d_pes_count, n_max);
+        if (e == hipSuccess) e = dalloc(&ctx->d_pes, ctx->pes_cap);
+        for (auto& sl : ctx->slot)
+            if (e == hipSuccess) e = dalloc(&sl.d_pts, n_max * (size_t)ctx->cfg.max_pictures);
+        for (auto& ev : ctx->ev_demux)
+            if (e == hipSuccess) e = hipEventCreate(&ev);
+        if (e != hipSuccess)
+            return fail(ctx, EFX_ERR_DEVICE, "efx_upload_streams: transport-stream buffers", e);
+    }
     static const uint8_t tail[kEsTailBytes] = {0, 0, 0, 1, 0xB7, 0, 0, 1, 0xB7};
     ctx->h_stream_off.assign((size_t)n_streams + 1, 0);
-    ctx->pts.assign((size_t)n_streams, {});
-    size_t pos = 0;
-    std::vector<uint8_t> es;
-    std::vector<std::pair<size_t, int64_t>> pes;
+    ctx->h_es_len.assign((size_t)n_streams, 0);
+    std::vector<uint32_t> ts_len, pkt_base;
+    if (is_ts) {
+        ts_len.resize(n_streams);
+        pkt_base.resize(n_streams);
+    }
+    size_t pos = 0, packets = 0;
     for (int i = 0; i < n_streams; i++) {
         const uint8_t* src = data[i];
-        size_t n = len[i];
+        const size_t n = len[i];
         if (!src && n)
             return fail(ctx, EFX_ERR_ARG, "efx_upload_streams: null stream");
-        if (format == EFX_FORMAT_TS) {
-            es.clear();
-            pes.clear();
-            demux_ts(src, n, es, pes);
-            src = es.data();
-            n = es.size();
-        }
-        size_t padded = (n + kEsTailBytes + 15) & ~(size_t)15;
+        const size_t padded = (n + kEsTailBytes + 15) & ~(size_t)15;
         if (pos + padded + kEsGuardBytes > ctx->es_cap)
             return fail(ctx, EFX_ERR_CAPACITY, "efx_upload_streams: more bytes than max_stream_bytes");
         ctx->h_stream_off[i] = pos;
+        ctx->h_es_len[i] = (uint32_t)n;
         if (n)
             memcpy(ctx->h_es + pos, src, n);
-        memcpy(ctx->h_es + pos + n, tail, kEsTailBytes);
-        memset(ctx->h_es + pos + n + kEsTailBytes, 0, padded - n - kEsTailBytes);
-        if (format == EFX_FORMAT_TS) {
-            // PTS latched at each picture start code: the newest PES whose payload began no later
-            // than two bytes past the picture_start_code (the bit reader's look-ahead,
-            // player.cpp:348-352,692-702)
-            size_t k = 0;
-            int64_t cur = -1;
-            const uint8_t* b = ctx->h_es + pos;
-            for (size_t j = 0; j + 3 < n; j++)
-                if (b[j] == 0 && b[j + 1] == 0 && b[j + 2] == 1 && b[j + 3] == 0) {
-                    while (k < pes.size() && pes[k].first <= j + 3 + 2)
-                        cur = pes[k++].second;
-                    ctx->pts[i].push_back(cur);
-                }
+        if (is_ts) {
+            // raw packets; k_demux writes the ES, the end-of-data tail and the zero fill
+            memset(ctx->h_es + pos + n, 0, padded - n);
+            ts_len[i] = (uint32_t)n;
+            pkt_base[i] = (uint32_t)packets;
+            packets += n / 188;
+        } else {
+            memcpy(ctx->h_es + pos + n, tail, kEsTailBytes);
+            memset(ctx->h_es + pos + n + kEsTailBytes, 0, padded - n - kEsTailBytes);
         }
         pos += padded;
     }
@@ -354,13 +343,57 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
     ctx->h_stream_off[n_streams] = pos;
     ctx->es_used = pos;
     ctx->n_streams = n_streams;
-    EFX_HIP(hipMemcpyAsync(ctx->d_es, ctx->h_es, pos + kEsGuardBytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->ts_input = is_ts;
+    ctx->demux_ms = 0.f;
+    ctx->ts_bytes = 0;
+    hipStream_t st = ctx->stream;
     EFX_HIP(hipMemcpyAsync(ctx->d_stream_off, ctx->h_stream_off.data(), ((size_t)n_streams + 1) * sizeof(uint64_t),
-                           hipMemcpyHostToDevice, ctx->stream));
-    EFX_HIP(hipStreamSynchronize(ctx->stream));
+                           hipMemcpyHostToDevice, st));
+    if (is_ts) {
+        if (packets > ctx->pes_cap)
+            return fail(ctx, EFX_ERR_CAPACITY, "efx_upload_streams: PES list capacity");
+        EFX_HIP(hipMemcpyAsync(ctx->d_ts, ctx->h_es, pos + kEsGuardBytes, hipMemcpyHostToDevice, st));
+        EFX_HIP(hipMemcpyAsync(ctx->d_ts_len, ts_len.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        EFX_HIP(hipMemcpyAsync(ctx->d_pkt_base, pkt_base.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        EFX_HIP(hipMemsetAsync(ctx->d_es + pos, 0, kEsGuardBytes, st));
+        // MpegDecoder::more()/demux() for the whole batch (player.cpp:381-493)
+        if (ctx->timing)
+            EFX_HIP(hipEventRecord(ctx->ev_demux[0], st));
+        hipLaunchKernelGGL(k_demux, dim3(n_streams), dim3(256), 0, st, ctx->d_ts, ctx->d_stream_off, ctx->d_ts_len,
+                           ctx->d_pkt_base, ctx->d_es, ctx->d_es_len, ctx->d_pes, ctx->d_pes_count);
+        if (ctx->timing)
+            EFX_HIP(hipEventRecord(ctx->ev_demux[1], st));
+        EFX_HIP(hipGetLastError());
+        for (int i = 0; i < n_streams; i++)
+            ctx->ts_bytes += ts_len[i];
+    } else
+        EFX_HIP(hipMemcpyAsync(ctx->d_es, ctx->h_es, pos + kEsGuardBytes, hipMemcpyHostToDevice, st));
+    EFX_HIP(hipStreamSynchronize(st));
+    if (is_ts && ctx->timing)
+        EFX_HIP(hipEventElapsedTime(&ctx->demux_ms, ctx->ev_demux[0], ctx->ev_demux[1]));
     ctx->uploaded = true;
     ctx->decoded = false;
     ctx->results_valid = false;
+    return EFX_OK;
+}
+
+int efx_download_es(efx_ctx* ctx, int stream, uint8_t* dst, size_t cap, size_t* es_len)
+{
+    if (!ctx || !es_len || stream < 0 || stream >= ctx->n_streams || (!dst && cap))
+        return EFX_ERR_ARG;
+    if (!ctx->uploaded)
+        return fail(ctx, EFX_ERR_STATE, "efx_download_es: no streams uploaded");
+    size_t n;
+    if (ctx->ts_input) {
+        uint32_t v = 0;
+        EFX_HIP(hipMemcpy(&v, ctx->d_es_len + stream, sizeof(v), hipMemcpyDeviceToHost));
+        n = v;
+    } else
+        n = ctx->h_es_len[stream];
+    *es_len = n;
+    size_t c = n < cap ? n : cap;
+    if (c)
+        EFX_HIP(hipMemcpy(dst, ctx->d_es + ctx->h_stream_off[stream], c, hipMemcpyDeviceToHost));
     return EFX_OK;
 }
 
@@ -404,7 +437,8 @@ int efx_decode(efx_ctx* ctx)
     if (sl.timed)
         EFX_HIP(hipEventRecord(sl.ev[0], sp));
     hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, sp, ctx->d_es, ctx->d_stream_off, P, ctx->d_pics, ctx->d_slices_tmp,
-                       sl.d_pic_count, sl.d_status, ctx->d_qtab, ctx->d_tables->scan);
+                       sl.d_pic_count, sl.d_status, ctx->d_qtab, ctx->d_tables->scan, ctx->d_pes, ctx->d_pkt_base,
+                       ctx->d_pes_count, ctx->ts_input ? sl.d_pts : nullptr);
     hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, ctx->d_pics, sl.d_pic_count, n, P, ctx->d_slice_base,
                        sl.d_counters);
     hipLaunchKernelGGL(k_slice_emit, dim3((n * P * kMaxSlicesPerPicture + 255) / 256), dim3(256), 0, sp, ctx->d_pics,
@@ -457,6 +491,10 @@ static int fetch_results(efx_ctx* ctx)
     EFX_HIP(hipMemcpy(ctx->h_pic_count.data(), sl.d_pic_count, ctx->n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost));
     EFX_HIP(hipMemcpy(ctx->h_status.data(), sl.d_status, ctx->n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost));
     EFX_HIP(hipMemcpy(&ctx->h_counters, sl.d_counters, sizeof(DecodeCounters), hipMemcpyDeviceToHost));
+    if (ctx->ts_input) {
+        ctx->h_pts.resize((size_t)ctx->n_streams * ctx->cfg.max_pictures);
+        EFX_HIP(hipMemcpy(ctx->h_pts.data(), sl.d_pts, ctx->h_pts.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    }
     ctx->results_valid = true;
     return EFX_OK;
 }
@@ -487,8 +525,14 @@ int efx_picture_pts(efx_ctx* ctx, int stream, int picture, int64_t* pts)
 {
     if (!ctx || !pts || stream < 0 || stream >= ctx->n_streams || picture < 0)
         return EFX_ERR_ARG;
-    const auto& v = ctx->pts[stream];
-    *pts = v.empty() ? (int64_t)picture : (picture < (int)v.size() ? v[picture] : -1);
+    if (!ctx->ts_input) {
+        *pts = picture;  // elementary-stream input carries no PTS: pictures are numbered
+        return EFX_OK;
+    }
+    int r = fetch_results(ctx);
+    if (r)
+        return r;
+    *pts = picture < (int)ctx->h_pic_count[stream] ? ctx->h_pts[(size_t)stream * ctx->cfg.max_pictures + picture] : -1;
     return EFX_OK;
 }
 
@@ -613,6 +657,8 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out)
     t.slices = ctx->h_counters.total_slices;
     t.coefficients = ctx->h_counters.coefficients;
     t.es_bytes = ctx->es_used;
+    t.demux_ms = ctx->demux_ms;
+    t.ts_bytes = ctx->ts_bytes;
     *out = t;
     return EFX_OK;
 }

@@ -1,6 +1,8 @@
 // efx_internal.h -- structures shared by the host side of libefx and its gfx950 kernels.
 //
 // Pipeline of one efx_decode():
+//   k_demux        (TS input, at upload) one workgroup per stream: 188-byte packets -> ES + PES PTS list
+//                                                                            (player.cpp:294-307,381-493)
 //   k_index        one wave per stream: start-code scan + header parse      (player.cpp:1355-1367,646-730)
 //   k_slice_scan   prefix sum of slice counts in picture-major order
 //   k_slice_emit   dense slice descriptors
@@ -31,6 +33,14 @@ struct PicInfo {
     uint8_t custom_q;      // 1: quantiser tables at qtab[(stream*max_pictures+pic)*64]
     uint16_t reserved;
     uint32_t seq_off;      // stream-relative offset of the governing sequence header payload
+    uint32_t start_off;    // stream-relative offset of the first byte after the picture start code
+};
+
+// one PES header that carried a PTS (k_demux): ES offset of its first payload byte, 33-bit PTS
+struct PesEntry {
+    uint32_t es_off;
+    uint32_t reserved;
+    int64_t pts;
 };
 
 struct SliceTmp {

@@ -1,0 +1,213 @@
+// k_demux.hip -- MPEG transport stream -> video elementary stream, on the device (gfx950).
+//
+// Restates MpegDecoder::more() / demux() / parse_pts() (reference src/player.cpp:294-307,381-436,
+// 459-493) for a whole batch: the reference walks 188-byte packets one at a time, keeps PID 0x100,
+// skips the adaptation field and -- on payload_unit_start -- the PES header at its fixed offsets,
+// latching the PES PTS, and hands the remaining payload bytes to the bit reader.  Here one
+// workgroup owns one stream and walks it in chunks of kChunk packets:
+//
+//   1. the chunk (kChunk x 188 bytes, 16-byte aligned in the TS buffer) is staged in LDS with
+//      coalesced 16-byte loads;
+//   2. one thread per packet parses its header out of LDS -> (payload start, payload bytes, PTS);
+//   3. a workgroup prefix sum of the payload sizes gives every packet its ES offset (packet order
+//      is stream order) and compacts the PES PTS list;
+//   4. the ES bytes of the chunk are produced output-centric: one thread per destination dword,
+//      the source packet found by binary search in the LDS prefix array, four LDS byte reads,
+//      one coalesced dword store (byte stores only on the two ragged chunk edges).
+//
+// After the last packet the workgroup appends the reference's end-of-data tail
+// 00 | 00 00 01 B7 | 00 00 01 B7 (player.cpp:456,472) and zero-fills the stream's region.
+#include <hip/hip_runtime.h>
+
+#include "efx_internal.h"
+#include "efx.h"
+
+namespace efx {
+
+namespace {
+
+constexpr int kChunk = 128;  // packets per workgroup iteration
+constexpr int kTsPacket = 188;
+constexpr int kThreads = 256;
+
+__device__ inline uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d)
+            v += o;
+    }
+    return v;
+}
+
+}  // namespace
+
+// grid = streams, block = 256.  stream_off[s] .. stream_off[s+1] is the stream's region in BOTH
+// the TS buffer (first ts_len[s] bytes used) and the ES buffer (fully written here).
+__global__ __launch_bounds__(kThreads) void k_demux(const uint8_t* __restrict__ ts, const uint64_t* __restrict__ stream_off,
+                                                    const uint32_t* __restrict__ ts_len,
+                                                    const uint32_t* __restrict__ pkt_base, uint8_t* __restrict__ es,
+                                                    uint32_t* __restrict__ es_len, PesEntry* __restrict__ pes,
+                                                    uint32_t* __restrict__ pes_count)
+{
+    __shared__ uint4 sh_pkt4[kChunk * kTsPacket / 16 + 1];
+    __shared__ uint32_t sh_prefix[kChunk + 1];  // exclusive prefix of payload bytes; [npk] = chunk total
+    __shared__ int32_t sh_src[kChunk];          // LDS byte offset of the payload (-1: emit a zero byte)
+    __shared__ uint32_t sh_wave[2][4];          // per-wave totals: payload bytes, PTS flags
+
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint8_t* src = ts + stream_off[s];
+    uint8_t* dst = es + stream_off[s];
+    const uint32_t region = (uint32_t)(stream_off[s + 1] - stream_off[s]);
+    const uint32_t n_packets = ts_len[s] / kTsPacket;  // a trailing partial packet is never read (player.cpp:459-468)
+    PesEntry* my_pes = pes + pkt_base[s];
+    const uint8_t* pk = reinterpret_cast<const uint8_t*>(sh_pkt4);
+
+    uint32_t es_pos = 0, n_pes = 0;
+    for (uint32_t first = 0; first < n_packets; first += kChunk) {
+        const uint32_t npk = min((uint32_t)kChunk, n_packets - first);
+        // ---- 1. stage the chunk --------------------------------------------------------------
+        {
+            const uint4* g = reinterpret_cast<const uint4*>(src + (size_t)first * kTsPacket);  // 128 * 188 = 16 * 1504
+            const uint32_t n16 = (npk * kTsPacket + 15) / 16;  // may read <= 15 bytes past the packets: inside the buffer
+            for (uint32_t i = tid; i < n16; i += kThreads)
+                sh_pkt4[i] = g[i];
+        }
+        __syncthreads();
+        // ---- 2. one thread per packet --------------------------------------------------------
+        uint32_t n = 0, has_pts = 0;
+        int32_t from = 0;
+        int64_t pts = -1;
+        if ((uint32_t)tid < npk) {
+            const uint8_t* p = pk + tid * kTsPacket;
+            if (p[0] != 0x47) {
+                n = 1;  // "ts lost sync": the bit reader is handed one zero byte (player.cpp:465-467)
+                from = -1;
+            } else {
+                const uint32_t pid = ((p[1] << 8) + p[2]) & 0x1FFF;
+                int pay = 4;
+                if (p[3] & 0x20)
+                    pay = 5 + p[4];  // adaptation field
+                bool keep = (p[3] & 0x10) != 0;
+                if (keep && (p[1] & 0x40)) {  // payload_unit_start: PES header at fixed offsets (player.cpp:396-419)
+                    if (pay + 9 > kTsPacket)
+                        keep = false;
+                    else {
+                        const uint8_t* q = p + pay + 6;
+                        const uint32_t flags = (q[0] << 8) | q[1];
+                        pay += 9 + q[2];
+                        q += 3;
+                        if ((flags & 0x0080) && (q - p) + 5 <= kTsPacket && (q[0] & 0xF0) == ((flags >> 2) & 0x30)) {
+                            pts = ((int64_t)(q[0] & 0x0E)) << 29;  // parse_pts, player.cpp:294-307
+                            pts += (int64_t)((((q[1] << 8) | q[2]) >> 1) << 15);
+                            pts += (((q[3] << 8) | q[4]) >> 1);
+                        }
+                    }
+                }
+                if (keep && pid == 0x100) {
+                    has_pts = pts != -1;
+                    if (pay < kTsPacket) {
+                        n = kTsPacket - pay;
+                        from = tid * kTsPacket + pay;
+                    }
+                }
+            }
+        }
+        // ---- 3. prefix sums over the chunk (packets live in waves 0 and 1) -------------------
+        const int wave = tid >> 6, lane = tid & 63;
+        uint32_t incl_n = 0, incl_f = 0;
+        if (wave < 2) {
+            incl_n = wave_incl_scan(n);
+            incl_f = wave_incl_scan(has_pts);
+            if (lane == 63) {
+                sh_wave[0][wave] = incl_n;
+                sh_wave[1][wave] = incl_f;
+            }
+        }
+        __syncthreads();
+        const uint32_t total = sh_wave[0][0] + sh_wave[0][1];
+        const uint32_t total_pes = sh_wave[1][0] + sh_wave[1][1];
+        if (wave < 2) {
+            const uint32_t excl_n = incl_n - n + (wave ? sh_wave[0][0] : 0);
+            const uint32_t excl_f = incl_f - has_pts + (wave ? sh_wave[1][0] : 0);
+            sh_prefix[tid] = (uint32_t)tid < npk ? excl_n : total;
+            sh_src[tid] = from;
+            if (has_pts) {
+                PesEntry e;
+                e.es_off = es_pos + excl_n;
+                e.reserved = 0;
+                e.pts = pts;
+                my_pes[n_pes + excl_f] = e;
+            }
+            if (tid == 0)
+                sh_prefix[kChunk] = total;
+        }
+        __syncthreads();
+        // ---- 4. gather: one destination dword per thread -------------------------------------
+        const uint32_t lo = es_pos, hi = es_pos + total;
+        for (uint32_t d = (lo >> 2) + tid; d * 4 < hi; d += kThreads) {
+            const uint32_t o0 = d * 4;
+            uint32_t first_o = max(o0, lo), last_o = min(o0 + 4, hi);  // bytes [first_o, last_o) of this dword
+            // packet holding byte first_o: the last j with prefix[j] <= rel (zero-length packets share a prefix)
+            uint32_t rel = first_o - lo;
+            int a = 0, b = kChunk;  // invariant: prefix[a] <= rel < prefix[b]
+#pragma unroll
+            for (int it = 0; it < 7; it++) {
+                int m = (a + b) >> 1;
+                if (sh_prefix[m] <= rel)
+                    a = m;
+                else
+                    b = m;
+            }
+            uint32_t word = 0;
+            uint32_t next = sh_prefix[a + 1];
+            for (uint32_t o = first_o; o < last_o; o++, rel++) {
+                while (rel >= next) {
+                    a++;
+                    next = sh_prefix[a + 1];
+                }
+                const int32_t sp = sh_src[a];
+                const uint32_t byte = sp < 0 ? 0u : pk[sp + (rel - sh_prefix[a])];
+                word |= byte << ((o & 3) * 8);
+            }
+            if (last_o - first_o == 4)
+                *reinterpret_cast<uint32_t*>(dst + o0) = word;
+            else
+                for (uint32_t o = first_o; o < last_o; o++)
+                    dst[o] = (uint8_t)(word >> ((o & 3) * 8));
+        }
+        es_pos = hi;
+        n_pes += total_pes;
+        __syncthreads();
+    }
+
+    // ---- end of data: tail + zero fill up to the region end (16-byte aligned) ---------------------
+    const uint32_t tail_lo = es_pos;
+    for (uint32_t d = (tail_lo >> 2) + tid; d * 4 < region; d += kThreads) {
+        const uint32_t o0 = d * 4;
+        uint32_t word = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t o = o0 + k;
+            if (o >= tail_lo && o < tail_lo + kEsTailBytes) {
+                const uint32_t t = o - tail_lo;  // 00 | 00 00 01 B7 | 00 00 01 B7
+                const uint32_t byte = (t == 3 || t == 7) ? 0x01u : ((t == 4 || t == 8) ? 0xB7u : 0u);
+                word |= byte << (k * 8);
+            }
+        }
+        if (o0 >= tail_lo)
+            *reinterpret_cast<uint32_t*>(dst + o0) = word;
+        else
+            for (uint32_t o = tail_lo; o < o0 + 4; o++)
+                dst[o] = (uint8_t)(word >> ((o & 3) * 8));
+    }
+    if (tid == 0) {
+        es_len[s] = es_pos;
+        pes_count[s] = n_pes;
+    }
+}
+
+}  // namespace efx

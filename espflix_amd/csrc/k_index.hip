@@ -46,7 +46,9 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
                                               int max_pictures, PicInfo* __restrict__ pics,
                                               SliceTmp* __restrict__ slices_tmp, uint32_t* __restrict__ pic_count,
                                               uint32_t* __restrict__ status, uint32_t* __restrict__ qtab,
-                                              const uint32_t* __restrict__ scan_tab)
+                                              const uint32_t* __restrict__ scan_tab, const PesEntry* __restrict__ pes,
+                                              const uint32_t* __restrict__ pkt_base,
+                                              const uint32_t* __restrict__ pes_count, int64_t* __restrict__ pts_out)
 {
     __shared__ uint32_t u_off[kMaxUnitsPerStream];
     __shared__ uint32_t u_info[kMaxUnitsPerStream];
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
                 pi.custom_q = seq_flags ? 1 : 0;
                 pi.reserved = (uint16_t)seq_flags;
                 pi.seq_off = seq_off;
+                pi.start_off = u_off[i];
                 mypics[pic] = pi;
             } else if (code >= 0x01 && code <= 0xAF) {
                 // slice(): rows beyond the picture are rejected (player.cpp:1255-1258)
@@ -208,6 +211,28 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
     // The reference stores a loaded matrix in arrival order and later indexes it with the RASTER
     // position zz (player.cpp:646-651,1113); so entry zz of the table is the zz-th byte sent.
     uint32_t npics = sh_misc[0];
+
+    // ---- 3b. PTS latched at each picture header (flush_picture, player.cpp:692-702) -----------
+    // The reference latches _pts when picture() runs; by then its bit reader has pulled in the two
+    // bytes after the picture_start_code (FILL_BITS look-ahead, player.cpp:348-352), so the PTS in
+    // force is that of the newest PES whose payload starts at or before start_off + 1.
+    if (pts_out) {
+        const PesEntry* mp = pes + pkt_base[s];
+        const uint32_t np = pes_count[s];
+        for (uint32_t p = lane; p < npics; p += 64) {
+            const uint32_t limit = mypics[p].start_off + 1;
+            uint32_t a = 0, b = np;  // first entry with es_off > limit
+            while (a < b) {
+                uint32_t m = (a + b) >> 1;
+                if (mp[m].es_off <= limit)
+                    a = m + 1;
+                else
+                    b = m;
+            }
+            pts_out[(size_t)s * max_pictures + p] = a ? mp[a - 1].pts : -1;
+        }
+    }
+
     for (uint32_t p = 0; p < npics; p++) {
         PicInfo pi = mypics[p];
         if (!pi.custom_q)

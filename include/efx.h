@@ -76,10 +76,17 @@ const char* efx_status_string(int status);
 /* -- bitstream in ------------------------------------------------------------------------ */
 /* Stands in for the Buffer hand-off MpegDecoder::push_full / pop_empty (src/player.cpp:371-379,
  * src/streamer.h:139-143) for a whole batch: copies n_streams byte ranges (host pointers, the
- * caller keeps ownership) into HBM.  TS input is demultiplexed on the host first.  Like
- * MpegDecoder::more() at end of data (src/player.cpp:456,469-473) each stream is terminated
- * with 00 | 00 00 01 B7 | 00 00 01 B7.  Does NOT reset the frame rings. */
+ * caller keeps ownership) into HBM.  EFX_FORMAT_TS input (188-byte packets, video on PID 0x100)
+ * is demultiplexed ON THE DEVICE: MpegDecoder::more/demux/parse_pts (src/player.cpp:294-307,
+ * 381-436,459-493) for the whole batch -- adaptation fields and PES headers skipped at the
+ * reference's fixed offsets, one zero byte per packet that lost sync, PES PTS values kept for
+ * efx_picture_pts.  Like MpegDecoder::more() at end of data (src/player.cpp:456,469-473) each
+ * stream is terminated with 00 | 00 00 01 B7 | 00 00 01 B7.  Does NOT reset the frame rings. */
 int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, const size_t* len, int format);
+/* The elementary stream the decoder sees for `stream` (what MpegDecoder::more() feeds the bit
+ * reader, src/player.cpp:459-493), without the end-of-data tail: *es_len receives its length,
+ * up to `cap` bytes are copied to dst (dst may be NULL when cap is 0). */
+int efx_download_es(efx_ctx* ctx, int stream, uint8_t* dst, size_t cap, size_t* es_len);
 
 /* MpegDecoder::reset + Frame::init (src/player.cpp:439-453): zero the frame rings and restart
  * picture numbering. */
@@ -100,8 +107,8 @@ int efx_sync(efx_ctx* ctx);
 int efx_picture_count(efx_ctx* ctx, int stream, int* n_pictures);
 /* OR of EFX_STREAM_* bits for a stream (valid after efx_sync) */
 int efx_stream_status(efx_ctx* ctx, int stream, uint32_t* bits);
-/* PES PTS latched for picture `picture` (flush_picture, src/player.cpp:692-702); ES input
- * yields the picture index. */
+/* PES PTS latched for picture `picture` (flush_picture, src/player.cpp:692-702; -1 when no PES
+ * with a PTS preceded it); valid after efx_decode for TS input; ES input yields the picture index. */
 int efx_picture_pts(efx_ctx* ctx, int stream, int picture, int64_t* pts);
 
 /* -- frames out (the push_video up-call surface, src/video.h:49) ------------------------- */
@@ -142,6 +149,9 @@ int efx_pdm(efx_ctx* ctx, int n_streams, const int16_t* pcm_device, int n_sample
 typedef struct efx_timing {
     float index_ms, parse_ms, recon_ms, total_ms; /* HIP-event times of the last efx_decode */
     uint64_t pictures, slices, coefficients, es_bytes;
+    float demux_ms;    /* k_demux of the last EFX_FORMAT_TS upload (0 for ES input or timing off at upload) */
+    float reserved;
+    uint64_t ts_bytes; /* transport-stream bytes of the last upload */
 } efx_timing;
 /* Enable HIP-event timing of the decode stages (off by default: events serialise the stages). */
 int efx_set_timing(efx_ctx* ctx, int enable);

@@ -342,24 +342,31 @@ static int src_byte(dec_t* d)
         const uint8_t* pend = p + 188;
         int64_t pts = -1;
         if (p[1] & 0x40) { /* payload_unit_start: fixed-offset PES header (player.cpp:387-406) */
+            /* The reference reads the nine header bytes wherever they fall; when they do not fit
+             * in the packet that is a read outside it, whose result depends on how the transport
+             * was buffered, not on the stream.  Defined here: such a packet is dropped. */
+            if (pay + 9 > pend)
+                continue;
             const uint8_t* q = pay + 6;
             int flags = (q[0] << 8) | q[1];
             pay = q + 3 + q[2];
             q += 3;
-            if (flags & 0x0080)
+            if ((flags & 0x0080) && q + 5 <= pend)
                 pts = parse_pts(q, flags);
         }
         if (pid != 0x100)
             continue; /* audio 0x101/0x102 goes to push_audio, everything else is dropped */
         if (pts != -1)
             d->pts = pts;
-        d->cur = pay;
+        /* player.cpp:419 returns *_data++ without checking for an empty payload: with nothing
+         * left in the packet it would hand the bit reader the byte AFTER the packet (the next
+         * packet's sync byte, or whatever follows the 8-packet Buffer).  Defined here: a packet
+         * without payload bytes contributes nothing. */
+        if (pay >= pend)
+            continue;
+        d->cur = pay + 1;
         d->end = pend;
-        /* player.cpp:419 returns *_data++ without checking for an empty payload */
-        const uint8_t* lim = d->data + d->len;
-        int b = (d->cur < lim) ? *d->cur : 0;
-        d->cur++;
-        return b;
+        return *pay;
     }
 }
 

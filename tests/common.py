@@ -37,3 +37,93 @@ def pdm_pcm(k: int = 0, calls: int = 40) -> np.ndarray:
 def fnv_bytes(a: np.ndarray) -> int:
     import oracle
     return oracle.fnv1a64(np.ascontiguousarray(a).view(np.uint8).reshape(-1))
+
+
+# ---- transport-stream packetiser (test input only) -------------------------------------------
+def _pts_field(prefix: int, pts: int) -> bytes:
+    a = (prefix << 4) | (((pts >> 30) & 7) << 1) | 1
+    b = (((pts >> 15) & 0x7FFF) << 1) | 1
+    c = ((pts & 0x7FFF) << 1) | 1
+    return bytes([a, b >> 8, b & 0xFF, c >> 8, c & 0xFF])
+
+
+def ts_packet(pid: int, payload: bytes, pusi: bool = False, cc: int = 0, afc_only: bool = False) -> bytes:
+    """One 188-byte packet; short payloads are padded with an adaptation field of stuffing."""
+    assert len(payload) <= 184
+    hdr = bytes([0x47, (0x40 if pusi else 0) | (pid >> 8), pid & 0xFF])
+    if afc_only:  # adaptation field only, no payload flag
+        return hdr + bytes([0x20 | (cc & 15), 183, 0x00]) + b"\xFF" * 182
+    if len(payload) == 184:
+        return hdr + bytes([0x10 | (cc & 15)]) + payload
+    L = 183 - len(payload)
+    af = bytes([L]) + (bytes([0x00]) + b"\xFF" * (L - 1) if L else b"")
+    return hdr + bytes([0x30 | (cc & 15)]) + af + payload
+
+
+def pes_header(pts: int | None, dts: bool = False, stuffing: int = 0) -> bytes:
+    """Video PES header as MpegDecoder::demux reads it (player.cpp:381-405): 00 00 01 E0, length
+    0, flags, header_data_length, [PTS], [DTS], stuffing."""
+    opt = b""
+    flags2 = 0
+    if pts is not None:
+        flags2 = 0xC0 if dts else 0x80
+        opt += _pts_field(3 if dts else 2, pts)
+        if dts:
+            opt += _pts_field(1, max(pts - 3003, 0))
+    opt += b"\xFF" * stuffing
+    return bytes([0, 0, 1, 0xE0, 0, 0, 0x80, flags2, len(opt)]) + opt
+
+
+def packetize(es: bytes, pes_starts, rng, noise: bool = True, min_payload: int = 1) -> bytes:
+    """Wrap an elementary stream into a transport stream the way a hostile-but-legal muxer might:
+    pes_starts = [(es_offset, pts or None, dts, stuffing)], sorted; payload sizes are random;
+    null / audio-PID / adaptation-only packets are interleaved when `noise`."""
+    out = bytearray()
+    cc = 0
+    bounds = [p[0] for p in pes_starts] + [len(es)]
+    assert bounds[0] == 0
+    for k, (off, pts, dts, stuffing) in enumerate(pes_starts):
+        chunk = es[off:bounds[k + 1]]
+        first = True
+        pos = 0
+        while first or pos < len(chunk):
+            head = pes_header(pts, dts, stuffing) if first else b""
+            room = 184 - len(head)
+            n = min(len(chunk) - pos, int(rng.integers(min_payload, room + 1)) if rng.integers(0, 3) else room)
+            out += ts_packet(0x100, head + chunk[pos:pos + n], pusi=first, cc=cc)
+            cc += 1
+            pos += n
+            first = False
+            if noise:
+                r = int(rng.integers(0, 12))
+                if r == 0:
+                    out += ts_packet(0x1FFF, bytes(184))
+                elif r == 1:  # an audio PES the video path must ignore
+                    out += ts_packet(0x102, pes_header(int(rng.integers(0, 1 << 33))) + bytes(rng.integers(0, 256, 40, dtype=np.uint8)), pusi=True)
+                elif r == 2:
+                    out += ts_packet(0x100, b"", afc_only=True, cc=cc)
+                elif r == 3:
+                    out += ts_packet(0x101, bytes(rng.integers(0, 256, 184, dtype=np.uint8)))
+    return bytes(out)
+
+
+def picture_offsets(es: bytes):
+    """Offsets of every picture_start_code (00 00 01 00) in an elementary stream."""
+    a = np.frombuffer(es, dtype=np.uint8)
+    m = (a[:-3] == 0) & (a[1:-2] == 0) & (a[2:-1] == 1) & (a[3:] == 0)
+    return [int(i) for i in np.nonzero(m)[0]]
+
+
+def hostile_ts(es: bytes, seed: int, noise: bool = True) -> bytes:
+    """PES boundaries placed a few bytes either side of the picture start codes (the PTS latch
+    depends on the bit reader's look-ahead), PTS present / absent / with DTS, header stuffing."""
+    rng = np.random.default_rng(seed)
+    starts = [(0, 129003, False, 0)]
+    for i, p in enumerate(picture_offsets(es)):
+        off = p + int(rng.integers(-3, 9))
+        if off <= starts[-1][0] or off >= len(es):
+            continue
+        kind = int(rng.integers(0, 6))
+        pts = None if kind == 0 else 200000 + 3003 * i + int(rng.integers(0, 100))
+        starts.append((off, pts, kind == 1, int(rng.integers(0, 4)) if kind == 2 else 0))
+    return packetize(es, starts, rng, noise=noise)

@@ -137,7 +137,7 @@ def ref_decode(ts: np.ndarray | str, flush_last: bool = True, want_frames: bool 
             np.ascontiguousarray(ts, dtype=np.uint8).tofile(src)
         out = os.path.join(td, "out.bin") if want_frames else "-"
         cmd = [os.path.join(REF_DIR, "efx_ref_decode"), "decode", src, out] + (["flush"] if flush_last else [])
-        p = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True, timeout=600)
+        p = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True, timeout=120)
         rows = [l.split() for l in p.stderr.splitlines() if l.startswith("F ")]
         hashes = np.array([int(r[3], 16) for r in rows], dtype=np.uint64)
         pts = np.array([int(r[2]) for r in rows], dtype=np.int64)

@@ -1,0 +1,133 @@
+"""transport-stream demultiplexing on the device (k_demux) against the
+oracle's restatement of MpegDecoder::more/demux/parse_pts (player.cpp:294-307,381-493) and the
+reference-derived goldens."""
+import numpy as np
+import pytest
+
+import common
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def efx():
+    import espflix_amd
+    espflix_amd.load_library()
+    return espflix_amd
+
+
+def upload(efx, blobs, fmt, max_pictures=100, **kw):
+    dec = efx.Decoder(max_streams=len(blobs), max_pictures=max_pictures, **kw)
+    dec.upload(blobs, fmt)
+    return dec
+
+
+def check_es(dec, blobs):
+    for i, ts in enumerate(blobs):
+        want = oracle.ts_to_es(np.frombuffer(ts, dtype=np.uint8)).tobytes()
+        got = dec.es(i)
+        assert len(got) == len(want), (i, len(got), len(want))
+        assert got == want, i
+
+
+@pytest.mark.parametrize("clip", ["splash", "vmedia"])
+def test_clip_es_bytes(efx, clips, clip):
+    ts = clips[clip]
+    dec = upload(efx, [ts], efx.FORMAT_TS)
+    check_es(dec, [ts])
+
+
+def test_synthetic_batch_es_equals_generator_es(efx):
+    from espflix_amd import gen
+    b = gen.Batch(0, 64, 12)
+    blobs = [b.ts(k) for k in range(64)]
+    dec = upload(efx, blobs, efx.FORMAT_TS, max_pictures=12)
+    for k in range(64):
+        assert dec.es(k) == b.es(k).tobytes(), k
+
+
+def test_hostile_muxing_es_pts_and_frames(efx, clips):
+    """Random payload sizes (1..184 bytes), PES boundaries around the picture start codes, PTS
+    absent / PTS+DTS / header stuffing, interleaved null, audio and adaptation-only packets:
+    ES bytes, per-picture PTS and decoded frames equal the oracle's."""
+    from espflix_amd import gen
+    b = gen.Batch(40, 6, 6)
+    clip_es = oracle.ts_to_es(clips["vmedia"]).tobytes()
+    es_list = [b.es(k).tobytes() for k in range(6)] + [clip_es[:common.picture_offsets(clip_es)[10]]]  # whole pictures
+    blobs = [common.hostile_ts(es, 1000 + i) for i, es in enumerate(es_list)]
+    dec = upload(efx, blobs, efx.FORMAT_TS, max_pictures=40)
+    check_es(dec, blobs)
+    dec.decode()
+    for i, ts in enumerate(blobs):
+        n, hashes, pts, _ = oracle.decode(np.frombuffer(ts, dtype=np.uint8), efx.FORMAT_TS, flush_last=True)
+        assert dec.picture_count(i) == n
+        assert [dec.picture_pts(i, p) for p in range(n)] == [int(x) for x in pts], i
+
+
+def test_malformed_packets(efx):
+    """Packets the reference would mis-handle are defined here exactly as in the oracle: lost sync
+    -> one zero byte; no-payload flag, adaptation field swallowing the packet, PES header that
+    does not fit -> nothing; a trailing partial packet is ignored."""
+    rng = np.random.default_rng(7)
+    es = bytes(rng.integers(0, 256, 5000, dtype=np.uint8))
+    good = common.packetize(es, [(0, 90000, False, 0), (2500, None, False, 2)], rng, noise=True)
+    pk = [bytearray(good[i:i + 188]) for i in range(0, len(good), 188)]
+    pk[3][0] = 0x48                                    # lost sync
+    pk[5][3] = (pk[5][3] & 0xCF) | 0x20                # adaptation only: payload flag cleared
+    pk.insert(7, bytearray(common.ts_packet(0x100, bytes(10), pusi=False)))
+    pk[7][4] = 200                                     # adaptation_field_length beyond the packet
+    short = bytearray(common.ts_packet(0x100, bytes(range(6)), pusi=True))  # 6 bytes cannot hold a PES header
+    pk.insert(9, short)
+    bad_prefix = bytearray(common.ts_packet(0x100, common.pes_header(12345) + bytes(20), pusi=True))
+    bad_prefix[188 - 20 - 5] ^= 0x10                   # PTS marker nibble no longer matches the flags
+    pk.insert(11, bad_prefix)
+    blob = b"".join(bytes(p) for p in pk) + good[:100]  # + trailing partial packet
+    tiny = [b"", good[:188], good[:187], bytes(188), bytes([0x47]) + bytes(187)]
+    blobs = [blob] + tiny
+    dec = upload(efx, blobs, efx.FORMAT_TS)
+    check_es(dec, blobs)
+    dec.decode()  # garbage ES: must terminate and report, not crash
+    for i in range(len(blobs)):
+        dec.stream_status(i)
+
+
+def test_chunk_boundaries_and_tiny_payloads(efx):
+    """> 128 packets per stream (k_demux works in chunks of 128) with 1..4-byte payloads: every
+    ragged dword edge and zero-length packet case of the gather."""
+    rng = np.random.default_rng(11)
+    blobs = []
+    for n_es in (300, 1000, 4097, 20000):
+        es = bytes(rng.integers(0, 256, n_es, dtype=np.uint8))
+        out = bytearray()
+        pos = 0
+        first = True
+        while pos < len(es):
+            n = int(rng.integers(0, 5)) if n_es < 5000 else int(rng.integers(0, 185))
+            head = common.pes_header(int(rng.integers(0, 1 << 33))) if first else b""
+            n = min(n, 184 - len(head), len(es) - pos)
+            out += common.ts_packet(0x100, head + es[pos:pos + n], pusi=first)
+            pos += n
+            first = False
+        blobs.append(bytes(out))
+    dec = upload(efx, blobs, efx.FORMAT_TS)
+    check_es(dec, blobs)
+
+
+def test_es_download_for_es_input(efx):
+    from espflix_amd import gen
+    b = gen.Batch(3, 2, 2)
+    dec = upload(efx, [b.es(0), b.es(1)], efx.FORMAT_ES, max_pictures=2)
+    assert dec.es(0) == b.es(0).tobytes() and dec.es(1) == b.es(1).tobytes()
+
+
+def test_demux_timing_reported(efx):
+    from espflix_amd import gen
+    b = gen.Batch(0, 32, 12)
+    blobs = [b.ts(k) for k in range(32)]
+    dec = efx.Decoder(max_streams=32, max_pictures=12)
+    dec.set_timing(True)
+    dec.upload(blobs, efx.FORMAT_TS)
+    dec.decode()
+    t = dec.timing()
+    assert t.ts_bytes == sum(len(x) for x in blobs) and t.demux_ms > 0

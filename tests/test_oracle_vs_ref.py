@@ -56,3 +56,19 @@ def test_pdm_random(k):
             beep.value = 5
         words.append(oracle.write_pcm_16(st, beep, None if (c % 5) == 4 else pcm[c * 128:(c + 1) * 128]))
     assert np.array_equal(np.concatenate(words), ref)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_hostile_muxing_pts_latch(seed, clips):
+    """PES boundaries a few bytes either side of the picture start codes, PTS absent / with DTS /
+    header stuffing, random payload sizes, interleaved null / audio / adaptation-only packets: the
+    restatement's demux and its PTS latch (look-ahead of the bit reader) follow the reference."""
+    b = gen.Batch(200 + seed, 2, 8)
+    clip_es = oracle.ts_to_es(clips["vmedia"]).tobytes()
+    es_list = [b.es(0).tobytes(), b.es(1).tobytes(), clip_es[:common.picture_offsets(clip_es)[10]]]  # whole pictures
+    for i, es in enumerate(es_list):
+        ts = np.frombuffer(common.hostile_ts(es, 10 * seed + i), dtype=np.uint8)
+        rh, rpts, _ = oracle.ref_decode(ts)
+        n, h, pts, _ = oracle.decode(ts, 1)
+        assert n == len(rh) and (h == rh).all(), (seed, i)
+        assert (pts == rpts).all(), (seed, i, pts.tolist(), rpts.tolist())

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the video-out / audio-out kernels (BASELINE configs[3]): composite NTSC / PAL
-fields and PDM blocks for a batch of streams, with the HBM roofline fraction from the
+fields and PDM blocks and the transport-stream demultiplexer for a batch of streams, with the HBM roofline fraction from the
 algorithmic bytes of SURVEY.md section 8d (field: 101 376 B read + 477 888 B written NTSC,
 708 864 B PAL; PDM: 2 B read + 4 B written per sample).  Prints one JSON line per kernel."""
 import json, os, sys, time
@@ -53,4 +53,23 @@ print(json.dumps({"kernel": "k_pdm", "streams": S, "samples_per_stream": n, "str
                   "ms_per_launch": dt * 1e3,
                   "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / dt / 8e12,
                                "note": "serial 32x recurrence per sample: ALU bound, one lane per stream"}}))
+dec.close()
+
+# TS demux on the device: S streams x GOP(12), TS bytes read + ES bytes written
+b = gen.Batch(0, S, 12, 12, 0)
+ts = [b.ts(k) for k in range(S)]
+dec = efx.Decoder(S, 12, 2, max_stream_bytes=sum(len(x) for x in ts) + 4096)
+dec.set_timing(True)
+best = 1e9
+for _ in range(5):
+    dec.upload(ts, efx.FORMAT_TS)
+    dec.decode()
+    t = dec.timing()
+    best = min(best, t.demux_ms)
+es_bytes = sum(b.es(k).size for k in range(S))
+alg = t.ts_bytes + es_bytes
+print(json.dumps({"kernel": "k_demux", "streams": S, "ts_bytes": t.ts_bytes, "es_bytes": es_bytes,
+                  "ms_per_launch": best, "ts_GB_per_s": t.ts_bytes / best / 1e6,
+                  "roofline": {"bound": "hbm", "achieved": alg / best / 1e6, "peak": 8000.0, "unit": "GB/s",
+                               "frac": alg / best / 1e6 / 8000.0, "algorithmic_bytes_per_launch": alg}}))
 dec.close()
