@@ -59,6 +59,12 @@ class _VideoParams(C.Structure):
                                        "burst_start", "burst_width", "active_start")]
 
 
+class _FieldOpts(C.Structure):
+    _fields_ = [("first_stream", C.c_int), ("n_streams", C.c_int), ("slot", C.c_int), ("other_slot", C.c_int),
+                ("ntsc", C.c_int), ("frame_counter", C.c_int), ("hscroll", C.c_int), ("overlay", C.c_void_p),
+                ("overlay_stride", C.c_size_t), ("overlay_blend", C.c_int), ("overlay_progress", C.c_int)]
+
+
 class _Timing(C.Structure):
     _fields_ = [("index_ms", C.c_float), ("parse_ms", C.c_float), ("recon_ms", C.c_float), ("total_ms", C.c_float),
                 ("pictures", C.c_uint64), ("slices", C.c_uint64), ("coefficients", C.c_uint64), ("es_bytes", C.c_uint64),
@@ -88,6 +94,7 @@ _SYMBOLS = {
     "efx_upload_frame": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "efx_video_get_params": (C.c_int, [C.c_int, C.POINTER(_VideoParams)]),
     "efx_composite_fields": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "efx_composite_fields_ex": (C.c_int, [_P, C.POINTER(_FieldOpts), _P]),
     "efx_pdm": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
     "efx_set_timing": (C.c_int, [_P, C.c_int]),
     "efx_get_timing": (C.c_int, [_P, C.POINTER(_Timing)]),
@@ -290,6 +297,16 @@ class Decoder:
         ptr = dst.ptr if isinstance(dst, DeviceBuffer) else dst
         _check(self._ctx, self._lib.efx_composite_fields(self._ctx, first_stream, n_streams, slot, 1 if ntsc else 0,
                                                          frame_counter, ptr))
+
+    def composite_fields_ex(self, dst: DeviceBuffer | int, first_stream: int, n_streams: int, slot: int, ntsc: bool,
+                            frame_counter: int, other_slot: int | None = None, hscroll: int = 0,
+                            overlay: DeviceBuffer | int | None = None, overlay_stride: int = 0, overlay_blend: int = 0,
+                            overlay_progress: int = 0):
+        """video_isr with the two-frame slide (_hscroll) and the overlay / progress bar (composite())."""
+        g = lambda b: None if b is None else (b.ptr if isinstance(b, DeviceBuffer) else b)
+        o = _FieldOpts(first_stream, n_streams, slot, slot if other_slot is None else other_slot, 1 if ntsc else 0,
+                       frame_counter, hscroll, g(overlay), overlay_stride, overlay_blend, overlay_progress)
+        _check(self._ctx, self._lib.efx_composite_fields_ex(self._ctx, C.byref(o), g(dst)))
 
     def pdm(self, n_streams: int, pcm: DeviceBuffer | int, n_samples: int, state: DeviceBuffer | int,
             dst: DeviceBuffer | int):

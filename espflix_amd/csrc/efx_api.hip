@@ -27,7 +27,7 @@ __global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const
 __global__ void k_recon(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, int, int, int);
 __global__ void k_frame_hash(const uint8_t*, int, uint64_t*);
 __global__ void k_fill(uint32_t*, uint32_t, size_t);
-__global__ void k_composite(const uint8_t*, int, int, int, const VideoTables*, int, uint16_t*);
+__global__ void k_composite(const uint8_t*, const VideoTables*, FieldArgs, uint16_t*);
 __global__ void k_pdm(const int16_t*, int, int, int32_t*, uint16_t*);
 #ifdef EFX_PARSE_PROFILE
 __global__ void k_parse_set_prof(uint32_t*);
@@ -604,18 +604,52 @@ int efx_video_get_params(int ntsc, efx_video_params* out)
     return EFX_OK;
 }
 
+int efx_composite_fields_ex(efx_ctx* ctx, const efx_field_opts* o, uint16_t* dst_device)
+{
+    if (!ctx || !o || !dst_device || o->first_stream < 0 || o->n_streams <= 0 ||
+        o->first_stream + o->n_streams > ctx->cfg.max_streams || o->slot < 0 || o->slot >= ctx->cfg.ring_depth)
+        return EFX_ERR_ARG;
+    if (o->hscroll && (o->other_slot < 0 || o->other_slot >= ctx->cfg.ring_depth || (o->hscroll & 7) ||
+                       o->hscroll <= -EFX_FRAME_WIDTH || o->hscroll >= EFX_FRAME_WIDTH))
+        return fail(ctx, EFX_ERR_ARG, "efx_composite_fields_ex: hscroll must be a multiple of 8 in (-352, 352)");
+    if (o->overlay_blend < -1)
+        return fail(ctx, EFX_ERR_ARG, "efx_composite_fields_ex: overlay_blend must be -1 or >= 0");
+    FieldArgs a{};
+    a.first_stream = o->first_stream;
+    a.ring_depth = ctx->cfg.ring_depth;
+    a.slot = o->slot;
+    a.other_slot = o->hscroll ? o->other_slot : o->slot;
+    a.frame_counter = o->frame_counter;
+    a.hscroll = o->hscroll;
+    a.overlay = o->overlay;
+    a.overlay_stride = o->overlay_stride;
+    // composite(), video.cpp:857-859
+    int scale = 0;
+    if (o->overlay_blend) {
+        scale = 255 / 4;
+        if (o->overlay_blend != -1 && o->overlay_blend < 32)
+            scale = (scale * o->overlay_blend) >> 5;
+    }
+    a.overlay_scale = scale;
+    a.overlay_progress = o->overlay_progress;
+    const int lines = o->ntsc ? 262 : 312;
+    const int blocks = o->n_streams * ((lines + 7) / 8);
+    hipLaunchKernelGGL(k_composite, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_frames, ctx->d_video[o->ntsc ? 1 : 0], a,
+                       dst_device);
+    EFX_HIP(hipGetLastError());
+    return EFX_OK;
+}
+
 int efx_composite_fields(efx_ctx* ctx, int first_stream, int n_streams, int slot, int ntsc, int frame_counter,
                          uint16_t* dst_device)
 {
-    if (!ctx || !dst_device || first_stream < 0 || n_streams <= 0 || first_stream + n_streams > ctx->cfg.max_streams ||
-        slot < 0 || slot >= ctx->cfg.ring_depth)
-        return EFX_ERR_ARG;
-    const int lines = ntsc ? 262 : 312;
-    const int blocks = n_streams * ((lines + 7) / 8);
-    hipLaunchKernelGGL(k_composite, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_frames, first_stream, ctx->cfg.ring_depth,
-                       slot, ctx->d_video[ntsc ? 1 : 0], frame_counter, dst_device);
-    EFX_HIP(hipGetLastError());
-    return EFX_OK;
+    efx_field_opts o{};
+    o.first_stream = first_stream;
+    o.n_streams = n_streams;
+    o.slot = o.other_slot = slot;
+    o.ntsc = ntsc;
+    o.frame_counter = frame_counter;
+    return efx_composite_fields_ex(ctx, &o, dst_device);
 }
 
 int efx_pdm(efx_ctx* ctx, int n_streams, const int16_t* pcm_device, int n_samples, int32_t* state_device, uint16_t* dst_device)

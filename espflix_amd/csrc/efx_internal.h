@@ -98,6 +98,18 @@ struct VideoTables {
     uint32_t color_tab[768];
 };
 
+// k_composite launch arguments (by value)
+struct FieldArgs {
+    int first_stream, ring_depth;
+    int slot, other_slot;   // ring slots of the displayed frame and of the frame scrolled in
+    int frame_counter;      // dither phase
+    int hscroll;            // multiple of 8 in (-352, 352)
+    const uint8_t* overlay; // device, 16 x 80 bytes per stream (or shared: stride 0); may be null
+    size_t overlay_stride;
+    int overlay_scale;      // 0 = overlay off; 63 full, (63 * blend) >> 5 while fading
+    int overlay_progress;
+};
+
 void build_parse_tables(ParseTables* t);
 void build_video_tables(int ntsc, VideoTables* t);
 

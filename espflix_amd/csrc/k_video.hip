@@ -9,6 +9,11 @@
 // of one stream; the 3 KiB chroma-phase LUT lives in LDS; every thread produces one 16-byte
 // (8-sample) store, so line writes are fully coalesced.
 //
+// Two-frame horizontal scroll (_hscroll, video.cpp:1146-1154: the front frame from column h, then
+// the other frame from column 0, each blit restarting its running luma average) and the 80 x 16
+// time / progress-bar overlay (composite(), video.cpp:845-887, drawn on the black lines 2..17
+// below the picture) are evaluated in the same pass.
+//
 // k_pdm restates pdm_second_order() (espflix.ino:73-107): the recurrence is serial per stream,
 // so one lane owns one stream and walks its samples.
 #include <hip/hip_runtime.h>
@@ -67,10 +72,10 @@ __device__ inline uint32_t line_sample(const VideoTables& v, int kind, int i, in
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void k_composite(const uint8_t* __restrict__ frames, int first_stream, int ring_depth,
-                                                   int slot, const VideoTables* __restrict__ vt, int frame_counter,
-                                                   uint16_t* __restrict__ out)
+__global__ __launch_bounds__(256) void k_composite(const uint8_t* __restrict__ frames, const VideoTables* __restrict__ vt,
+                                                   FieldArgs a, uint16_t* __restrict__ out)
 {
+    const int first_stream = a.first_stream, ring_depth = a.ring_depth, frame_counter = a.frame_counter;
     __shared__ VideoTables v;
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(vt);
@@ -83,7 +88,17 @@ __global__ __launch_bounds__(256) void k_composite(const uint8_t* __restrict__ f
     const int blocks_per_field = (v.line_count + kLinesPerBlock - 1) / kLinesPerBlock;
     const int s = blockIdx.x / blocks_per_field;
     const int line0 = (blockIdx.x - s * blocks_per_field) * kLinesPerBlock;
-    const uint8_t* frame = frames + ((size_t)(first_stream + s) * ring_depth + slot) * kFrameBytes;
+    const uint8_t* stream_frames = frames + (size_t)(first_stream + s) * ring_depth * kFrameBytes;
+    // video_isr, video.cpp:1146-1154: a negative scroll shows the OTHER frame first
+    int hscroll = a.hscroll, lead_slot = a.slot, trail_slot = a.other_slot;
+    if (hscroll < 0) {
+        hscroll += EFX_FRAME_WIDTH;
+        lead_slot = a.other_slot;
+        trail_slot = a.slot;
+    }
+    const int lead_groups = (EFX_FRAME_WIDTH - hscroll) / 4;  // 4-pixel groups taken from the leading frame
+    const uint8_t* overlay = a.overlay ? a.overlay + (size_t)s * a.overlay_stride : nullptr;
+    const int overlay_top = 32 + (v.pal ? 32 : 0) + 192 + 2;  // ptop, video.cpp:1182
     const int groups = v.line_width / 8;  // 16-byte groups per line
     const int active_top = 32 + (v.pal ? 32 : 0);
     const int vsync_start = v.line_count - (v.pal ? 8 : 3);
@@ -101,10 +116,15 @@ __global__ __launch_bounds__(256) void k_composite(const uint8_t* __restrict__ f
             // blit(), video.cpp:690-804: 4 luma pixels -> 8 samples
             const int line = i - active_top;
             const int odd = line & 1;
+            // source group: the leading frame from column hscroll, then the trailing frame from 0
+            const bool lead = pg < lead_groups;
+            const int sg = lead ? pg + hscroll / 4 : pg - lead_groups;
+            const bool blit_start = lead ? pg == 0 : sg == 0;
+            const uint8_t* frame = stream_frames + (size_t)(lead ? lead_slot : trail_slot) * kFrameBytes;
             const uint8_t* yrow = frame + luma_row_off(line);
-            uint32_t y4 = *reinterpret_cast<const uint32_t*>(yrow + pg * 4);
+            uint32_t y4 = *reinterpret_cast<const uint32_t*>(yrow + sg * 4);
             const int crow = line >> 1;
-            const int coff = (pg >> 1) * 4;
+            const int coff = (sg >> 1) * 4;
             uint32_t u4 = *reinterpret_cast<const uint32_t*>(frame + chroma_row_off(1, crow) + coff);
             uint32_t v4 = *reinterpret_cast<const uint32_t*>(frame + chroma_row_off(2, crow) + coff);
             if (odd) {  // vertical chroma interpolation on odd lines (video.cpp:705-717)
@@ -115,10 +135,10 @@ __global__ __launch_bounds__(256) void k_composite(const uint8_t* __restrict__ f
                 v4 = ((v4 >> 1) & 0x7F7F7F7Fu) + ((v2 >> 1) & 0x7F7F7F7Fu);
             }
             const uint32_t dither = c_dither[(line & 3) + ((frame_counter & 1) << 2)];
-            // running luma average starts from the previous group's last pixel (0 at the line start)
+            // running luma average starts from the previous group's last pixel (0 where a blit starts)
             uint32_t lum = 0;
-            if (pg > 0) {
-                uint32_t yp = *reinterpret_cast<const uint32_t*>(yrow + pg * 4 - 4);
+            if (!blit_start) {
+                uint32_t yp = *reinterpret_cast<const uint32_t*>(yrow + sg * 4 - 4);
                 lum = (((yp + dither) & 0xFCFCFCFCu) >> 2) >> 24;
             }
             uint32_t p0 = (y4 + dither) & 0xFCFCFCFCu;
@@ -126,7 +146,7 @@ __global__ __launch_bounds__(256) void k_composite(const uint8_t* __restrict__ f
             p0 >>= 2;
             p1 >>= 2;
             const uint32_t* tab_v = v.color_tab + (odd ? 512 : 256);
-            const int sh = (pg & 1) * 16;
+            const int sh = (sg & 1) * 16;
             uint32_t c = ((v.color_tab[(u4 >> sh) & 0xFF] + tab_v[(v4 >> sh) & 0xFF]) & 0xFCFCFCFCu) >> 2;
             lum = (((p0 & 0xFF) + lum) >> 1) & 0xFF;
             o.x = ((lum << 24) | ((p0 & 0xFF) << 8)) + c;
@@ -139,9 +159,32 @@ __global__ __launch_bounds__(256) void k_composite(const uint8_t* __restrict__ f
             uint32_t w[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                uint32_t a = line_sample(v, kind, g * 8 + 2 * k, i + 1) & 0xFFFF;
-                uint32_t b = line_sample(v, kind, g * 8 + 2 * k + 1, i + 1) & 0xFFFF;
-                w[k] = a | (b << 16);
+                uint32_t lo = line_sample(v, kind, g * 8 + 2 * k, i + 1) & 0xFFFF;
+                uint32_t hi = line_sample(v, kind, g * 8 + 2 * k + 1, i + 1) & 0xFFFF;
+                w[k] = lo | (hi << 16);
+            }
+            // composite(), video.cpp:845-887: overlay text = 80 bytes -> 160 samples starting 16
+            // samples into the picture window; on overlay lines 3..8 a 240-step progress bar
+            // follows after another 16 samples.  One overlay byte / bar step = one dword.
+            const int ol = i - overlay_top;
+            if (a.overlay_scale && ol >= 0 && ol < 16 && i < vsync_start) {
+                const int d0 = (g - first_pix_group) * 4 - 8;  // dword index relative to the first text dword
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int d = d0 + k;
+                    uint32_t p = 0;
+                    bool hit = false;
+                    if (d >= 0 && d < 80) {
+                        p = v.black_level + (overlay ? overlay[ol * 80 + d] : 0) * a.overlay_scale;
+                        hit = true;
+                    } else if (ol >= 3 && ol <= 8 && d >= 88 && d < 88 + 240) {
+                        const int step = (d - 88) & ~1;  // two dwords per step of 2
+                        p = v.black_level + (step < a.overlay_progress ? (a.overlay_scale << 8) : (a.overlay_scale << 7));
+                        hit = true;
+                    }
+                    if (hit)
+                        w[k] = (p << 16) | p;
+                }
             }
             o = make_uint4(w[0], w[1], w[2], w[3]);
         }

@@ -138,6 +138,32 @@ int efx_video_get_params(int ntsc, efx_video_params* out);
 int efx_composite_fields(efx_ctx* ctx, int first_stream, int n_streams, int slot, int ntsc, int frame_counter,
                          uint16_t* dst_device);
 
+/* The same with the two display features of video_isr that involve more than the front frame:
+ *  - hscroll: the ease-in / ease-out slide between the two Frames of a pair (_hscroll,
+ *    src/video.cpp:1077-1088,1146-1154): a multiple of 8 in (-352, 352); h > 0 shows `slot` from
+ *    column h followed by `other_slot` from column 0, h < 0 shows `other_slot` from column
+ *    352 + h followed by `slot` from column 0;
+ *  - the 80 x 16 time / progress-bar overlay (composite(), src/video.cpp:838-887; the buffer
+ *    _video_composite, src/video.h:52-55) on the sixteen lines starting two lines below the
+ *    picture: overlay_blend is _video_composite_blend (0 off, -1 or >= 32 full, 1..31 fading --
+ *    the caller decrements it once per field as video_isr does, src/video.cpp:1192-1193),
+ *    overlay_progress is _video_composite_progress (0..240).
+ * overlay (device memory) holds n_streams blocks of 1280 bytes overlay_stride apart, or one
+ * block shared by all streams when overlay_stride is 0; NULL with a non-zero blend draws the
+ * bar over an all-zero text area. */
+typedef struct efx_field_opts {
+    int first_stream, n_streams;
+    int slot, other_slot;
+    int ntsc;
+    int frame_counter;
+    int hscroll;
+    const uint8_t* overlay;
+    size_t overlay_stride;
+    int overlay_blend;
+    int overlay_progress;
+} efx_field_opts;
+int efx_composite_fields_ex(efx_ctx* ctx, const efx_field_opts* opts, uint16_t* dst_device);
+
 /* -- PDM audio out (pdm_second_order / write_pcm_16, espflix.ino:73-145) ------------------ */
 /* n_streams independent modulators.  pcm: n_streams x n_samples int16 (stream-major, device);
  * state: n_streams x 3 int32 (_i0,_i1,_i2; device, updated in place); dst: n_streams x

@@ -121,9 +121,19 @@ void video_pause(int p);
 extern "C" void video_isr(volatile void* buf);
 // publish the frames the line callback displays (the reference's push_video does this through
 // file-scope globals _frames/_next_frame, src/video.cpp:1027,1054)
-void efx_video_present(Frame* frames, int front);
+// `mode` is push_video's: 2 / 3 start the ease-in / ease-out slide between the two Frames at the
+// flip (src/video.cpp:1047-1050,1166-1171).
+void efx_video_present(Frame* frames, int front, int mode = 0);
 int efx_video_line_width();
 int efx_video_line_count();
+
+// the time / progress-bar overlay the host draws into (src/video.h:52-55, src/video.cpp:838-843)
+#define VIDEO_COMPOSITE_WIDTH 80
+#define VIDEO_COMPOSITE_HEIGHT 16
+#define VIDEO_COMPOSITE_PROGRESS_WIDTH (352 - VIDEO_COMPOSITE_WIDTH - 32)
+extern uint8_t _video_composite[VIDEO_COMPOSITE_HEIGHT * VIDEO_COMPOSITE_WIDTH];
+extern int _video_composite_blend;     // -1 always show, 1-31 blend, >=32 show
+extern int _video_composite_progress;
 
 void write_pcm_16(const int16_t* s, int n, int channels);
 void beep();
@@ -351,9 +361,25 @@ struct VideoState {
     Frame* frames;
     int front;
     int line_counter, frame_counter;
+    int hscroll, animate, animate_index;  // _hscroll, _animate, _animate_index (video.cpp:940-943)
     uint16_t* d_field;
+    uint8_t* d_overlay;
     std::vector<uint16_t> field;
-    VideoState() : ctx(0), ntsc(1), frames(0), front(-1), line_counter(0), frame_counter(0), d_field(0) {}
+    VideoState()
+        : ctx(0), ntsc(1), frames(0), front(-1), line_counter(0), frame_counter(0), hscroll(0), animate(0),
+          animate_index(0), d_field(0), d_overlay(0)
+    {
+    }
+    void step_animation()  // animate(), video.cpp:1076-1088
+    {
+        static const int16_t easd[16] = {0, 8, 16, 24, 48, 72, 104, 136, 176, 216, 248, 280, 304, 328, 336, 344};
+        if (animate_index == 0)
+            hscroll = 0;
+        else if (animate_index < 0)
+            hscroll = -easd[-++animate_index];
+        else
+            hscroll = easd[--animate_index];
+    }
 };
 inline VideoState& vs()
 {
@@ -385,6 +411,10 @@ void video_init(int ntsc)  // video.cpp:572-601
     void* p = 0;
     efx_device_alloc(v.ctx, n * 2, &p);
     v.d_field = (uint16_t*)p;
+    if (!v.d_overlay) {
+        efx_device_alloc(v.ctx, sizeof(_video_composite), &p);
+        v.d_overlay = (uint8_t*)p;
+    }
     v.field.assign(n, 0);
     v.line_counter = v.frame_counter = 0;
 }
@@ -392,10 +422,22 @@ void video_init(int ntsc)  // video.cpp:572-601
 void video_reset() {}
 void video_pause(int) {}
 
-void efx_video_present(Frame* frames, int front)
+uint8_t _video_composite[VIDEO_COMPOSITE_HEIGHT * VIDEO_COMPOSITE_WIDTH];
+int _video_composite_blend = 0;
+int _video_composite_progress = 0;
+
+void efx_video_present(Frame* frames, int front, int mode)
 {
-    efx_player_detail::vs().frames = frames;
-    efx_player_detail::vs().front = front;
+    efx_player_detail::VideoState& v = efx_player_detail::vs();
+    v.frames = frames;
+    v.front = front;
+    // the flip the ISR performs in a blanking line (video.cpp:1162-1175)
+    if (mode == 2)
+        v.animate_index = -16;
+    else if (mode == 3)
+        v.animate_index = 16;
+    if (mode)
+        v.step_animation();
 }
 int efx_video_line_width() { return efx_player_detail::vs().vp.line_width; }
 int efx_video_line_count() { return efx_player_detail::vs().vp.line_count; }
@@ -409,16 +451,36 @@ extern "C" void video_isr(volatile void* vbuf)  // video.cpp:1122-1198, one call
         // render the whole field on the GPU from the current front Frame (host memory, may have been
         // drawn into by UI code), then hand it out line by line
         std::vector<uint8_t> fr(EFX_FRAME_BYTES);
-        for (int s = 0; s < FB_SLICES; s++)
-            memcpy(&fr[(size_t)s * EFX_STRIP_BYTES], v.frames[v.front]._slices[s], EFX_STRIP_BYTES);
-        efx_upload_frame(v.ctx, 0, 0, &fr[0]);
-        efx_composite_fields(v.ctx, 0, 1, 0, v.ntsc, v.frame_counter, v.d_field);
+        for (int k = 0; k < (v.hscroll ? 2 : 1); k++) {  // ring slot 0 = front, 1 = the other Frame of the pair
+            const Frame& f = v.frames[k ? v.front ^ 1 : v.front];
+            for (int s = 0; s < FB_SLICES; s++)
+                memcpy(&fr[(size_t)s * EFX_STRIP_BYTES], f._slices[s], EFX_STRIP_BYTES);
+            efx_upload_frame(v.ctx, 0, k, &fr[0]);
+        }
+        efx_field_opts o;
+        memset(&o, 0, sizeof(o));
+        o.n_streams = 1;
+        o.slot = 0;
+        o.other_slot = 1;
+        o.ntsc = v.ntsc;
+        o.frame_counter = v.frame_counter;
+        o.hscroll = v.hscroll;
+        if (_video_composite_blend) {
+            efx_memcpy_h2d(v.ctx, v.d_overlay, _video_composite, sizeof(_video_composite));
+            o.overlay = v.d_overlay;
+            o.overlay_blend = _video_composite_blend < -1 ? -1 : _video_composite_blend;
+            o.overlay_progress = _video_composite_progress;
+        }
+        efx_composite_fields_ex(v.ctx, &o, v.d_field);
         efx_memcpy_d2h(v.ctx, &v.field[0], v.d_field, v.field.size() * 2);
     }
     memcpy((void*)vbuf, &v.field[(size_t)v.line_counter * v.vp.line_width], (size_t)v.vp.line_width * 2);
-    if (++v.line_counter == v.vp.line_count) {
+    if (++v.line_counter == v.vp.line_count) {  // video.cpp:1189-1196
         v.line_counter = 0;
         v.frame_counter++;
+        if (_video_composite_blend > 0)
+            --_video_composite_blend;
+        v.step_animation();
     }
 }
 

@@ -1108,19 +1108,21 @@ static void st32(uint16_t* dst, uint32_t w) /* one 32-bit store = two little-end
     dst[1] = (uint16_t)(w >> 16);
 }
 
-/* blit (video.cpp:690-804) for x = 0, width = 352: four luma pixels per step. */
-static void blit_line(const video_t* v, const frame_t* f, uint16_t* dst, int line, int frame_counter)
+/* blit (video.cpp:690-804): `width` luma pixels from column x (x and width multiples of 8), four
+ * luma pixels per step. */
+static void blit_line(const video_t* v, const frame_t* f, uint16_t* dst, int line, int frame_counter, int x, int width)
 {
-    const uint8_t* y = luma_row(f, line);
-    const uint8_t* u = cr_row(f, line >> 1);
-    const uint8_t* w = cb_row(f, line >> 1);
+    x &= ~3;
+    const uint8_t* y = luma_row(f, line) + x;
+    const uint8_t* u = cr_row(f, line >> 1) + (x >> 1);
+    const uint8_t* w = cb_row(f, line >> 1) + (x >> 1);
     const uint8_t* u2 = u;
     const uint8_t* w2 = w;
     int odd = line & 1;
     if (odd) {
         int n = (line >> 1) + (line == 191 ? 0 : 1);
-        u2 = cr_row(f, n);
-        w2 = cb_row(f, n);
+        u2 = cr_row(f, n) + (x >> 1);
+        w2 = cb_row(f, n) + (x >> 1);
     }
     const uint32_t* tab_u = v->color_tab;
     const uint32_t* tab_v = v->color_tab + (odd ? 512 : 256);
@@ -1128,7 +1130,7 @@ static void blit_line(const video_t* v, const frame_t* f, uint16_t* dst, int lin
         dst += 80;
     uint32_t dither = dither_tab[(line & 3) + ((frame_counter & 1) << 2)];
     uint8_t lum = 0;
-    for (int g = 0; g < FB_WIDTH / 4; g++) {
+    for (int g = 0; g < width / 4; g++) {
         uint32_t u4 = ld32(u + (g >> 1) * 4), v4 = ld32(w + (g >> 1) * 4);
         if (odd) {
             u4 = ((u4 >> 1) & 0x7F7F7F7Fu) + ((ld32(u2 + (g >> 1) * 4) >> 1) & 0x7F7F7F7Fu);
@@ -1201,15 +1203,45 @@ static void put_pal_sync(const video_t* v, uint16_t* line, int i) /* video.cpp:9
     }
 }
 
-long efxo_video_field(const uint8_t* frames2, int ntsc, int frame_counter0, int nfields, uint16_t* out)
+/* composite(), video.cpp:845-887: overlay text and progress bar on line `line` of the overlay */
+static void put_overlay(const video_t* v, uint16_t* dst, int line, const uint8_t* overlay, int blend, int progress)
 {
-    if (!frames2 || !out || nfields < 0)
+    if (!blend)
+        return;
+    if (v->pal)
+        dst += 80;
+    dst += 16; /* d32 += 8 */
+    int scale = 255 / 4;
+    if (blend != -1 && blend < 32)
+        scale = (scale * blend) >> 5;
+    for (int n = 0; n < 80; n++) {
+        uint32_t p = BLACK_LEVEL + (overlay ? overlay[line * 80 + n] : 0) * scale;
+        st32(dst, (p << 16) | p);
+        dst += 2;
+    }
+    if (line < 3 || line > 8)
+        return;
+    dst += 16;
+    uint32_t c0 = BLACK_LEVEL + (scale << 8), c1 = BLACK_LEVEL + (scale << 7);
+    for (int i = 0; i < 352 - 80 - 32; i += 2) {
+        uint32_t c = i < progress ? c0 : c1;
+        st32(dst, (c << 16) | c);
+        st32(dst + 2, (c << 16) | c);
+        dst += 4;
+    }
+}
+
+long efxo_video_field_ex(const uint8_t* frames2, int ntsc, int frame_counter0, int nfields, int front,
+                         const int16_t* hscroll, const uint8_t* overlay, int blend, int progress, uint16_t* out)
+{
+    if (!frames2 || !out || nfields < 0 || front < 0 || front > 1)
         return -1;
     video_t v;
     video_setup(&v, ntsc);
-    frame_t f; /* front frame = Frame[0] */
-    for (int s = 0; s < STRIPS; s++)
-        f.strip[s] = (uint8_t*)frames2 + (size_t)s * STRIP_BYTES;
+    frame_t fr[2];
+    for (int k = 0; k < 2; k++)
+        for (int s = 0; s < STRIPS; s++)
+            fr[k].strip[s] = (uint8_t*)frames2 + (size_t)k * EFXO_FRAME_BYTES + (size_t)s * STRIP_BYTES;
     /* two DMA line buffers ping-pong (video.cpp:171-186); active lines only rewrite sync,
      * burst and the picture window, the rest is what the last blanking line left there */
     uint16_t* bufs[2];
@@ -1226,21 +1258,40 @@ long efxo_video_field(const uint8_t* frames2, int ntsc, int frame_counter0, int 
             if (i >= active_top && i < active_bottom) {
                 put_sync(buf, v.hsync);
                 put_burst(&v, buf, line_counter);
-                blit_line(&v, &f, buf + v.active_start + 16, i - active_top, frame_counter);
+                uint16_t* dst = buf + v.active_start + 16;
+                int f = front, h = hscroll ? hscroll[fld] : 0; /* video.cpp:1146-1154 */
+                if (h < 0) {
+                    h += 352;
+                    f ^= 1;
+                }
+                blit_line(&v, &fr[f], dst, i - active_top, frame_counter, h, 352 - h);
+                if (h)
+                    blit_line(&v, &fr[f ^ 1], dst + (352 - h) * 2, i - active_top, frame_counter, 0, h);
             } else if (i >= vsync_start) {
                 if (v.pal)
                     put_pal_sync(&v, buf, i);
                 else
                     put_blanking(&v, buf, 1, line_counter);
-            } else
+            } else {
                 put_blanking(&v, buf, 0, line_counter);
+                int ptop = active_bottom + 2; /* video.cpp:1181-1187 */
+                if (i >= ptop && i < ptop + 16)
+                    put_overlay(&v, buf + v.active_start + 16, i - ptop, overlay, blend, progress);
+            }
             memcpy(out + ((size_t)fld * v.line_count + i) * v.line_width, buf, (size_t)v.line_width * 2);
         }
         frame_counter++;
+        if (blend > 0) /* video.cpp:1192-1193 */
+            --blend;
     }
     free(bufs[0]);
     free(bufs[1]);
     return (long)v.line_count * v.line_width;
+}
+
+long efxo_video_field(const uint8_t* frames2, int ntsc, int frame_counter0, int nfields, uint16_t* out)
+{
+    return efxo_video_field_ex(frames2, ntsc, frame_counter0, nfields, 0, NULL, NULL, 0, 0, out);
 }
 
 /* ------------------------------------------------------------------------------------ */

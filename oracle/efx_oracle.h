@@ -50,6 +50,13 @@ uint64_t efxo_fnv1a64(const uint8_t* p, size_t n, uint64_t h);
  * h-scroll.  Produces nfields fields starting with _frame_counter = frame_counter0, each
  * line_count x line_width u16.  Returns samples written per field, or <0. */
 long efxo_video_field(const uint8_t* frames2, int ntsc, int frame_counter0, int nfields, uint16_t* out);
+/* The same with the displayed frame `front` (0/1), a per-field _hscroll value (NULL = 0; the
+ * two-frame slide of video.cpp:1146-1154) and the 80 x 16 overlay + progress bar of composite()
+ * (video.cpp:845-887): overlay = 1280 bytes or NULL, blend = _video_composite_blend at the first
+ * field (decremented per field while > 0, video.cpp:1192-1193), progress =
+ * _video_composite_progress. */
+long efxo_video_field_ex(const uint8_t* frames2, int ntsc, int frame_counter0, int nfields, int front,
+                         const int16_t* hscroll, const uint8_t* overlay, int blend, int progress, uint16_t* out);
 /* geometry: {line_width,line_count,hsync,hsync_long,hsync_short,burst_start,burst_width,active_start} */
 void efxo_video_params(int ntsc, int32_t out8[8]);
 /* the 768-entry colour LUT video_init leaves in _color_tab (video.cpp:584-591) */

@@ -12,6 +12,13 @@
 //        frames.bin = 2 x 101376 bytes (Frame[0], Frame[1] in strip order); front = 0.
 //        Output: nfields x line_count x line_width little-endian u16 samples.
 //        _frame_counter starts at 0 and is advanced by the ISR itself (dither parity).
+//   efx_ref_video fieldx <frames.bin> <ntsc:1|0> <nfields> <out.bin> <front:0|1> <hscroll.bin|-> <overlay.bin|-> <blend> <progress>
+//        the same with the reference's own display state set before the fields run:
+//        _current_frame = front; _hscroll (src/video.cpp:941) = the fld-th int16 of hscroll.bin
+//        before each field (the ISR's animate() zeroes it again at field end while
+//        _animate_index is 0); _video_composite (src/video.cpp:841) = the 1280 overlay bytes,
+//        _video_composite_blend / _video_composite_progress as given (the ISR decrements the
+//        blend once per field itself).
 //   efx_ref_video params <ntsc:1|0> <out.bin>
 //        dumps int32 {line_width,line_count,hsync,hsync_long,hsync_short,burst_start,
 //        burst_width,active_start} followed by _color_tab[768] (u32) and dither4x4[8] (u32).
@@ -33,6 +40,8 @@ extern volatile int _line_counter, _frame_counter;
 extern int _line_width, _line_count, _hsync, _hsync_long, _hsync_short, _burst_start, _burst_width, _active_start;
 extern uint32_t _color_tab[256 * 3];
 extern uint32_t dither4x4[];
+extern int16_t _hscroll, _animate_index;
+extern int _video_composite_blend, _video_composite_progress;
 
 std::string to_string(int i) { return std::to_string(i); }
 void video_init_hw(int, int) {}
@@ -54,7 +63,8 @@ int main(int argc, char** argv)
         fclose(f);
         return 0;
     }
-    if (cmd == "field" && argc == 6) {
+    if ((cmd == "field" && argc == 6) || (cmd == "fieldx" && argc == 11)) {
+        const bool ex = cmd == "fieldx";
         static Frame fb[2];
         fb[0].init();
         fb[1].init();
@@ -68,14 +78,37 @@ int main(int argc, char** argv)
         int nfields = atoi(argv[4]);
         _frames = fb;
         _current_frame = 0;
+        std::vector<int16_t> hs;
+        if (ex) {
+            _current_frame = (int8_t)atoi(argv[6]);
+            if (strcmp(argv[7], "-")) {
+                hs.resize(nfields, 0);
+                FILE* h = fopen(argv[7], "rb");
+                if (!h || fread(&hs[0], 2, nfields, h) != (size_t)nfields) return 2;
+                fclose(h);
+            }
+            if (strcmp(argv[8], "-")) {
+                FILE* h = fopen(argv[8], "rb");
+                if (!h || fread(_video_composite, 1, VIDEO_COMPOSITE_WIDTH * VIDEO_COMPOSITE_HEIGHT, h) !=
+                              VIDEO_COMPOSITE_WIDTH * VIDEO_COMPOSITE_HEIGHT) return 2;
+                fclose(h);
+            }
+            _video_composite_blend = atoi(argv[9]);
+            _video_composite_progress = atoi(argv[10]);
+        }
         std::vector<uint16_t> a(_line_width, 0), b(_line_width, 0);
         FILE* o = fopen(argv[5], "wb");
-        for (int fld = 0; fld < nfields; fld++)
+        for (int fld = 0; fld < nfields; fld++) {
+            if (!hs.empty()) {
+                _animate_index = 0;
+                _hscroll = hs[fld];
+            }
             for (int l = 0; l < _line_count; l++) {
                 uint16_t* buf = (l & 1) ? &b[0] : &a[0];   // two DMA descriptors ping-pong (src/video.cpp:171-186)
                 video_isr(buf);
                 fwrite(buf, 2, _line_width, o);
             }
+        }
         fclose(o);
         return 0;
     }

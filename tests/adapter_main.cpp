@@ -77,6 +77,20 @@ int main(int argc, char** argv)
     }
     printf("V %016llx\n", (unsigned long long)h);
 
+    // slide back to the previous picture (push_video mode 3) under a fading time overlay, as the
+    // navigation UI does (espflix.cpp:62-84,873): three more fields
+    for (int i = 0; i < VIDEO_COMPOSITE_WIDTH * VIDEO_COMPOSITE_HEIGHT; i++)
+        _video_composite[i] = (uint8_t)(i * 7);
+    _video_composite_blend = 33;
+    _video_composite_progress = 120;
+    efx_video_present(g_frames, g_front ^ 1, 3);
+    h = 0xcbf29ce484222325ull;
+    for (int l = 0; l < 3 * efx_video_line_count(); l++) {
+        video_isr(&line[0]);
+        h = fnv((const uint8_t*)&line[0], line.size() * 2, h);
+    }
+    printf("W %016llx %d\n", (unsigned long long)h, _video_composite_blend);
+
     efx_set_pdm_sink(audio_sink);
     int16_t pcm[128];
     for (int c = 0; c < 3; c++) {

@@ -127,3 +127,27 @@ def hostile_ts(es: bytes, seed: int, noise: bool = True) -> bytes:
         pts = None if kind == 0 else 200000 + 3003 * i + int(rng.integers(0, 100))
         starts.append((off, pts, kind == 1, int(rng.integers(0, 4)) if kind == 2 else 0))
     return packetize(es, starts, rng, noise=noise)
+
+
+# ---- display-state cases shared by the oracle-vs-reference, golden and GPU tests ---------------
+EASE = [0, 8, 16, 24, 48, 72, 104, 136, 176, 216, 248, 280, 304, 328, 336, 344]   # _easd, video.cpp:1076
+
+
+def overlay_bytes(seed: int) -> np.ndarray:
+    """An 80 x 16 overlay (_video_composite): random glyph-like bytes incl. 0 and 255."""
+    rng = np.random.default_rng(seed)
+    o = rng.integers(0, 256, 1280, dtype=np.uint8)
+    o[rng.integers(0, 1280, 200)] = 0
+    o[rng.integers(0, 1280, 50)] = 255
+    return o
+
+
+# (name, front, hscroll per field or None, overlay seed or None, blend, progress)
+DISPLAY_CASES = [
+    ("slide_in", 0, [0] + [-e for e in EASE[::-1]], None, 0, 0),        # animate() with _animate_index = -16
+    ("slide_out", 1, [0] + EASE[::-1], None, 0, 0),                       # _animate_index = 16
+    ("overlay_full", 0, None, 5, -1, 100),
+    ("overlay_fade", 1, None, 6, 34, 239),                                # 34, 33, 32 full, then 31.. fading
+    ("overlay_bar_only", 0, None, None, 3, 1),
+    ("both", 0, [8, -8, 344, -344, 176, -176], 7, 40, 240),
+]

@@ -9,6 +9,7 @@ Everything in golden.json is an output of the reference itself:
              embedded in the reference (src/splash.h, src/vmedia.h), with and without the final
              flush_picture(1)
   synthetic  the same for generator streams (TS-wrapped) of several flavours
+  display    FNV of video_isr() fields with _hscroll slides and the composite() overlay / progress bar
   composite  FNV of video_isr() fields (NTSC and PAL, 3 fields) for LCG / random / decoded frames
   pdm        FNV of write_pcm_16() output incl. silence and beep calls
   tables     zig_zag, scale_dct_q, _color_tab, video geometry
@@ -29,7 +30,7 @@ import oracle
 from espflix_amd import gen
 
 assert oracle.have_ref(), "build oracle/_ref first (make ref)"
-out = {"clips": {}, "synthetic": {}, "composite": {}, "pdm": {}, "tables": {}}
+out = {"clips": {}, "synthetic": {}, "composite": {}, "display": {}, "pdm": {}, "tables": {}}
 
 for clip in ("splash", "vmedia"):
     subprocess.run([os.path.join(oracle.REF_DIR, "efx_ref_decode"), "fixture", "@" + clip,
@@ -53,6 +54,15 @@ for name, fr in inputs.items():
     for ntsc in (True, False):
         f = oracle.ref_video_field(fr, ntsc, 3)
         out["composite"][f"{name}:{'ntsc' if ntsc else 'pal'}"] = [f"{common.fnv_bytes(f[i]):016x}" for i in range(3)]
+
+# display state: two-frame slide (_hscroll) and overlay / progress bar, on random frames <= 248
+disp = np.minimum(common.random_frames(77), 248)
+for name, front, hs, ov_seed, blend, progress in common.DISPLAY_CASES:
+    n = len(hs) if hs is not None else 6
+    ov = common.overlay_bytes(ov_seed) if ov_seed is not None else (np.zeros(1280, np.uint8) if blend else None)
+    for ntsc in (True, False):
+        f = oracle.ref_video_field_ex(disp, ntsc, n, front, hs, ov, blend, progress)
+        out["display"][f"{name}:{'ntsc' if ntsc else 'pal'}"] = [f"{common.fnv_bytes(f[i]):016x}" for i in range(n)]
 
 pcm = common.pdm_pcm(0, 40)
 out["pdm"]["sine220_silence7_beep3"] = f"{common.fnv_bytes(oracle.ref_pdm(pcm, silence_every=7, beep_at=3)):016x}"

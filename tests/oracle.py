@@ -89,6 +89,28 @@ def video_field(frames2: np.ndarray, ntsc: bool, frame_counter0: int, nfields: i
     return out
 
 
+def video_field_ex(frames2: np.ndarray, ntsc: bool, frame_counter0: int, nfields: int, front: int = 0, hscroll=None,
+                   overlay=None, blend: int = 0, progress: int = 0) -> np.ndarray:
+    """hscroll: one value per field or None; overlay: 1280 bytes or None; blend decrements per field."""
+    frames2 = np.ascontiguousarray(frames2, dtype=np.uint8)
+    assert frames2.size == 2 * FRAME_BYTES
+    p = video_params(ntsc)
+    out = np.zeros((nfields, p[1], p[0]), dtype=np.uint16)
+    hs = None if hscroll is None else np.ascontiguousarray(hscroll, dtype=np.int16)
+    ov = None if overlay is None else np.ascontiguousarray(overlay, dtype=np.uint8)
+    assert hs is None or hs.size == nfields
+    assert ov is None or ov.size == 1280
+    L = lib()
+    L.efxo_video_field_ex.restype = C.c_long
+    L.efxo_video_field_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_int, C.c_void_p]
+    r = L.efxo_video_field_ex(frames2.ctypes.data, 1 if ntsc else 0, frame_counter0, nfields, front,
+                              hs.ctypes.data if hs is not None else None, ov.ctypes.data if ov is not None else None,
+                              blend, progress, out.ctypes.data)
+    assert r == p[0] * p[1]
+    return out
+
+
 def color_tab(ntsc: bool) -> np.ndarray:
     t = np.zeros(768, dtype=np.uint32)
     lib().efxo_color_tab(1 if ntsc else 0, t.ctypes.data)
@@ -151,6 +173,24 @@ def ref_video_field(frames2: np.ndarray, ntsc: bool, nfields: int) -> np.ndarray
         np.ascontiguousarray(frames2, dtype=np.uint8).tofile(src)
         subprocess.run([os.path.join(REF_DIR, "efx_ref_video"), "field", src, "1" if ntsc else "0", str(nfields), out],
                        check=True, timeout=600)
+        p = video_params(ntsc)
+        return np.fromfile(out, dtype=np.uint16).reshape(nfields, p[1], p[0])
+
+
+def ref_video_field_ex(frames2: np.ndarray, ntsc: bool, nfields: int, front: int = 0, hscroll=None, overlay=None,
+                       blend: int = 0, progress: int = 0) -> np.ndarray:
+    with tempfile.TemporaryDirectory() as td:
+        src, out = os.path.join(td, "f.bin"), os.path.join(td, "o.bin")
+        np.ascontiguousarray(frames2, dtype=np.uint8).tofile(src)
+        hs, ov = "-", "-"
+        if hscroll is not None:
+            hs = os.path.join(td, "h.bin")
+            np.ascontiguousarray(hscroll, dtype=np.int16).tofile(hs)
+        if overlay is not None:
+            ov = os.path.join(td, "v.bin")
+            np.ascontiguousarray(overlay, dtype=np.uint8).tofile(ov)
+        subprocess.run([os.path.join(REF_DIR, "efx_ref_video"), "fieldx", src, "1" if ntsc else "0", str(nfields), out,
+                        str(front), hs, ov, str(blend), str(progress)], check=True, timeout=600)
         p = video_params(ntsc)
         return np.fromfile(out, dtype=np.uint16).reshape(nfields, p[1], p[0])
 

@@ -38,6 +38,11 @@ def test_reference_style_host_program(tmp_path, clip, golden):
     want = oracle.video_field(np.concatenate([fr[-1], fr[-1]]), True, 0, 1)
     v = [r for r in rows if r[0] == "V"][0][1]
     assert v == f"{oracle.fnv1a64(want.reshape(-1).view(np.uint8)):016x}"
+    # slide (mode 3) to the previous picture under the fading overlay: fields 1..3
+    ov = (np.arange(1280) * 7).astype(np.uint8)
+    want = oracle.video_field_ex(np.concatenate([fr[-2], fr[-1]]), True, 1, 3, 0, [344, 336, 328], ov, 33, 120)
+    w = [r for r in rows if r[0] == "W"][0]
+    assert w[1] == f"{oracle.fnv1a64(want.reshape(-1).view(np.uint8)):016x}" and w[2] == "30"
     # three write_pcm_16 calls (the middle one silence), state carried across calls
     import ctypes
     st = np.zeros(3, dtype=np.int32)

@@ -102,3 +102,67 @@ def test_pdm_vs_reference_golden_and_oracle(efx, golden):
         part = d_o2.download(np.uint16, S * 256).reshape(S, 256)
         assert np.array_equal(part, got[:, c * 256:(c + 1) * 256])
     dec.close()
+
+
+def test_display_state_hscroll_and_overlay(efx, golden):
+    """the two-frame slide (_hscroll, video.cpp:1146-1154) and the overlay / progress
+    bar (composite(), video.cpp:845-887) in k_composite: every field bit-exact against the
+    reference goldens and the oracle; the caller decrements the blend per field as the ISR does."""
+    disp = np.minimum(common.random_frames(77), 248)
+    dec = efx.Decoder(1, 1, 2)
+    dec.upload_frame(0, 0, disp[:efx.FRAME_BYTES])
+    dec.upload_frame(0, 1, disp[efx.FRAME_BYTES:])
+    d_ov = dec.alloc(1280)
+    for name, front, hs, ov_seed, blend0, progress in common.DISPLAY_CASES:
+        n = len(hs) if hs is not None else 6
+        ov = common.overlay_bytes(ov_seed) if ov_seed is not None else None
+        d_ov.upload(ov if ov is not None else np.zeros(1280, np.uint8))
+        for ntsc in (True, False):
+            vp = efx.video_params(ntsc)
+            cnt = vp["line_width"] * vp["line_count"]
+            dst = dec.alloc(cnt * 2)
+            want = oracle.video_field_ex(disp, ntsc, 0, n, front, hs, ov, blend0, progress)
+            blend = blend0
+            got = []
+            for fld in range(n):
+                dec.composite_fields_ex(dst, 0, 1, front, ntsc, fld, other_slot=front ^ 1, hscroll=hs[fld] if hs else 0,
+                                        overlay=d_ov if ov is not None else None, overlay_blend=blend, overlay_progress=progress)
+                dec.sync()
+                f = dst.download(np.uint16, cnt).reshape(vp["line_count"], vp["line_width"])
+                assert np.array_equal(f, want[fld]), (name, ntsc, fld)
+                got.append(f"{common.fnv_bytes(f):016x}")
+                if blend > 0:
+                    blend -= 1
+            assert got == golden["display"][f"{name}:{'ntsc' if ntsc else 'pal'}"], name
+            dst.free()
+    dec.close()
+
+
+def test_display_state_batch_and_arguments(efx):
+    """Per-stream overlays (stride) and a shared overlay give each stream its own field; bad
+    scroll values are rejected."""
+    from espflix_amd import gen
+    b = gen.Batch(0, 4, 2, 12, 0)
+    dec = efx.Decoder(4, 2, 3)
+    dec.upload(b.all_es())
+    dec.decode()
+    frames = [[dec.download_frame(i, s) for s in range(3)] for i in range(4)]
+    ovs = np.stack([common.overlay_bytes(20 + i) for i in range(4)])
+    d_ov = dec.alloc(ovs.size)
+    d_ov.upload(ovs)
+    vp = efx.video_params(True)
+    cnt = vp["line_width"] * vp["line_count"]
+    dst = dec.alloc(4 * cnt * 2)
+    s1, s2 = dec.picture_slot(0), dec.picture_slot(1)
+    dec.composite_fields_ex(dst, 0, 4, s2, True, 3, other_slot=s1, hscroll=-104, overlay=d_ov, overlay_stride=1280,
+                            overlay_blend=17, overlay_progress=77)
+    dec.sync()
+    got = dst.download(np.uint16, 4 * cnt).reshape(4, vp["line_count"], vp["line_width"])
+    for i in range(4):
+        pair = np.concatenate([frames[i][s2], frames[i][s1]])  # oracle frame 0 = displayed, 1 = other
+        want = oracle.video_field_ex(pair, True, 3, 1, 0, [-104], ovs[i], 17, 77)[0]
+        assert np.array_equal(got[i], want), i
+    for bad in (4, 352, -352, 1000):
+        with pytest.raises(efx.EfxError):
+            dec.composite_fields_ex(dst, 0, 4, s2, True, 0, other_slot=s1, hscroll=bad)
+    dec.close()

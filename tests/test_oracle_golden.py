@@ -116,3 +116,15 @@ def test_truncated_stream_stops_cleanly():
         n, h, _, _ = oracle.decode(es[:cut], 0)
         k = int(np.searchsorted(offs, cut, side="right")) - 1   # pictures wholly before the cut
         assert n >= k and (h[:k] == full[:k]).all()
+
+
+def test_display_state_fields(golden):
+    """_hscroll slides and the composite() overlay / progress bar against the reference goldens."""
+    disp = np.minimum(common.random_frames(77), 248)
+    for name, front, hs, ov_seed, blend, progress in common.DISPLAY_CASES:
+        n = len(hs) if hs is not None else 6
+        ov = common.overlay_bytes(ov_seed) if ov_seed is not None else None
+        for ntsc in (True, False):
+            f = oracle.video_field_ex(disp, ntsc, 0, n, front, hs, ov, blend, progress)
+            got = [f"{common.fnv_bytes(f[i]):016x}" for i in range(n)]
+            assert got == golden["display"][f"{name}:{'ntsc' if ntsc else 'pal'}"], name

@@ -72,3 +72,18 @@ def test_hostile_muxing_pts_latch(seed, clips):
         n, h, pts, _ = oracle.decode(ts, 1)
         assert n == len(rh) and (h == rh).all(), (seed, i)
         assert (pts == rpts).all(), (seed, i, pts.tolist(), rpts.tolist())
+
+
+@pytest.mark.parametrize("ntsc", [True, False])
+@pytest.mark.parametrize("case", common.DISPLAY_CASES, ids=[c[0] for c in common.DISPLAY_CASES])
+def test_display_state_hscroll_and_overlay(case, ntsc):
+    """The two-frame slide (_hscroll) and the overlay / progress bar (composite()) of video_isr."""
+    name, front, hs, ov_seed, blend, progress = case
+    fr = common.random_frames(77)
+    fr = np.minimum(fr, 248)
+    n = len(hs) if hs is not None else 6
+    ov = common.overlay_bytes(ov_seed) if ov_seed is not None else None
+    ref = oracle.ref_video_field_ex(fr, ntsc, n, front, hs, ov if ov is not None else (np.zeros(1280, np.uint8) if blend else None),
+                                    blend, progress)
+    got = oracle.video_field_ex(fr, ntsc, 0, n, front, hs, ov, blend, progress)
+    assert np.array_equal(ref, got)
