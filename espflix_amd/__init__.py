@@ -23,6 +23,7 @@ STRIPS = 12
 STRIP_BYTES = 8448
 FRAME_BYTES = 101376
 
+SBC_PROBE_FIRST = 1
 FORMAT_ES = 0
 FORMAT_TS = 1
 
@@ -95,6 +96,8 @@ _SYMBOLS = {
     "efx_video_get_params": (C.c_int, [C.c_int, C.POINTER(_VideoParams)]),
     "efx_composite_fields": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "efx_composite_fields_ex": (C.c_int, [_P, C.POINTER(_FieldOpts), _P]),
+    "efx_sbc_state_bytes": (C.c_size_t, []),
+    "efx_sbc_decode": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, _P, C.c_int]),
     "efx_pdm": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
     "efx_set_timing": (C.c_int, [_P, C.c_int]),
     "efx_get_timing": (C.c_int, [_P, C.POINTER(_Timing)]),
@@ -129,6 +132,10 @@ def video_params(ntsc: bool) -> dict:
     p = _VideoParams()
     _check(None, load_library().efx_video_get_params(1 if ntsc else 0, C.byref(p)))
     return {n: getattr(p, n) for n, _ in _VideoParams._fields_}
+
+
+def sbc_state_bytes() -> int:
+    return int(load_library().efx_sbc_state_bytes())
 
 
 def _check(ctx, status: int):
@@ -307,6 +314,13 @@ class Decoder:
         o = _FieldOpts(first_stream, n_streams, slot, slot if other_slot is None else other_slot, 1 if ntsc else 0,
                        frame_counter, hscroll, g(overlay), overlay_stride, overlay_blend, overlay_progress)
         _check(self._ctx, self._lib.efx_composite_fields_ex(self._ctx, C.byref(o), g(dst)))
+
+    def sbc_decode(self, n_streams: int, frames: DeviceBuffer | int, stream_stride: int, frame_bytes: int, n_frames: int,
+                   state: DeviceBuffer | int, pcm: DeviceBuffer | int, pcm_stride: int, ret: DeviceBuffer | int | None = None,
+                   pcm_count: DeviceBuffer | int | None = None, probe_first: bool = False):
+        g = lambda b: None if b is None else (b.ptr if isinstance(b, DeviceBuffer) else b)
+        _check(self._ctx, self._lib.efx_sbc_decode(self._ctx, n_streams, g(frames), stream_stride, frame_bytes, n_frames,
+                                                   g(state), g(pcm), pcm_stride, g(ret), g(pcm_count), 1 if probe_first else 0))
 
     def pdm(self, n_streams: int, pcm: DeviceBuffer | int, n_samples: int, state: DeviceBuffer | int,
             dst: DeviceBuffer | int):

@@ -29,6 +29,7 @@ __global__ void k_frame_hash(const uint8_t*, int, uint64_t*);
 __global__ void k_fill(uint32_t*, uint32_t, size_t);
 __global__ void k_composite(const uint8_t*, const VideoTables*, FieldArgs, uint16_t*);
 __global__ void k_pdm(const int16_t*, int, int, int32_t*, uint16_t*);
+__global__ void k_sbc(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int);
 #ifdef EFX_PARSE_PROFILE
 __global__ void k_parse_set_prof(uint32_t*);
 #endif
@@ -89,6 +90,7 @@ struct efx_ctx {
     uint64_t calls = 0;
     hipStream_t parse_stream = nullptr;
     VideoTables* d_video[2] = {nullptr, nullptr};  // [0] PAL, [1] NTSC
+    SbcTables* d_sbc_tables = nullptr;
     uint64_t* d_hash = nullptr;
 
     // host staging / results
@@ -211,6 +213,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     A(dalloc(&ctx->d_video[0], 1));
     A(dalloc(&ctx->d_video[1], 1));
     A(dalloc(&ctx->d_hash, n * D));
+    A(dalloc(&ctx->d_sbc_tables, 1));
     A(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_es), ctx->es_cap, hipHostMallocDefault));
     if (e != hipSuccess) {
         fprintf(stderr, "efx_create: %s\n", hipGetErrorString(e));
@@ -224,6 +227,11 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         VideoTables vt;
         build_video_tables(ntsc, &vt);
         A(hipMemcpy(ctx->d_video[ntsc], &vt, sizeof(vt), hipMemcpyHostToDevice));
+    }
+    {
+        SbcTables st;
+        build_sbc_tables(&st);
+        A(hipMemcpy(ctx->d_sbc_tables, &st, sizeof(st), hipMemcpyHostToDevice));
     }
     A(hipMemset(ctx->d_frames, 0, n * D * kFrameBytes));
     A(hipMemset(ctx->d_es, 0, ctx->es_cap));
@@ -250,7 +258,7 @@ void efx_destroy(efx_ctx* ctx)
         (void)hipStreamSynchronize(ctx->stream);
     void* bufs[] = {ctx->d_es,   ctx->d_stream_off, ctx->d_pics,  ctx->d_slices_tmp, ctx->d_qtab,     ctx->d_tables,
                     ctx->d_slice_base, ctx->d_descs, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_hash,
-                    ctx->d_ts, ctx->d_ts_len, ctx->d_pkt_base, ctx->d_es_len, ctx->d_pes_count, ctx->d_pes};
+                    ctx->d_ts, ctx->d_ts_len, ctx->d_pkt_base, ctx->d_es_len, ctx->d_pes_count, ctx->d_pes, ctx->d_sbc_tables};
     for (auto& ev : ctx->ev_demux)
         if (ev)
             (void)hipEventDestroy(ev);
@@ -658,6 +666,22 @@ int efx_pdm(efx_ctx* ctx, int n_streams, const int16_t* pcm_device, int n_sample
         return EFX_ERR_ARG;
     hipLaunchKernelGGL(k_pdm, dim3((n_streams + 63) / 64), dim3(64), 0, ctx->stream, pcm_device, n_streams, n_samples,
                        state_device, dst_device);
+    EFX_HIP(hipGetLastError());
+    return EFX_OK;
+}
+
+size_t efx_sbc_state_bytes(void) { return sizeof(SbcState); }
+
+int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, size_t stream_stride, int frame_bytes,
+                   int n_frames, void* state_device, int16_t* pcm_device, size_t pcm_stride, uint32_t* ret_device,
+                   uint32_t* pcm_count_device, int flags)
+{
+    if (!ctx || !frames_device || !state_device || !pcm_device || n_streams <= 0 || n_frames < 0 || frame_bytes <= 0 ||
+        (size_t)frame_bytes * (size_t)n_frames > 0x7FFFFFFFu || ((uintptr_t)state_device & 3))
+        return EFX_ERR_ARG;
+    hipLaunchKernelGGL(k_sbc, dim3(n_streams), dim3(64), 0, ctx->stream, frames_device, stream_stride, frame_bytes, n_frames,
+                       static_cast<SbcState*>(state_device), ctx->d_sbc_tables, pcm_device, pcm_stride, ret_device,
+                       pcm_count_device, flags);
     EFX_HIP(hipGetLastError());
     return EFX_OK;
 }

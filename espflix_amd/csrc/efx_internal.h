@@ -110,6 +110,23 @@ struct FieldArgs {
     int overlay_progress;
 };
 
+// SBC synthesis tables (sbc_decoder.cpp:41-71), generated from the A2DP definitions
+struct SbcTables {
+    int32_t syn[128];   // syn[i * 8 + k] = floor(65536 cos((i + 4)(2k + 1) pi / 16))
+    int32_t proto[80];  // proto[i * 10 + j] = floor(-8 * 32768 * Proto_8_80[8 j + i])
+};
+
+// per-stream SBC decoder state (the reference's SBC_Decode, sbc_decoder.h:12-25, with the sliding
+// synthesis buffer kept as the last nine rows of matrixing outputs); all zero = sbc_init()
+struct SbcState {
+    int32_t hist[2][9][16];
+    int32_t sb_sample[16][2][8];
+    uint8_t frequency, blocks, channels, mode, allocation, subbands, bitpool, reserved;
+    uint8_t pad[8];
+};
+static_assert(sizeof(SbcState) == 2192, "SbcState layout");
+
+void build_sbc_tables(SbcTables* t);
 void build_parse_tables(ParseTables* t);
 void build_video_tables(int ntsc, VideoTables* t);
 

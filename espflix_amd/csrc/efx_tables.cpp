@@ -156,4 +156,32 @@ void build_video_tables(int ntsc, VideoTables* t)
     }
 }
 
+// SBC synthesis matrix and prototype window (sbc_decoder.cpp:41-71) from their A2DP Appendix B
+// definitions: N[i][k] = cos((i + 4)(2k + 1) pi / 16) in 16.16, and the 80-tap prototype filter
+// Proto_8_80 scaled by -8 in 1.15, both rounded toward minus infinity.  The filter is symmetric
+// about tap 40 except that taps 48 and 64 are the negatives of taps 32 and 16.
+void build_sbc_tables(SbcTables* t)
+{
+    static const double proto_half[41] = {
+        0.00000000E+00, 1.56575398E-04, 3.43256425E-04, 5.54620202E-04, 8.23919506E-04, 1.13992507E-03,
+        1.47640169E-03, 1.78371725E-03, 2.01182542E-03, 2.10371989E-03, 1.99454554E-03, 1.61656283E-03,
+        9.02154502E-04, -1.78805361E-04, -1.64973098E-03, -3.49717454E-03, 5.65949473E-03, 8.02941163E-03,
+        1.04584443E-02, 1.27472335E-02, 1.46525263E-02, 1.59045603E-02, 1.62208471E-02, 1.53184106E-02,
+        1.29371806E-02, 8.85757540E-03, 2.92408442E-03, -4.91578024E-03, -1.46404076E-02, -2.61098752E-02,
+        -3.90751381E-02, -5.31873032E-02, 6.79989431E-02, 8.29847578E-02, 9.75753918E-02, 1.11196689E-01,
+        1.23264548E-01, 1.33264415E-01, 1.40753505E-01, 1.45389847E-01, 1.46955068E-01};
+    for (int i = 0; i < 16; i++)
+        for (int k = 0; k < 8; k++) {
+            double x = std::cos((i + 4) * (2 * k + 1) * M_PI / 16) * 65536.0;
+            t->syn[i * 8 + k] = std::fabs(x) < 1e-6 ? 0 : (int32_t)std::floor(x);
+        }
+    for (int n = 0; n < 80; n++) {
+        int h = n <= 40 ? n : 80 - n;
+        double p = proto_half[h];
+        if (n > 40 && (h == 16 || h == 32))
+            p = -p;
+        t->proto[(n & 7) * 10 + (n >> 3)] = p == 0 ? 0 : (int32_t)std::floor(-8.0 * 32768.0 * p);
+    }
+}
+
 }  // namespace efx

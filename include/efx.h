@@ -171,6 +171,25 @@ int efx_composite_fields_ex(efx_ctx* ctx, const efx_field_opts* opts, uint16_t* 
 int efx_pdm(efx_ctx* ctx, int n_streams, const int16_t* pcm_device, int n_samples, int32_t* state_device,
             uint16_t* dst_device);
 
+/* -- SBC audio decode (sbc_decoder, src/sbc_decoder.cpp:346-378; decode_audio, src/video.cpp:962-989) -- */
+/* Bytes of decoder state per stream (the reference's SBC_Decode, src/sbc_decoder.h:12-25).  All
+ * zero is sbc_init(). */
+size_t efx_sbc_state_bytes(void);
+#define EFX_SBC_PROBE_FIRST 1 /* decode frame 0 once more up front and drop that PCM: decode_audio()'s
+                                 frame-size probe (src/video.cpp:964-972) synthesises the first frame twice */
+/* n_streams independent decoders.  frames: n_frames frames of frame_bytes per stream,
+ * stream_stride bytes apart (device); state: n_streams x efx_sbc_state_bytes() (device, updated);
+ * pcm: per stream pcm_stride int16 apart (device), frames back to back, blocks x 8 x channels
+ * samples each with the channel blocks NOT interleaved (src/sbc_decoder.h:27); ret (device, may
+ * be NULL): per (stream, frame) sbc_decoder()'s return value in the low 16 bits (0xFFFF = -1) and
+ * its decoded byte count in the high 16; pcm_count (device, may be NULL): samples written per
+ * stream.  8 subbands, mono / dual / stereo; joint stereo, 4 subbands, a bad sync byte (and a
+ * bitpool above 128, which hangs the reference) are rejected exactly as sbc_decoder() does --
+ * including its re-synthesis of the previous subband samples.  Asynchronous. */
+int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, size_t stream_stride, int frame_bytes,
+                   int n_frames, void* state_device, int16_t* pcm_device, size_t pcm_stride, uint32_t* ret_device,
+                   uint32_t* pcm_count_device, int flags);
+
 /* -- measurement -------------------------------------------------------------------------- */
 typedef struct efx_timing {
     float index_ms, parse_ms, recon_ms, total_ms; /* HIP-event times of the last efx_decode */

@@ -1345,3 +1345,277 @@ void efxo_write_pcm_16(int32_t state[3], int* beep, const int16_t* s, int n, uin
         for (int i = 0; i < 256; i++)
             out256[i] = 0xAAAA;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* SBC audio (sbc_decoder.cpp)                                                          */
+
+static const uint8_t sbc_block_mode[4] = {4, 8, 12, 16}; /* sbc_decoder.cpp:22 */
+static const int8_t sbc_offset4[4][4] = {{-1, 0, 0, 0}, {-2, 0, 0, 1}, {-2, 0, 0, 1}, {-2, 0, 0, 1}};
+static const int8_t sbc_offset8[4][8] = {{-2, 0, 0, 0, 0, 0, 0, 1},
+                                         {-3, 0, 0, 0, 0, 0, 1, 2},
+                                         {-4, 0, 0, 0, 0, 0, 1, 2},
+                                         {-4, 0, 0, 0, 0, 0, 1, 2}}; /* A2DP 12.8 */
+
+/* The reference tabulates the synthesis matrix and the prototype window as fixed-point words
+ * (sbc_decoder.cpp:41-71).  They are the A2DP (Appendix B) definitions
+ *   syn[i][k]      = floor(65536 cos((i + 4)(2k + 1) pi / 16))               16 x 8
+ *   m[i][j]        = floor(-8 * 32768 * Proto_8_80[8 j + i])                  8 x 10
+ * with Proto_8_80 the standard's 80-tap prototype filter (symmetric about tap 40 except that
+ * taps 48 and 64 are the negatives of taps 32 and 16).  Generated here from those
+ * definitions; test_oracle_vs_ref pins every word against the reference's own tables. */
+static const double sbc_proto_8_80_half[41] = {
+    0.00000000E+00, 1.56575398E-04, 3.43256425E-04, 5.54620202E-04, 8.23919506E-04, 1.13992507E-03,
+    1.47640169E-03, 1.78371725E-03, 2.01182542E-03, 2.10371989E-03, 1.99454554E-03, 1.61656283E-03,
+    9.02154502E-04, -1.78805361E-04, -1.64973098E-03, -3.49717454E-03, 5.65949473E-03, 8.02941163E-03,
+    1.04584443E-02, 1.27472335E-02, 1.46525263E-02, 1.59045603E-02, 1.62208471E-02, 1.53184106E-02,
+    1.29371806E-02, 8.85757540E-03, 2.92408442E-03, -4.91578024E-03, -1.46404076E-02, -2.61098752E-02,
+    -3.90751381E-02, -5.31873032E-02, 6.79989431E-02, 8.29847578E-02, 9.75753918E-02, 1.11196689E-01,
+    1.23264548E-01, 1.33264415E-01, 1.40753505E-01, 1.45389847E-01, 1.46955068E-01};
+static int32_t sbc_syn_8[128], sbc_proto_8[80];
+static int sbc_tables_ready;
+
+static void sbc_tables_init(void)
+{
+    if (sbc_tables_ready)
+        return;
+    for (int i = 0; i < 16; i++)
+        for (int k = 0; k < 8; k++) {
+            double x = cos((i + 4) * (2 * k + 1) * M_PI / 16) * 65536.0;
+            sbc_syn_8[i * 8 + k] = fabs(x) < 1e-6 ? 0 : (int32_t)floor(x);
+        }
+    for (int n = 0; n < 80; n++) {
+        int h = n <= 40 ? n : 80 - n;
+        double p = sbc_proto_8_80_half[h];
+        if (n > 40 && (h == 16 || h == 32))
+            p = -p;
+        int32_t d = p == 0 ? 0 : (int32_t)floor(-8.0 * 32768.0 * p);
+        sbc_proto_8[(n & 7) * 10 + (n >> 3)] = d;
+    }
+    sbc_tables_ready = 1;
+}
+
+void efxo_sbc_tables(int32_t syn128[128], int32_t proto80[80])
+{
+    sbc_tables_init();
+    memcpy(syn128, sbc_syn_8, sizeof(sbc_syn_8));
+    memcpy(proto80, sbc_proto_8, sizeof(sbc_proto_8));
+}
+
+static void sbc_synthesize8(int32_t* v, uint8_t* offset, const int32_t* src, int16_t* dst) /* sbc_decoder.cpp:74-139 */
+{
+    const int32_t* syn = sbc_syn_8;
+    for (int i = 0; i < 16; i++) { /* matrixing: 128 MACs, 32-bit wrapping accumulate */
+        if (!offset[i]) {
+            for (int j = 0; j < 9; j++)
+                v[j + 160] = v[j];
+            offset[i] = 160;
+        }
+        int k = --offset[i];
+        uint32_t s = 0;
+        for (int j = 0; j < 8; j++)
+            s += (uint32_t)syn[j] * (uint32_t)src[j];
+        syn += 8;
+        v[k] = (int32_t)s >> 15;
+    }
+    const int32_t* m = sbc_proto_8;
+    for (int i = 0; i < 8; i++) { /* windowing: 80 MACs */
+        const int32_t* p0 = v + offset[i];
+        const int32_t* p1 = v + offset[(i + 8) & 0xF] + 1;
+        uint32_t s = 0;
+        for (int j = 0; j < 10; j += 2) {
+            s += (uint32_t)p0[j] * (uint32_t)m[j];
+            s += (uint32_t)p1[j] * (uint32_t)m[j + 1];
+        }
+        m += 10;
+        int32_t r = (int32_t)s >> 15;
+        if (r < -0x7FFF)
+            r = -0x7FFF;
+        else if (r > 0x7FFF)
+            r = 0x7FFF;
+        dst[i] = (int16_t)r;
+    }
+}
+
+static void sbc_bit_allocation(const efxo_sbc* sbc, uint8_t (*scale_factor)[8], int (*bits)[8]) /* sbc_decoder.cpp:142-240 */
+{
+    int sf = sbc->frequency, bp = sbc->bitpool, nsb = sbc->subbands;
+    int bitneed[2][8];
+    for (int ch = 0; ch < sbc->channels; ch++) {
+        int max_bitneed = 0;
+        for (int sb = 0; sb < nsb; sb++) {
+            int s = scale_factor[ch][sb];
+            if (sbc->allocation) /* SNR */
+                bitneed[ch][sb] = s;
+            else if (s == 0) /* loudness */
+                bitneed[ch][sb] = -5;
+            else {
+                int loudness = s - (nsb == 4 ? sbc_offset4[sf][sb] : sbc_offset8[sf][sb]);
+                if (loudness > 0)
+                    loudness /= 2;
+                bitneed[ch][sb] = loudness;
+            }
+            if (bitneed[ch][sb] > max_bitneed)
+                max_bitneed = bitneed[ch][sb];
+        }
+        int bitcount = 0, slicecount = 0, bitslice = max_bitneed + 1;
+        do {
+            bitslice--;
+            bitcount += slicecount;
+            slicecount = 0;
+            for (int sb = 0; sb < nsb; sb++) {
+                if (bitneed[ch][sb] > bitslice + 1 && bitneed[ch][sb] < bitslice + 16)
+                    slicecount++;
+                else if (bitneed[ch][sb] == bitslice + 1)
+                    slicecount += 2;
+            }
+        } while (bitcount + slicecount < bp);
+        if (bitcount + slicecount == bp) {
+            bitcount += slicecount;
+            bitslice--;
+        }
+        for (int sb = 0; sb < nsb; sb++) {
+            if (bitneed[ch][sb] < bitslice + 2)
+                bits[ch][sb] = 0;
+            else {
+                bits[ch][sb] = bitneed[ch][sb] - bitslice;
+                if (bits[ch][sb] > 16)
+                    bits[ch][sb] = 16;
+            }
+        }
+        for (int sb = 0; bitcount < bp && sb < nsb; sb++) {
+            if (bits[ch][sb] >= 2 && bits[ch][sb] < 16) {
+                bits[ch][sb]++;
+                bitcount++;
+            } else if (bitneed[ch][sb] == bitslice + 1 && bp > bitcount + 1) {
+                bits[ch][sb] = 2;
+                bitcount += 2;
+            }
+        }
+        for (int sb = 0; bitcount < bp && sb < nsb; sb++) {
+            if (bits[ch][sb] < 16) {
+                bits[ch][sb]++;
+                bitcount++;
+            }
+        }
+    }
+}
+
+static int sbc_get_samples(efxo_sbc* sbc, const uint8_t* data, int len) /* sbc_decoder.cpp:276-344 */
+{
+    int bits[2][8];
+    uint8_t scale_factor[2][8];
+    if (len < 4 || data[0] != 0x9C)
+        return -1;
+    sbc->frequency = (data[1] >> 6) & 3;
+    sbc->blocks = sbc_block_mode[(data[1] >> 4) & 3];
+    sbc->mode = (data[1] >> 2) & 3;
+    sbc->channels = !sbc->mode ? 1 : 2;
+    sbc->allocation = (data[1] >> 1) & 1;
+    sbc->subbands = (data[1] & 1) ? 8 : 4;
+    sbc->bitpool = data[2];
+    if (sbc->mode == 3 || sbc->subbands == 4) /* CRC ignored */
+        return -1;
+    /* A bitpool above 16 bits x 8 subbands can never be met: the reference's allocation loop
+     * (sbc_decoder.cpp:186-198) then never terminates.  Defined here: the frame is rejected like
+     * a joint-stereo one. */
+    if (sbc->bitpool > 128)
+        return -1;
+    const uint8_t* sf = data + 4;
+    for (int ch = 0; ch < sbc->channels; ch++)
+        for (int sb = 0; sb < sbc->subbands; sb += 2) {
+            uint8_t a = *sf++;
+            scale_factor[ch][sb] = a >> 4;
+            scale_factor[ch][sb + 1] = a & 0xF;
+        }
+    sbc_bit_allocation(sbc, scale_factor, bits);
+    int b_count = 0;
+    uint32_t b_bits = 0;
+    const uint8_t* b_data = data + 4 + (sbc->channels * sbc->subbands >> 1);
+    for (int blk = 0; blk < sbc->blocks; blk++)
+        for (int ch = 0; ch < sbc->channels; ch++)
+            for (int sb = 0; sb < sbc->subbands; sb++) {
+                int32_t sample = 0;
+                int level = bits[ch][sb];
+                if (level) {
+                    while (b_count < level) {
+                        b_bits = (b_bits << 8) | *b_data++;
+                        b_count += 8;
+                    }
+                    b_count -= level;
+                    sample = (int32_t)((b_bits >> b_count) & ((1u << level) - 1));
+                    int scale = scale_factor[ch][sb];
+                    /* IQUANT (sbc_decoder.cpp:263-270): 32-bit wrapping shift, C division */
+                    sample = (sample << 1) | 1;
+                    sample = (int32_t)((uint32_t)sample << scale) / ((1 << level) - 1);
+                    sample -= 1 << scale;
+                }
+                sbc->sb_sample[blk][ch][sb] = sample;
+            }
+    return (int)(b_data - data);
+}
+
+void efxo_sbc_init(efxo_sbc* s) { memset(s, 0, sizeof(*s)); } /* sbc_decoder.cpp:375-378 */
+
+int efxo_sbc_decode(efxo_sbc* sbc, const uint8_t* src, int src_len, int16_t* dst, int* decoded) /* sbc_decoder.cpp:346-373 */
+{
+    sbc_tables_init();
+    if (!sbc->inited) {
+        sbc->inited = 1;
+        for (int ch = 0; ch < 2; ch++)
+            for (int i = 0; i < 16; i++)
+                sbc->v_offset[ch][i] = (uint8_t)((i + 1) * 10);
+    }
+    int framelen = sbc_get_samples(sbc, src, src_len);
+    if (sbc->subbands == 4)
+        return -1;
+    /* a frame get_samples() rejected is still synthesised -- from the subband samples and the
+     * geometry the state holds (the previous frame's, or zeros) */
+    int16_t* pcm = dst;
+    for (int ch = 0; ch < sbc->channels; ch++)
+        for (int blk = 0; blk < sbc->blocks; blk++) {
+            sbc_synthesize8(sbc->v[ch], sbc->v_offset[ch], sbc->sb_sample[blk][ch], pcm);
+            pcm += 8;
+        }
+    if (decoded)
+        *decoded = sbc->blocks * sbc->subbands * sbc->channels * 2;
+    return framelen;
+}
+
+size_t efxo_ts_audio_es(const uint8_t* ts, size_t len, uint8_t* out, size_t cap) /* player.cpp:381-433,459-493 */
+{
+    size_t n = 0;
+    int64_t audio_pts = -1;
+    for (size_t pos = 0; pos + 188 <= len; pos += 188) {
+        const uint8_t* p = ts + pos;
+        if (p[0] != 0x47)
+            continue;
+        int pid = ((p[1] << 8) + p[2]) & 0x1fff;
+        const uint8_t* pay = p + 4;
+        if (p[3] & 0x20)
+            pay = p + 5 + p[4];
+        if (!(p[3] & 0x10))
+            continue;
+        const uint8_t* pend = p + 188;
+        int64_t pts = -1;
+        int start = p[1] & 0x40;
+        if (start) {
+            if (pay + 9 > pend) /* defined as for video: a PES header that does not fit drops the packet */
+                continue;
+            const uint8_t* q = pay + 6;
+            int flags = (q[0] << 8) | q[1];
+            pay = q + 3 + q[2];
+            q += 3;
+            if ((flags & 0x0080) && q + 5 <= pend)
+                pts = parse_pts(q, flags);
+        }
+        if (pid != 0x101 && pid != 0x102)
+            continue;
+        if (start)
+            audio_pts = pts;
+        if (audio_pts != -1 && pay < pend)
+            for (const uint8_t* b = pay; b < pend; b++, n++)
+                if (n < cap)
+                    out[n] = *b;
+    }
+    return n;
+}

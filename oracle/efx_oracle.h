@@ -70,6 +70,26 @@ void efxo_pdm_second_order(int32_t state[3], uint16_t* dst, const int16_t* src, 
 /* write_pcm_16 (espflix.ino:123-145): s==NULL -> 256 x 0xAAAA; *beep>0 -> sine burst. */
 void efxo_write_pcm_16(int32_t state[3], int* beep, const int16_t* s, int n, uint16_t out256[256]);
 
+/* SBC audio: restatement of sbc_decoder.cpp:74-373 (8 subbands, mono / dual / stereo; joint
+ * stereo and 4 subbands are rejected as in the reference).  The state is the reference's
+ * SBC_Decode (sbc_decoder.h:12-25); zero it with efxo_sbc_init. */
+typedef struct efxo_sbc {
+    uint8_t inited, frequency, blocks, channels, mode, allocation, subbands, bitpool;
+    int32_t sb_sample[16][2][8];
+    int32_t v[2][160 + 10];
+    uint8_t v_offset[2][16];
+} efxo_sbc;
+void efxo_sbc_init(efxo_sbc* s);
+/* the synthesis matrix SBC_syn_8[128] and window SBC_proto_8[80] (sbc_decoder.cpp:41-71) */
+void efxo_sbc_tables(int32_t syn128[128], int32_t proto80[80]);
+/* sbc_decoder(): returns the frame length consumed (or -1), writes blocks*8*channels int16
+ * (channel blocks NOT interleaved) to dst and their byte count to *decoded. */
+int efxo_sbc_decode(efxo_sbc* s, const uint8_t* src, int src_len, int16_t* dst, int* decoded);
+/* The bytes push_audio() receives for a transport stream (MpegDecoder::demux audio branch,
+ * player.cpp:421-433): payloads of PID 0x101 / 0x102 behind the PES header, only while the
+ * latest audio PES header carried a PTS.  Returns the byte count (may exceed cap). */
+size_t efxo_ts_audio_es(const uint8_t* ts, size_t len, uint8_t* out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

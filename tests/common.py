@@ -151,3 +151,47 @@ DISPLAY_CASES = [
     ("overlay_bar_only", 0, None, None, 3, 1),
     ("both", 0, [8, -8, 344, -344, 176, -176], 7, 40, 240),
 ]
+
+
+# ---- SBC frames (test input only) ------------------------------------------------------------
+def sbc_frame_bytes(blocks: int, channels: int, bitpool: int) -> int:
+    return 4 + channels * 4 + (blocks * channels * bitpool + 7) // 8
+
+
+def sbc_frames(seed: int, n: int, freq: int = 3, blocks: int = 16, mode: int = 0, alloc: int = 0, bitpool: int = 28,
+               max_scale: int = 12) -> np.ndarray:
+    """n syntactically valid 8-subband SBC frames (A2DP frame layout as sbc_decoder.cpp:276-344
+    reads it): header 9C | freq blocks mode alloc 1 | bitpool | crc (ignored by the reference),
+    4-bit scale factors, then random sample bits.  Any bit pattern is a valid frame."""
+    rng = np.random.default_rng(seed)
+    channels = 1 if mode == 0 else 2
+    fb = sbc_frame_bytes(blocks, channels, bitpool)
+    out = np.zeros((n, fb), dtype=np.uint8)
+    out[:, 0] = 0x9C
+    out[:, 1] = (freq << 6) | ({4: 0, 8: 1, 12: 2, 16: 3}[blocks] << 4) | (mode << 2) | (alloc << 1) | 1
+    out[:, 2] = bitpool
+    out[:, 3] = rng.integers(0, 256, n)
+    sf = rng.integers(0, max_scale + 1, (n, channels * 8))
+    out[:, 4:4 + channels * 4] = (sf[:, 0::2] << 4) | sf[:, 1::2]
+    out[:, 4 + channels * 4:] = rng.integers(0, 256, (n, fb - 4 - channels * 4))
+    return out.reshape(-1)
+
+
+# (name, kwargs, frames, probe)
+SBC_CASES = [
+    ("espflix_mono_48k_bp28", dict(freq=3, blocks=16, mode=0, alloc=0, bitpool=28), 40, True),
+    ("mono_snr_32k_bp19_b12", dict(freq=1, blocks=12, mode=0, alloc=1, bitpool=19), 30, False),
+    ("dual_loud_44k_bp35_b8", dict(freq=2, blocks=8, mode=1, alloc=0, bitpool=35), 30, False),
+    ("stereo_snr_16k_bp53_b4", dict(freq=0, blocks=4, mode=2, alloc=1, bitpool=53), 50, False),
+    ("mono_bp2", dict(freq=3, blocks=16, mode=0, alloc=0, bitpool=2), 12, False),
+    ("mono_bp128_loud", dict(freq=3, blocks=16, mode=0, alloc=0, bitpool=128, max_scale=15), 12, False),
+    ("dual_bp128_snr", dict(freq=3, blocks=16, mode=1, alloc=1, bitpool=128, max_scale=15), 8, False),
+]
+
+
+def seed_of(name: str) -> int:
+    import zlib
+    return zlib.crc32(name.encode()) & 0xFFFF
+
+
+CLIP_SBC_FRAME_BYTES = {"splash": 64, "vmedia": 48}

@@ -10,6 +10,7 @@ Everything in golden.json is an output of the reference itself:
              flush_picture(1)
   synthetic  the same for generator streams (TS-wrapped) of several flavours
   display    FNV of video_isr() fields with _hscroll slides and the composite() overlay / progress bar
+  sbc        FNV of sbc_decoder() PCM for synthetic frame configurations and the clips' PID 0x102 audio
   composite  FNV of video_isr() fields (NTSC and PAL, 3 fields) for LCG / random / decoded frames
   pdm        FNV of write_pcm_16() output incl. silence and beep calls
   tables     zig_zag, scale_dct_q, _color_tab, video geometry
@@ -30,7 +31,7 @@ import oracle
 from espflix_amd import gen
 
 assert oracle.have_ref(), "build oracle/_ref first (make ref)"
-out = {"clips": {}, "synthetic": {}, "composite": {}, "display": {}, "pdm": {}, "tables": {}}
+out = {"clips": {}, "synthetic": {}, "composite": {}, "display": {}, "pdm": {}, "sbc": {}, "tables": {}}
 
 for clip in ("splash", "vmedia"):
     subprocess.run([os.path.join(oracle.REF_DIR, "efx_ref_decode"), "fixture", "@" + clip,
@@ -67,6 +68,23 @@ for name, front, hs, ov_seed, blend, progress in common.DISPLAY_CASES:
 pcm = common.pdm_pcm(0, 40)
 out["pdm"]["sine220_silence7_beep3"] = f"{common.fnv_bytes(oracle.ref_pdm(pcm, silence_every=7, beep_at=3)):016x}"
 out["pdm"]["sine220"] = f"{common.fnv_bytes(oracle.ref_pdm(pcm)):016x}"
+
+# SBC audio: PCM of the reference's sbc_decoder() on synthetic frames and on the clips' own audio
+for name, kw, n, probe in common.SBC_CASES:
+    fr = common.sbc_frames(common.seed_of(name), n, **kw)
+    fb = common.sbc_frame_bytes(kw["blocks"], 1 if kw["mode"] == 0 else 2, kw["bitpool"])
+    pcm_ref, _ = oracle.ref_sbc_decode(fr, fb, probe)
+    out["sbc"][name] = f"{common.fnv_bytes(pcm_ref):016x}"
+for clip in ("splash", "vmedia"):
+    ts = np.fromfile(os.path.join(HERE, clip + ".ts"), dtype=np.uint8)
+    es = oracle.ts_audio_es(ts)
+    fb = common.CLIP_SBC_FRAME_BYTES[clip]
+    pcm_ref, _ = oracle.ref_sbc_decode(es[:es.size // fb * fb], fb, True)
+    out["sbc"]["clip:" + clip] = {"frames": int(es.size // fb), "audio_es_fnv": f"{common.fnv_bytes(es):016x}",
+                                  "pcm_fnv": f"{common.fnv_bytes(pcm_ref):016x}"}
+syn, pro = oracle.ref_sbc_tables()
+out["tables"]["sbc_syn_8"] = f"{common.fnv_bytes(syn):016x}"
+out["tables"]["sbc_proto_8"] = f"{common.fnv_bytes(pro):016x}"
 
 for ntsc in (True, False):
     params, ctab, dither = oracle.ref_video_params(ntsc)

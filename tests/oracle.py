@@ -214,3 +214,67 @@ def ref_pdm(pcm: np.ndarray, silence_every: int = 0, beep_at: int = -1) -> np.nd
             cmd += ["beep_at", str(beep_at)]
         subprocess.run(cmd, check=True, timeout=600)
         return np.fromfile(out, dtype=np.uint16)
+
+
+# ---- SBC audio ---------------------------------------------------------------------------------
+class SbcState(C.Structure):
+    _fields_ = [("hdr", C.c_uint8 * 8), ("sb_sample", C.c_int32 * 256), ("v", C.c_int32 * 340),
+                ("v_offset", C.c_uint8 * 32)]
+
+
+def sbc_tables():
+    syn = np.zeros(128, dtype=np.int32)
+    pro = np.zeros(80, dtype=np.int32)
+    lib().efxo_sbc_tables.argtypes = [C.c_void_p, C.c_void_p]
+    lib().efxo_sbc_tables(syn.ctypes.data, pro.ctypes.data)
+    return syn, pro
+
+
+def sbc_decode(frames: np.ndarray, frame_bytes: int, probe: bool = False):
+    """Decode concatenated frames with the restatement.  Returns (pcm int16, [(ret, decoded)])."""
+    L = lib()
+    L.efxo_sbc_decode.restype = C.c_int
+    L.efxo_sbc_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.efxo_sbc_init.argtypes = [C.c_void_p]
+    st = SbcState()
+    L.efxo_sbc_init(C.byref(st))
+    data = np.concatenate([np.ascontiguousarray(frames, dtype=np.uint8), np.zeros(1024, np.uint8)])
+    n = (data.size - 1024) // frame_bytes
+    order = ([0] if probe else []) + list(range(n))
+    out, rets = [], []
+    pcm = np.zeros(256, dtype=np.int16)
+    for fi in order:
+        dec = C.c_int(0)
+        pcm[:] = 0
+        r = L.efxo_sbc_decode(C.byref(st), data[fi * frame_bytes:].ctypes.data, frame_bytes, pcm.ctypes.data, C.byref(dec))
+        rets.append((r, dec.value))
+        out.append(pcm[:dec.value // 2].copy())
+    return (np.concatenate(out) if out else np.zeros(0, np.int16)), rets
+
+
+def ts_audio_es(ts: np.ndarray) -> np.ndarray:
+    ts = np.ascontiguousarray(ts, dtype=np.uint8)
+    out = np.zeros(ts.size, dtype=np.uint8)
+    L = lib()
+    L.efxo_ts_audio_es.restype = C.c_size_t
+    L.efxo_ts_audio_es.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    n = L.efxo_ts_audio_es(ts.ctypes.data, ts.size, out.ctypes.data, out.size)
+    return out[:n].copy()
+
+
+def ref_sbc_decode(frames: np.ndarray, frame_bytes: int, probe: bool = False):
+    with tempfile.TemporaryDirectory() as td:
+        src, out = os.path.join(td, "f.bin"), os.path.join(td, "o.pcm")
+        np.ascontiguousarray(frames, dtype=np.uint8).tofile(src)
+        p = subprocess.run([os.path.join(REF_DIR, "efx_ref_sbc"), "decode", src, str(frame_bytes), out] +
+                           (["probe"] if probe else []), check=True, timeout=120, stderr=subprocess.PIPE, text=True)
+        rets = [(int(l.split()[2]), int(l.split()[3])) for l in p.stderr.splitlines() if l.startswith("R ")]
+        return np.fromfile(out, dtype=np.int16), rets
+
+
+def ref_sbc_tables():
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "t.bin")
+        subprocess.run([os.path.join(REF_DIR, "efx_ref_sbc"), "tables", out], check=True)
+        t = np.fromfile(out, dtype=np.int32)
+        return t[:128], t[128:208]

@@ -1,0 +1,135 @@
+"""the SBC audio decoder as a batch kernel (k_sbc) against the oracle's
+restatement of sbc_decoder.cpp and the reference-derived goldens; then SBC -> PCM -> PDM on the
+device end to end."""
+import numpy as np
+import pytest
+
+import common
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def efx():
+    import espflix_amd
+    espflix_amd.load_library()
+    return espflix_amd
+
+
+def gpu_sbc(efx, dec, streams, fb, probe=False, chunks=1):
+    """streams: list of equal-length frame byte arrays.  Returns (pcm list, ret array[n, frames])."""
+    n = len(streams)
+    frames = streams[0].size // fb
+    stride = (frames * fb + 15) & ~15
+    buf = np.zeros(n * stride, dtype=np.uint8)
+    for i, s in enumerate(streams):
+        buf[i * stride:i * stride + frames * fb] = s[:frames * fb]
+    d_fr, d_st = dec.alloc(buf.size), dec.alloc(n * efx.sbc_state_bytes())
+    d_fr.upload(buf)
+    d_st.upload(np.zeros(n * efx.sbc_state_bytes(), dtype=np.uint8))
+    pcm_stride = frames * 256
+    d_pcm, d_ret, d_cnt = dec.alloc(n * pcm_stride * 2), dec.alloc(n * frames * 4), dec.alloc(n * 4)
+    pcm = [np.zeros(0, np.int16) for _ in range(n)]
+    rets = np.zeros((n, frames), dtype=np.uint32)
+    per = (frames + chunks - 1) // chunks
+    for c in range(chunks):  # state carried across calls
+        f0, f1 = c * per, min(frames, (c + 1) * per)
+        if f1 <= f0:
+            continue
+        dec.sbc_decode(n, d_fr.ptr + f0 * fb, stride, fb, f1 - f0, d_st, d_pcm, pcm_stride, d_ret, d_cnt,
+                       probe_first=probe and c == 0)
+        dec.sync()
+        cnt = d_cnt.download(np.uint32, n)
+        allpcm = d_pcm.download(np.int16, n * pcm_stride).reshape(n, pcm_stride)
+        r = d_ret.download(np.uint32, n * (f1 - f0)).reshape(n, f1 - f0)
+        rets[:, f0:f1] = r
+        for i in range(n):
+            pcm[i] = np.concatenate([pcm[i], allpcm[i, :cnt[i]]])
+    for b in (d_fr, d_st, d_pcm, d_ret, d_cnt):
+        b.free()
+    return pcm, rets
+
+
+def unpack_ret(r):
+    v = int(r) & 0xFFFF
+    return (-1 if v == 0xFFFF else v, int(r) >> 16)
+
+
+@pytest.mark.parametrize("case", common.SBC_CASES, ids=[c[0] for c in common.SBC_CASES])
+def test_synthetic_frames(efx, golden, case):
+    name, kw, n, probe = case
+    fb = common.sbc_frame_bytes(kw["blocks"], 1 if kw["mode"] == 0 else 2, kw["bitpool"])
+    fr = common.sbc_frames(common.seed_of(name), n, **kw)
+    want, wret = oracle.sbc_decode(fr, fb, probe)
+    if probe:  # decode_audio() discards the probe's PCM; the harness keeps it
+        drop = wret[0][1] // 2
+        want_emitted, wret = want[drop:], wret[1:]
+    else:
+        want_emitted = want
+    dec = efx.Decoder(1, 1, 2)
+    pcm, rets = gpu_sbc(efx, dec, [fr], fb, probe)
+    assert [unpack_ret(r) for r in rets[0]] == wret
+    assert np.array_equal(pcm[0], want_emitted)
+    if not probe:
+        assert f"{common.fnv_bytes(pcm[0]):016x}" == golden["sbc"][name]
+    # the same stream in three calls: state (filter memory, stale samples, geometry) carries over
+    pcm3, _ = gpu_sbc(efx, dec, [fr], fb, probe, chunks=3)
+    assert np.array_equal(pcm3[0], want_emitted)
+    dec.close()
+
+
+@pytest.mark.parametrize("clip", ["splash", "vmedia"])
+def test_clip_audio(efx, golden, clips, clip):
+    es = oracle.ts_audio_es(clips[clip])
+    fb = common.CLIP_SBC_FRAME_BYTES[clip]
+    n = es.size // fb
+    want, wret = oracle.sbc_decode(es[:n * fb], fb, True)
+    assert f"{common.fnv_bytes(want):016x}" == golden["sbc"]["clip:" + clip]["pcm_fnv"]
+    dec = efx.Decoder(1, 1, 2)
+    pcm, rets = gpu_sbc(efx, dec, [es[:n * fb]], fb, True)
+    assert np.array_equal(pcm[0], want[128:])
+    assert all(unpack_ret(r) == (fb, 256) for r in rets[0])
+    dec.close()
+
+
+def test_rejected_frames(efx):
+    fr = common.sbc_frames(5, 14, freq=3, blocks=16, mode=0, alloc=0, bitpool=28).reshape(14, -1).copy()
+    fr[3, 0] = 0x9D   # bad sync: previous samples are synthesised again
+    fr[6, 1] |= 0x0C  # joint stereo: geometry changes to 2 channels, stale samples
+    fr[9, 1] &= 0xFE  # 4 subbands: returns -1 without synthesis ...
+    fr[10, 0] = 0     # ... and a bad sync right after still yields nothing
+    fr[12, 2] = 200   # bitpool the allocation loop cannot meet
+    want, wret = oracle.sbc_decode(fr.reshape(-1), fr.shape[1])
+    dec = efx.Decoder(1, 1, 2)
+    pcm, rets = gpu_sbc(efx, dec, [fr.reshape(-1)], fr.shape[1])
+    assert [unpack_ret(r) for r in rets[0]] == wret
+    assert [r[0] for r in wret][3] == -1 and wret[9] == (-1, 0) and wret[10] == (-1, 0)
+    assert np.array_equal(pcm[0], want)
+    dec.close()
+
+
+def test_batch_of_streams_and_pdm_chain(efx):
+    """256 streams with different content decode independently; the PCM then feeds k_pdm on the
+    device (config 4's audio half: SBC -> PCM -> PDM) and matches the oracle chain."""
+    S, frames = 256, 24
+    kw = dict(freq=3, blocks=16, mode=0, alloc=0, bitpool=28)
+    fb = common.sbc_frame_bytes(16, 1, 28)
+    streams = [common.sbc_frames(1000 + i, frames, **kw) for i in range(S)]
+    dec = efx.Decoder(S, 1, 2)
+    pcm, _ = gpu_sbc(efx, dec, streams, fb, True)
+    for i in (0, 1, 77, 255):
+        want, wret = oracle.sbc_decode(streams[i], fb, True)
+        assert np.array_equal(pcm[i], want[128:]), i
+    assert len({p.tobytes() for p in pcm}) == S
+    n = frames * 128
+    d_pcm, d_state, d_out = dec.alloc(S * n * 2), dec.alloc(S * 12), dec.alloc(S * n * 4)
+    d_pcm.upload(np.concatenate(pcm))
+    d_state.upload(np.zeros(S * 3, dtype=np.int32))
+    dec.pdm(S, d_pcm, n, d_state, d_out)
+    dec.sync()
+    words = d_out.download(np.uint16, S * n * 2).reshape(S, n * 2)
+    for i in (0, 200):
+        st = np.zeros(3, dtype=np.int32)
+        assert np.array_equal(words[i], oracle.pdm(st, pcm[i])), i
+    dec.close()

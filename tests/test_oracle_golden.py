@@ -128,3 +128,21 @@ def test_display_state_fields(golden):
             f = oracle.video_field_ex(disp, ntsc, 0, n, front, hs, ov, blend, progress)
             got = [f"{common.fnv_bytes(f[i]):016x}" for i in range(n)]
             assert got == golden["display"][f"{name}:{'ntsc' if ntsc else 'pal'}"], name
+
+
+def test_sbc_pcm_and_tables(golden, clips):
+    syn, pro = oracle.sbc_tables()
+    assert f"{common.fnv_bytes(syn):016x}" == golden["tables"]["sbc_syn_8"]
+    assert f"{common.fnv_bytes(pro):016x}" == golden["tables"]["sbc_proto_8"]
+    for name, kw, n, probe in common.SBC_CASES:
+        fr = common.sbc_frames(common.seed_of(name), n, **kw)
+        fb = common.sbc_frame_bytes(kw["blocks"], 1 if kw["mode"] == 0 else 2, kw["bitpool"])
+        pcm, _ = oracle.sbc_decode(fr, fb, probe)
+        assert f"{common.fnv_bytes(pcm):016x}" == golden["sbc"][name], name
+    for clip in ("splash", "vmedia"):
+        g = golden["sbc"]["clip:" + clip]
+        es = oracle.ts_audio_es(clips[clip])
+        fb = common.CLIP_SBC_FRAME_BYTES[clip]
+        assert es.size // fb == g["frames"] and f"{common.fnv_bytes(es):016x}" == g["audio_es_fnv"]
+        pcm, _ = oracle.sbc_decode(es[:es.size // fb * fb], fb, True)
+        assert f"{common.fnv_bytes(pcm):016x}" == g["pcm_fnv"]

@@ -87,3 +87,49 @@ def test_display_state_hscroll_and_overlay(case, ntsc):
                                     blend, progress)
     got = oracle.video_field_ex(fr, ntsc, 0, n, front, hs, ov, blend, progress)
     assert np.array_equal(ref, got)
+
+
+def test_sbc_tables():
+    syn, pro = oracle.sbc_tables()
+    rsyn, rpro = oracle.ref_sbc_tables()
+    assert np.array_equal(syn, rsyn) and np.array_equal(pro, rpro)
+
+
+@pytest.mark.parametrize("case", common.SBC_CASES, ids=[c[0] for c in common.SBC_CASES])
+def test_sbc_synthetic_frames(case):
+    name, kw, n, probe = case
+    fr = common.sbc_frames(common.seed_of(name), n, **kw)
+    ch = 1 if kw["mode"] == 0 else 2
+    fb = common.sbc_frame_bytes(kw["blocks"], ch, kw["bitpool"])
+    rpcm, rret = oracle.ref_sbc_decode(fr, fb, probe)
+    pcm, ret = oracle.sbc_decode(fr, fb, probe)
+    assert ret == rret and all(r[0] == fb for r in ret)
+    assert np.array_equal(pcm, rpcm)
+
+
+@pytest.mark.parametrize("clip", ["splash", "vmedia"])
+def test_sbc_clip_audio(clip, clips):
+    """The clips' own audio (PID 0x102), 128 samples per frame, decoded as decode_audio() does:
+    the first frame is probed for the frame size (64 bytes in splash, 48 in vmedia) and thereby
+    synthesised twice."""
+    es = oracle.ts_audio_es(clips[clip])
+    assert es.size >= 48 * 100 and es[0] == 0x9C
+    fb = oracle.sbc_decode(es[:64], 64)[1][0][0]
+    assert fb == common.CLIP_SBC_FRAME_BYTES[clip]
+    n = es.size // fb
+    rpcm, rret = oracle.ref_sbc_decode(es[:n * fb], fb, True)
+    pcm, ret = oracle.sbc_decode(es[:n * fb], fb, True)
+    assert ret == rret and all(r == (fb, 256) for r in ret)
+    assert np.array_equal(pcm, rpcm) and np.abs(pcm.astype(int)).max() > 1000
+
+
+def test_sbc_rejected_frames_resynthesise_state():
+    """Bad sync byte / joint stereo / 4 subbands: what sbc_decoder() does with the stale state."""
+    fr = common.sbc_frames(5, 12, freq=3, blocks=16, mode=0, alloc=0, bitpool=28).reshape(12, -1).copy()
+    fr[3, 0] = 0x9D                       # bad sync: previous samples are synthesised again
+    fr[6, 1] |= 0x0C                      # joint stereo: geometry changes to 2 channels, stale samples
+    fr[9, 1] &= 0xFE                      # 4 subbands: returns -1 without synthesis
+    rpcm, rret = oracle.ref_sbc_decode(fr.reshape(-1), fr.shape[1])
+    pcm, ret = oracle.sbc_decode(fr.reshape(-1), fr.shape[1])
+    assert ret == rret and np.array_equal(pcm, rpcm)
+    assert ret[3][0] == -1 and ret[6][0] == -1 and ret[9][0] == -1

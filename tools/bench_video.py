@@ -73,3 +73,27 @@ print(json.dumps({"kernel": "k_demux", "streams": S, "ts_bytes": t.ts_bytes, "es
                   "roofline": {"bound": "hbm", "achieved": alg / best / 1e6, "peak": 8000.0, "unit": "GB/s",
                                "frac": alg / best / 1e6 / 8000.0, "algorithmic_bytes_per_launch": alg}}))
 dec.close()
+
+# SBC audio decode: S streams x one second of 48 kHz mono audio (375 frames of 64 bytes)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import common
+frames, fb = 375, 64
+one = common.sbc_frames(1, frames, freq=3, blocks=16, mode=0, alloc=0, bitpool=28)
+dec = efx.Decoder(1, 1, 2)
+d_fr, d_st = dec.alloc(S * frames * fb), dec.alloc(S * efx.sbc_state_bytes())
+d_fr.upload(np.tile(one, S))
+d_st.upload(np.zeros(S * efx.sbc_state_bytes(), dtype=np.uint8))
+d_pcm = dec.alloc(S * frames * 128 * 2)
+dec.sbc_decode(S, d_fr, frames * fb, fb, frames, d_st, d_pcm, frames * 128)
+dec.sync()
+t0 = time.perf_counter()
+for i in range(5):
+    dec.sbc_decode(S, d_fr, frames * fb, fb, frames, d_st, d_pcm, frames * 128)
+dec.sync()
+dt = (time.perf_counter() - t0) / 5
+alg = S * frames * (fb + 256)
+print(json.dumps({"kernel": "k_sbc", "streams": S, "frames_per_stream": frames, "stream_seconds_per_s": S / dt,
+                  "ms_per_launch": dt * 1e3,
+                  "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / dt / 8e12,
+                               "note": "frames of a stream are serial (filter memory): one wave per stream"}}))
+dec.close()
