@@ -7,7 +7,7 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 CSRC     = espflix_amd/csrc
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
-OBJS     = $(CSRC)/efx_api.o $(CSRC)/k_demux.o $(CSRC)/k_index.o $(CSRC)/k_parse.o $(CSRC)/k_recon.o $(CSRC)/k_video.o $(CSRC)/k_sbc.o $(CSRC)/efx_tables.o
+OBJS     = $(CSRC)/efx_api.o $(CSRC)/k_demux.o $(CSRC)/k_index.o $(CSRC)/k_parse.o $(CSRC)/k_recon.o $(CSRC)/k_video.o $(CSRC)/k_sbc.o $(CSRC)/k_tsindex.o $(CSRC)/efx_tables.o
 
 .PHONY: all lib gen oracle ref clean prof
 all: lib gen oracle
@@ -26,7 +26,7 @@ espflix_amd/libefx.so: $(OBJS)
 # development aid: instrumented build (per-slice cycle counts from k_parse), never loaded by the product
 prof:
 	$(HIPCC) $(HIPFLAGS) -DEFX_PARSE_PROFILE $(EXP) -shared $(CSRC)/efx_api.hip $(CSRC)/k_demux.hip $(CSRC)/k_index.hip $(CSRC)/k_parse.hip \
-	    $(CSRC)/k_recon.hip $(CSRC)/k_video.hip $(CSRC)/k_sbc.hip -x hip $(CSRC)/efx_tables.cpp -o espflix_amd/libefx_prof.so
+	    $(CSRC)/k_recon.hip $(CSRC)/k_video.hip $(CSRC)/k_sbc.hip $(CSRC)/k_tsindex.hip -x hip $(CSRC)/efx_tables.cpp -o espflix_amd/libefx_prof.so
 
 espflix_amd/gen/libefx_gen.so: espflix_amd/gen/efx_gen.cpp $(CSRC)/mpeg1_codebook.h
 	g++ -std=c++17 -O2 -Wall -Wextra -fPIC -shared -pthread $< -o $@

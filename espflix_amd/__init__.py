@@ -66,6 +66,11 @@ class _FieldOpts(C.Structure):
                 ("overlay_stride", C.c_size_t), ("overlay_blend", C.c_int), ("overlay_progress", C.c_int)]
 
 
+class _IdxRec(C.Structure):
+    _fields_ = [("first_pts", C.c_int64), ("last_pts", C.c_int64), ("bin_size", C.c_uint32), ("trick_speed", C.c_uint32),
+                ("sample_count", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class _Timing(C.Structure):
     _fields_ = [("index_ms", C.c_float), ("parse_ms", C.c_float), ("recon_ms", C.c_float), ("total_ms", C.c_float),
                 ("pictures", C.c_uint64), ("slices", C.c_uint64), ("coefficients", C.c_uint64), ("es_bytes", C.c_uint64),
@@ -96,6 +101,10 @@ _SYMBOLS = {
     "efx_video_get_params": (C.c_int, [C.c_int, C.POINTER(_VideoParams)]),
     "efx_composite_fields": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "efx_composite_fields_ex": (C.c_int, [_P, C.POINTER(_FieldOpts), _P]),
+    "efx_index_streams": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t), _P, C.c_uint32, _P, _P, C.c_size_t]),
+    "efx_idx_build": (C.c_size_t, [_P, C.POINTER(_P), _P, C.c_size_t]),
+    "efx_idx_pts2offset": (C.c_uint32, [_P, C.c_int64, C.c_int]),
+    "efx_idx_pts2pts": (C.c_int64, [_P, C.c_int64, C.c_int]),
     "efx_sbc_state_bytes": (C.c_size_t, []),
     "efx_sbc_decode": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, _P, C.c_int]),
     "efx_pdm": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
@@ -132,6 +141,28 @@ def video_params(ntsc: bool) -> dict:
     p = _VideoParams()
     _check(None, load_library().efx_video_get_params(1 if ntsc else 0, C.byref(p)))
     return {n: getattr(p, n) for n, _ in _VideoParams._fields_}
+
+
+def idx_build(recs3, samples3) -> bytes:
+    """merge_index: video.idx bytes from three (rec dict, samples) results of Decoder.index_streams."""
+    lib = load_library()
+    recs = (_IdxRec * 3)(*[_IdxRec(**r) for r in recs3])
+    arrs = [np.ascontiguousarray(s, dtype=np.uint32) for s in samples3]
+    ptrs = (_P * 3)(*[a.ctypes.data for a in arrs])
+    n = lib.efx_idx_build(recs, ptrs, None, 0)
+    out = np.zeros(n, dtype=np.uint8)
+    assert lib.efx_idx_build(recs, ptrs, out.ctypes.data, n) == n
+    return out.tobytes()
+
+
+def idx_pts2offset(idx: bytes, pts: int, speed: int) -> int:
+    h = np.frombuffer(idx[:104], dtype=np.uint8).copy()
+    return int(load_library().efx_idx_pts2offset(h.ctypes.data, pts, speed))
+
+
+def idx_pts2pts(idx: bytes, pts: int, speed: int) -> int:
+    h = np.frombuffer(idx[:104], dtype=np.uint8).copy()
+    return int(load_library().efx_idx_pts2pts(h.ctypes.data, pts, speed))
 
 
 def sbc_state_bytes() -> int:
@@ -314,6 +345,21 @@ class Decoder:
         o = _FieldOpts(first_stream, n_streams, slot, slot if other_slot is None else other_slot, 1 if ntsc else 0,
                        frame_counter, hscroll, g(overlay), overlay_stride, overlay_blend, overlay_progress)
         _check(self._ctx, self._lib.efx_composite_fields_ex(self._ctx, C.byref(o), g(dst)))
+
+    def index_streams(self, streams, trick_speed=None, bin_size: int = 7500, samples_cap: int = 0):
+        """make_index + pts2seq for a batch of transport streams.  Returns [(rec dict, samples)]."""
+        arrs = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray, memoryview))
+                else np.ascontiguousarray(s, dtype=np.uint8) for s in streams]
+        n = len(arrs)
+        cap = samples_cap or max(16, max(a.size // 188 for a in arrs) + 2)
+        ptrs = (_P * n)(*[a.ctypes.data for a in arrs])
+        lens = (C.c_size_t * n)(*[a.size for a in arrs])
+        recs = (_IdxRec * n)()
+        samples = np.zeros((n, cap), dtype=np.uint32)
+        sp = None if trick_speed is None else (C.c_uint32 * n)(*trick_speed)
+        _check(self._ctx, self._lib.efx_index_streams(self._ctx, n, ptrs, lens, sp, bin_size, recs, samples.ctypes.data, cap))
+        return [({f: getattr(recs[i], f) for f, _ in _IdxRec._fields_}, samples[i, :recs[i].sample_count].copy())
+                for i in range(n)]
 
     def sbc_decode(self, n_streams: int, frames: DeviceBuffer | int, stream_stride: int, frame_bytes: int, n_frames: int,
                    state: DeviceBuffer | int, pcm: DeviceBuffer | int, pcm_stride: int, ret: DeviceBuffer | int | None = None,

@@ -5,6 +5,8 @@
 // EFX_ERR_NO_DEVICE / EFX_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -17,6 +19,8 @@ namespace efx {
 // kernels (k_demux.hip, k_index.hip, k_parse.hip, k_recon.hip, k_video.hip)
 __global__ void k_demux(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, uint8_t*, uint32_t*, PesEntry*,
                         uint32_t*);
+__global__ void k_ts_sequences(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, PesEntry*, IdxInfo*);
+__global__ void k_idx_bins(const PesEntry*, const uint32_t*, const IdxInfo*, uint32_t, uint32_t*, size_t);
 __global__ void k_index(const uint8_t*, const uint64_t*, int, PicInfo*, SliceTmp*, uint32_t*, uint32_t*, uint32_t*,
                         const uint32_t*, const PesEntry*, const uint32_t*, const uint32_t*, int64_t*);
 __global__ void k_slice_scan(const PicInfo*, const uint32_t*, int, int, uint32_t*, DecodeCounters*);
@@ -67,6 +71,13 @@ struct efx_ctx {
     uint32_t* d_pes_count = nullptr;
     PesEntry* d_pes = nullptr;
     size_t pes_cap = 0;
+    // efx_index_streams keeps its own lists: the ones above belong to the uploaded batch (k_index
+    // reads them at every efx_decode); only the transient TS staging buffer d_ts is shared
+    IdxInfo* d_idx_info = nullptr;
+    uint64_t* d_ts_off = nullptr;
+    uint32_t* d_idx_len = nullptr;
+    uint32_t* d_idx_base = nullptr;
+    PesEntry* d_idx_seq = nullptr;
     bool ts_input = false;
     hipEvent_t ev_demux[2] = {nullptr, nullptr};
     float demux_ms = 0.f;
@@ -258,7 +269,7 @@ void efx_destroy(efx_ctx* ctx)
         (void)hipStreamSynchronize(ctx->stream);
     void* bufs[] = {ctx->d_es,   ctx->d_stream_off, ctx->d_pics,  ctx->d_slices_tmp, ctx->d_qtab,     ctx->d_tables,
                     ctx->d_slice_base, ctx->d_descs, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_hash,
-                    ctx->d_ts, ctx->d_ts_len, ctx->d_pkt_base, ctx->d_es_len, ctx->d_pes_count, ctx->d_pes, ctx->d_sbc_tables};
+                    ctx->d_ts, ctx->d_ts_len, ctx->d_pkt_base, ctx->d_es_len, ctx->d_pes_count, ctx->d_pes, ctx->d_sbc_tables, ctx->d_idx_info, ctx->d_ts_off, ctx->d_idx_len, ctx->d_idx_base, ctx->d_idx_seq};
     for (auto& ev : ctx->ev_demux)
         if (ev)
             (void)hipEventDestroy(ev);
@@ -287,6 +298,36 @@ void efx_destroy(efx_ctx* ctx)
     delete ctx;
 }
 
+
+// transport-stream staging (first EFX_FORMAT_TS upload or first index call): the TS of stream i
+// occupies the same region of d_ts that its elementary stream will occupy in d_es (an ES is never
+// longer than its TS)
+static int ensure_ts_buffers(efx_ctx* ctx)
+{
+    if (ctx->d_ts)
+        return EFX_OK;
+    const size_t n_max = (size_t)ctx->cfg.max_streams;
+    ctx->pes_cap = ctx->es_cap / 188 + n_max;
+    hipError_t e = dalloc(&ctx->d_ts, ctx->es_cap);
+    if (e == hipSuccess) e = dalloc(&ctx->d_ts_len, n_max);
+    if (e == hipSuccess) e = dalloc(&ctx->d_pkt_base, n_max);
+    if (e == hipSuccess) e = dalloc(&ctx->d_es_len, n_max);
+    if (e == hipSuccess) e = dalloc(&ctx->d_pes_count, n_max);
+    if (e == hipSuccess) e = dalloc(&ctx->d_pes, ctx->pes_cap);
+    if (e == hipSuccess) e = dalloc(&ctx->d_idx_info, n_max);
+    if (e == hipSuccess) e = dalloc(&ctx->d_ts_off, n_max + 1);
+    if (e == hipSuccess) e = dalloc(&ctx->d_idx_len, n_max);
+    if (e == hipSuccess) e = dalloc(&ctx->d_idx_base, n_max);
+    if (e == hipSuccess) e = dalloc(&ctx->d_idx_seq, ctx->pes_cap);
+    for (auto& sl : ctx->slot)
+        if (e == hipSuccess) e = dalloc(&sl.d_pts, n_max * (size_t)ctx->cfg.max_pictures);
+    for (auto& ev : ctx->ev_demux)
+        if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e != hipSuccess)
+        return fail(ctx, EFX_ERR_DEVICE, "transport-stream buffers", e);
+    return EFX_OK;
+}
+
 int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, const size_t* len, int format)
 {
     if (!ctx || !data || !len || n_streams <= 0 || (format != EFX_FORMAT_ES && format != EFX_FORMAT_TS))
@@ -296,23 +337,10 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
     EFX_HIP(hipStreamSynchronize(ctx->parse_stream));  // the bitstream buffer may still be in use
     EFX_HIP(hipStreamSynchronize(ctx->stream));
     const bool is_ts = format == EFX_FORMAT_TS;
-    const size_t n_max = (size_t)ctx->cfg.max_streams;
-    if (is_ts && !ctx->d_ts) {
-        // transport-stream staging: the TS of stream i occupies the same region of d_ts that its
-        // elementary stream will occupy in d_es (an ES is never longer than its TS)
-        ctx->pes_cap = ctx->es_cap / 188 + n_max;
-        hipError_t e = dalloc(&ctx->d_ts, ctx->es_cap);
-        if (e == hipSuccess) e = dalloc(&ctx->d_ts_len, n_max);
-        if (e == hipSuccess) e = dalloc(&ctx->d_pkt_base, n_max);
-        if (e == hipSuccess) e = dalloc(&ctx->d_es_len, n_max);
-        if (e == hipSuccess) e = dalloc(&ctx->d_pes_count, n_max);
-        if (e == hipSuccess) e = dalloc(&ctx->d_pes, ctx->pes_cap);
-        for (auto& sl : ctx->slot)
-            if (e == hipSuccess) e = dalloc(&sl.d_pts, n_max * (size_t)ctx->cfg.max_pictures);
-        for (auto& ev : ctx->ev_demux)
-            if (e == hipSuccess) e = hipEventCreate(&ev);
-        if (e != hipSuccess)
-            return fail(ctx, EFX_ERR_DEVICE, "efx_upload_streams: transport-stream buffers", e);
+    if (is_ts) {
+        int r = ensure_ts_buffers(ctx);
+        if (r)
+            return r;
     }
     static const uint8_t tail[kEsTailBytes] = {0, 0, 0, 1, 0xB7, 0, 0, 1, 0xB7};
     ctx->h_stream_off.assign((size_t)n_streams + 1, 0);
@@ -668,6 +696,159 @@ int efx_pdm(efx_ctx* ctx, int n_streams, const int16_t* pcm_device, int n_sample
                        state_device, dst_device);
     EFX_HIP(hipGetLastError());
     return EFX_OK;
+}
+
+
+// ---- trick-play index (indexer/indexer.cpp, espflix.cpp:573-629) -------------------------------------
+
+int efx_index_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, const size_t* len, const uint32_t* trick_speed,
+                      uint32_t bin_size, efx_idx_rec* recs, uint32_t* samples, size_t samples_cap)
+{
+    if (!ctx || !ts || !len || !recs || !samples || n_streams <= 0 || bin_size == 0 || samples_cap == 0)
+        return fail(ctx, EFX_ERR_ARG, "efx_index_streams: bad argument");
+    if (n_streams > ctx->cfg.max_streams)
+        return fail(ctx, EFX_ERR_CAPACITY, "efx_index_streams: more streams than max_streams");
+    int r = ensure_ts_buffers(ctx);
+    if (r)
+        return r;
+    // the TS staging buffers are shared with efx_upload_streams, which only uses them during the call
+    EFX_HIP(hipStreamSynchronize(ctx->parse_stream));
+    EFX_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> off((size_t)n_streams + 1);
+    std::vector<uint32_t> tlen(n_streams), base(n_streams);
+    size_t pos = 0, packets = 0;
+    for (int i = 0; i < n_streams; i++) {
+        if (!ts[i] && len[i])
+            return fail(ctx, EFX_ERR_ARG, "efx_index_streams: null stream");
+        const size_t padded = (len[i] + 15) & ~(size_t)15;
+        if (pos + padded + kEsGuardBytes > ctx->es_cap)
+            return fail(ctx, EFX_ERR_CAPACITY, "efx_index_streams: more bytes than max_stream_bytes");
+        off[i] = pos;
+        if (len[i])
+            memcpy(ctx->h_es + pos, ts[i], len[i]);
+        memset(ctx->h_es + pos + len[i], 0, padded - len[i]);
+        tlen[i] = (uint32_t)len[i];
+        base[i] = (uint32_t)packets;
+        packets += len[i] / 188;
+        pos += padded;
+    }
+    off[n_streams] = pos;
+    hipStream_t st = ctx->stream;
+    uint32_t* d_samples = nullptr;
+    EFX_HIP(dalloc(&d_samples, (size_t)n_streams * samples_cap));
+    auto done = [&](int code) {
+        (void)hipFree(d_samples);
+        return code;
+    };
+    hipError_t e = hipMemcpyAsync(ctx->d_ts, ctx->h_es, pos, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_ts_off, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_idx_len, tlen.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_idx_base, base.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_samples, 0, (size_t)n_streams * samples_cap * sizeof(uint32_t), st);
+    if (e != hipSuccess)
+        return done(fail(ctx, EFX_ERR_DEVICE, "efx_index_streams: upload", e));
+    hipLaunchKernelGGL(k_ts_sequences, dim3(n_streams), dim3(256), 0, st, ctx->d_ts, ctx->d_ts_off, ctx->d_idx_len, ctx->d_idx_base,
+                       ctx->d_idx_seq, ctx->d_idx_info);
+    hipLaunchKernelGGL(k_idx_bins, dim3((unsigned)((samples_cap + 255) / 256), n_streams), dim3(256), 0, st, ctx->d_idx_seq,
+                       ctx->d_idx_base, ctx->d_idx_info, bin_size, d_samples, samples_cap);
+    std::vector<IdxInfo> info(n_streams);
+    e = hipMemcpyAsync(info.data(), ctx->d_idx_info, n_streams * sizeof(IdxInfo), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(samples, d_samples, (size_t)n_streams * samples_cap * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess)
+        return done(fail(ctx, EFX_ERR_DEVICE, "efx_index_streams: kernels", e));
+    int status = EFX_OK;
+    for (int i = 0; i < n_streams; i++) {
+        efx_idx_rec& rec = recs[i];
+        memset(&rec, 0, sizeof(rec));
+        rec.first_pts = info[i].first_pts;
+        rec.last_pts = info[i].last_pts;
+        rec.bin_size = bin_size;
+        rec.trick_speed = trick_speed ? trick_speed[i] : 1;
+        const int64_t end = rec.last_pts - rec.first_pts;
+        if (!info[i].n_seq || end < 0)
+            continue;  // no sequence header: sample_count 0 (the indexer would index out of an empty list)
+        const uint64_t count = (uint64_t)(end / bin_size) + 1;
+        if (count > samples_cap) {
+            status = fail(ctx, EFX_ERR_CAPACITY, "efx_index_streams: samples_cap too small");
+            continue;
+        }
+        rec.sample_count = (uint32_t)count;
+    }
+    return done(status);
+}
+
+size_t efx_idx_build(const efx_idx_rec recs[3], const uint32_t* const samples[3], uint8_t* out, size_t cap)
+{
+    if (!recs || !samples)
+        return 0;
+    size_t total = 8 + 3 * sizeof(efx_idx_rec);
+    for (int k = 0; k < 3; k++)
+        total += 4 * (size_t)recs[k].sample_count;
+    if (!out || total > cap)
+        return total;
+    const uint32_t sig = 'I' | ('D' << 8) | ('X' << 16), three = 3;  // merge_index, indexer.cpp:225-227
+    memcpy(out, &sig, 4);
+    memcpy(out + 4, &three, 4);
+    uint8_t* p = out + 8;
+    for (int k = 0; k < 3; k++) {
+        efx_idx_rec r = recs[k];
+        r.reserved = 0;
+        memcpy(p, &r, sizeof(r));
+        p += sizeof(r);
+    }
+    for (int k = 0; k < 3; k++) {
+        memcpy(p, samples[k], 4 * (size_t)recs[k].sample_count);
+        p += 4 * (size_t)recs[k].sample_count;
+    }
+    return total;
+}
+
+static void idx_recs(const void* hdr, efx_idx_rec r[3]) { memcpy(r, static_cast<const uint8_t*>(hdr) + 8, 3 * sizeof(efx_idx_rec)); }
+
+static int64_t idx_map_pts(int64_t pts, const efx_idx_rec& r, const efx_idx_rec& video)  // espflix.cpp:589-594
+{
+    pts -= r.first_pts;
+    pts *= video.last_pts - video.first_pts;
+    const int64_t d = r.last_pts - r.first_pts;
+    return d ? pts / d : 0;  // a one-picture trick stream would divide by zero in the reference
+}
+
+int64_t efx_idx_pts2pts(const void* idx_hdr, int64_t pts, int speed)  // espflix.cpp:597-604
+{
+    efx_idx_rec r[3];
+    idx_recs(idx_hdr, r);
+    if (speed == 1)
+        return r[0].first_pts + idx_map_pts(pts, r[1], r[0]);
+    if (speed == -1)
+        return r[0].last_pts - idx_map_pts(pts, r[2], r[0]);
+    return pts;
+}
+
+uint32_t efx_idx_pts2offset(const void* idx_hdr, int64_t pts, int speed)  // espflix.cpp:607-627
+{
+    efx_idx_rec r[3];
+    idx_recs(idx_hdr, r);
+    const efx_idx_rec &video = r[0], &fwd = r[1], &rwd = r[2];
+    pts = std::max(std::min(pts, video.last_pts), video.first_pts);
+    uint32_t offset;
+    switch (speed) {
+    case 1:
+        offset = (uint32_t)(pts - video.first_pts) / fwd.trick_speed / fwd.bin_size;
+        offset = std::min(fwd.sample_count - 1, offset);
+        offset += video.sample_count;
+        break;
+    case -1:
+        offset = (uint32_t)((video.last_pts - pts) - video.first_pts) / rwd.trick_speed / rwd.bin_size;
+        offset = std::min(rwd.sample_count - 1, offset);
+        offset += video.sample_count + fwd.sample_count;
+        break;
+    default:
+        offset = (uint32_t)((pts - video.first_pts) / video.bin_size);
+        offset = std::min(video.sample_count - 1, offset);
+        break;
+    }
+    return offset * 4 + (uint32_t)(8 + 3 * sizeof(efx_idx_rec));
 }
 
 size_t efx_sbc_state_bytes(void) { return sizeof(SbcState); }

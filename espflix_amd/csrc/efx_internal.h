@@ -98,6 +98,13 @@ struct VideoTables {
     uint32_t color_tab[768];
 };
 
+// per-stream result of k_ts_sequences
+struct IdxInfo {
+    int64_t first_pts, last_pts;  // origin (PTS of the first sequence start), PTS of the last video PES
+    uint32_t n_seq;
+    uint32_t fast;                // list sorted and short enough for the binary search
+};
+
 // k_composite launch arguments (by value)
 struct FieldArgs {
     int first_stream, ring_depth;

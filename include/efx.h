@@ -171,6 +171,32 @@ int efx_composite_fields_ex(efx_ctx* ctx, const efx_field_opts* opts, uint16_t* 
 int efx_pdm(efx_ctx* ctx, int n_streams, const int16_t* pcm_device, int n_samples, int32_t* state_device,
             uint16_t* dst_device);
 
+/* -- trick-play index (indexer/indexer.cpp; ESPFlix::idx_hdr, src/espflix.cpp:573-629) -------- */
+/* idx_rec as the indexer writes it (indexer/indexer.cpp:22-28): 28 bytes of fields + 4 of padding */
+typedef struct efx_idx_rec {
+    int64_t first_pts, last_pts;
+    uint32_t bin_size, trick_speed, sample_count;
+    uint32_t reserved;
+} efx_idx_rec;
+/* make_index(src) + pts2seq (indexer/indexer.cpp:86-217) for a batch of transport streams, on the
+ * device: every video PES that starts a sequence header contributes (PTS, packet number); each
+ * bin of bin_size ticks between the first such PTS and the last video PTS gets the packet number
+ * of the nearest one.  recs[i] describes stream i (trick_speed[i] is recorded, 1 if the array is
+ * NULL); its samples are written to samples + i * samples_cap.  A stream without a sequence header
+ * gets sample_count 0.  Host pointers; synchronous. */
+int efx_index_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, const size_t* len, const uint32_t* trick_speed,
+                      uint32_t bin_size, efx_idx_rec* recs, uint32_t* samples, size_t samples_cap);
+/* merge_index (indexer/indexer.cpp:219-237): the bytes of video.idx -- 'IDX', 3, the main /
+ * fast-forward / rewind records, then their samples.  Returns the size needed; writes only if it
+ * fits in cap. */
+size_t efx_idx_build(const efx_idx_rec recs[3], const uint32_t* const samples[3], uint8_t* out, size_t cap);
+/* idx_hdr::pts2offset and idx_hdr::pts2pts (src/espflix.cpp:597-627) on the 104-byte header of a
+ * video.idx: byte offset of the sample to read (get_index, src/espflix.cpp:823-829) for a
+ * main-timeline PTS at speed 0 / 1 / -1, and trick-stream PTS -> main-timeline PTS.  The sample,
+ * times 188, is the byte offset at which to start efx_upload_streams(EFX_FORMAT_TS). */
+uint32_t efx_idx_pts2offset(const void* idx_hdr, int64_t pts, int speed);
+int64_t efx_idx_pts2pts(const void* idx_hdr, int64_t pts, int speed);
+
 /* -- SBC audio decode (sbc_decoder, src/sbc_decoder.cpp:346-378; decode_audio, src/video.cpp:962-989) -- */
 /* Bytes of decoder state per stream (the reference's SBC_Decode, src/sbc_decoder.h:12-25).  All
  * zero is sbc_init(). */

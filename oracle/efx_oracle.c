@@ -1619,3 +1619,174 @@ size_t efxo_ts_audio_es(const uint8_t* ts, size_t len, uint8_t* out, size_t cap)
     }
     return n;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* trick-play index (indexer/indexer.cpp, espflix.cpp:573-629)                          */
+
+long efxo_ts_sequences(const uint8_t* ts, size_t len, int64_t* first_pts, int64_t* last_pts, int64_t* seq_pts,
+                       uint32_t* seq_pos, long cap) /* indexer.cpp:86-176 */
+{
+    int64_t origin = -1, video_pts = -1;
+    long n = 0;
+    uint32_t packet = 0;
+    for (size_t pos = 0; pos + 188 <= len; pos += 188, packet++) {
+        const uint8_t* d = ts + pos;
+        int pid = ((d[1] << 8) + d[2]) & 0x1fff;
+        const uint8_t* data = d + 4;
+        if (d[3] & 0x20)
+            data = d + 5 + d[4];
+        if (!(d[3] & 0x10) || !(d[1] & 0x40))
+            continue;
+        /* parse(), indexer.cpp:54-74: pts = 0 without a PTS flag, -1 on a marker mismatch; the
+         * "marker" is the fourth payload byte (the start code value).  The indexer reads these
+         * bytes wherever they fall; a header that leaves the packet is skipped here. */
+        const uint8_t* end = d + 188;
+        if (data + 9 > end)
+            continue;
+        const uint8_t* q = data + 6;
+        int flags = (q[0] << 8) | q[1];
+        const uint8_t* payload = q + 3 + q[2];
+        q += 3;
+        int64_t pts = 0;
+        if (flags & 0x0080)
+            pts = q + 5 <= end ? parse_pts(q, flags) : -1;
+        int m = payload + 3 < end ? payload[3] : -1;
+        if (pid != 0x100)
+            continue;
+        if (m == 0xB3) {
+            if (origin == -1)
+                origin = pts;
+            if (n < cap) {
+                seq_pts[n] = pts;
+                seq_pos[n] = packet;
+            }
+            n++;
+        }
+        video_pts = pts;
+    }
+    *first_pts = origin;
+    *last_pts = video_pts;
+    return n;
+}
+
+static uint32_t idx_pts2pos(int64_t pts, const int64_t* seq_pts, const uint32_t* seq_pos, long n) /* indexer.cpp:182-195 */
+{
+    long mini = 0;
+    int mine = 0x7FFFFFF;
+    for (long i = 0; i < n; i++) {
+        int64_t dd = seq_pts[i] - pts;
+        int e = (int)(uint32_t)(uint64_t)(dd < 0 ? -dd : dd); /* (int)abs(...) of an int64 */
+        if (e < mine) {
+            mine = e;
+            mini = i;
+        }
+    }
+    return seq_pos[mini];
+}
+
+size_t efxo_make_idx(const uint8_t* const ts[3], const size_t len[3], uint8_t* out, size_t cap) /* indexer.cpp:197-237 */
+{
+    efxo_idx_rec rec[3];
+    uint32_t* samples[3] = {0, 0, 0};
+    const uint32_t speed[3] = {1, 15, 15};
+    size_t total = 8 + 3 * 32;
+    int bad = 0;
+    for (int k = 0; k < 3; k++) {
+        long cap_seq = (long)(len[k] / 188) + 1;
+        int64_t* sp = (int64_t*)malloc(sizeof(int64_t) * (size_t)cap_seq);
+        uint32_t* so = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)cap_seq);
+        int64_t first, last;
+        long n = efxo_ts_sequences(ts[k], len[k], &first, &last, sp, so, cap_seq);
+        memset(&rec[k], 0, sizeof(rec[k]));
+        if (n <= 0)
+            bad = 1;
+        else {
+            const uint32_t bin = 90000 / 12;
+            int64_t end = last - first;
+            size_t count = end < 0 ? 0 : (size_t)(end / bin) + 1;
+            samples[k] = (uint32_t*)malloc(4 * (count ? count : 1));
+            size_t c = 0;
+            for (int64_t pts = 0; pts <= end; pts += bin) /* pts2seq, indexer.cpp:197-217 */
+                samples[k][c++] = idx_pts2pos(pts + first, sp, so, n);
+            rec[k].first_pts = first;
+            rec[k].last_pts = last;
+            rec[k].sample_count = (uint32_t)c;
+            rec[k].bin_size = bin;
+            rec[k].trick_speed = speed[k];
+            total += 4 * c;
+        }
+        free(sp);
+        free(so);
+    }
+    if (!bad && total <= cap) {
+        uint32_t sig = 'I' | ('D' << 8) | ('X' << 16), three = 3;
+        uint8_t* p = out;
+        memcpy(p, &sig, 4);
+        memcpy(p + 4, &three, 4);
+        p += 8;
+        for (int k = 0; k < 3; k++) {
+            /* idx_rec as the compiler lays it out: 28 bytes of fields + 4 of tail padding, which
+             * fwrite() of the struct writes out as whatever the stack held -- compared masked */
+            memcpy(p, &rec[k], 32);
+            p += 32;
+        }
+        for (int k = 0; k < 3; k++) {
+            memcpy(p, samples[k], 4 * (size_t)rec[k].sample_count);
+            p += 4 * (size_t)rec[k].sample_count;
+        }
+    }
+    for (int k = 0; k < 3; k++)
+        free(samples[k]);
+    return bad ? 0 : total;
+}
+
+static void idx_load(const uint8_t* hdr, efxo_idx_rec r[3])
+{
+    memcpy(r, hdr + 8, 96);
+}
+
+static int64_t idx_map_pts(int64_t pts, const efxo_idx_rec* r, const efxo_idx_rec* video) /* espflix.cpp:589-594 */
+{
+    pts -= r->first_pts;
+    pts *= video->last_pts - video->first_pts;
+    return pts / (r->last_pts - r->first_pts);
+}
+
+int64_t efxo_idx_pts2pts(const uint8_t* hdr, int64_t pts, int speed) /* espflix.cpp:597-604 */
+{
+    efxo_idx_rec r[3];
+    idx_load(hdr, r);
+    if (speed == 1)
+        return r[0].first_pts + idx_map_pts(pts, &r[1], &r[0]);
+    if (speed == -1)
+        return r[0].last_pts - idx_map_pts(pts, &r[2], &r[0]);
+    return pts;
+}
+
+uint32_t efxo_idx_pts2offset(const uint8_t* hdr, int64_t pts, int speed) /* espflix.cpp:607-627 */
+{
+    efxo_idx_rec r[3];
+    idx_load(hdr, r);
+    const efxo_idx_rec *video = &r[0], *fwd = &r[1], *rwd = &r[2];
+    uint32_t offset;
+    if (pts > video->last_pts)
+        pts = video->last_pts;
+    if (pts < video->first_pts)
+        pts = video->first_pts;
+    if (speed == 1) {
+        offset = (uint32_t)(pts - video->first_pts) / fwd->trick_speed / fwd->bin_size;
+        if (fwd->sample_count - 1 < offset)
+            offset = fwd->sample_count - 1;
+        offset += video->sample_count;
+    } else if (speed == -1) {
+        offset = (uint32_t)((video->last_pts - pts) - video->first_pts) / rwd->trick_speed / rwd->bin_size;
+        if (rwd->sample_count - 1 < offset)
+            offset = rwd->sample_count - 1;
+        offset += video->sample_count + fwd->sample_count;
+    } else {
+        offset = (uint32_t)((pts - video->first_pts) / video->bin_size);
+        if (video->sample_count - 1 < offset)
+            offset = video->sample_count - 1;
+    }
+    return offset * 4 + 104;
+}

@@ -90,6 +90,27 @@ int efxo_sbc_decode(efxo_sbc* s, const uint8_t* src, int src_len, int16_t* dst, 
  * latest audio PES header carried a PTS.  Returns the byte count (may exceed cap). */
 size_t efxo_ts_audio_es(const uint8_t* ts, size_t len, uint8_t* out, size_t cap);
 
+/* Trick-play index: restatement of the indexer (indexer/indexer.cpp:22-36,86-237) and of the
+ * player's idx_hdr arithmetic (src/espflix.cpp:573-629).  video.idx = idx_hdr (104 bytes: sig
+ * 'IDX', len 3, three idx_rec of 32 bytes) followed by the uint32 samples of the main, fast-forward
+ * and rewind streams; a sample is the 188-byte packet number of the PES that starts the sequence
+ * header nearest (in PTS) to its bin. */
+typedef struct efxo_idx_rec {
+    int64_t first_pts, last_pts;
+    uint32_t bin_size, trick_speed, sample_count;
+    uint32_t pad;
+} efxo_idx_rec;
+/* make_index(src, idxs), indexer.cpp:86-176: sequence-start (pts, packet) pairs of one transport
+ * stream; returns their number (may exceed cap), first_pts = origin, last_pts = last video PES pts */
+long efxo_ts_sequences(const uint8_t* ts, size_t len, int64_t* first_pts, int64_t* last_pts, int64_t* seq_pts,
+                       uint32_t* seq_pos, long cap);
+/* make_index(path) + merge_index, indexer.cpp:180-237,301-308: the bytes of video.idx for the
+ * three streams (main, fwd, rwd); returns the size (may exceed cap), 0 if a stream has no sequence */
+size_t efxo_make_idx(const uint8_t* const ts[3], const size_t len[3], uint8_t* out, size_t cap);
+/* idx_hdr::pts2offset / pts2pts, espflix.cpp:589-627 (hdr = the first 104 bytes of video.idx) */
+uint32_t efxo_idx_pts2offset(const uint8_t* hdr, int64_t pts, int speed);
+int64_t efxo_idx_pts2pts(const uint8_t* hdr, int64_t pts, int speed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -195,3 +195,27 @@ def seed_of(name: str) -> int:
 
 
 CLIP_SBC_FRAME_BYTES = {"splash": 64, "vmedia": 48}
+
+
+def index_titles():
+    """(name, [main, fwd, rwd] transport streams) for the trick-play index tests: synthetic titles
+    with a sequence header per GOP (GOP 12 main, GOP 3 trick streams as the indexer's ffmpeg
+    recipe makes them, indexer.cpp:292-295)."""
+    from espflix_amd import gen
+    out = []
+    for t in range(2):
+        main = gen.Batch(300 + t, 1, 96 + 24 * t, 12, 0).ts(0)
+        fwd = gen.Batch(310 + t, 1, 24, 3, 0).ts(0)
+        rwd = gen.Batch(320 + t, 1, 21, 3, 0).ts(0)
+        out.append((f"title{t}", [main, fwd, rwd]))
+    return out
+
+
+def index_queries(hdr_first: int, hdr_last: int):
+    """(pts, speed) probes around and beyond the indexed range."""
+    q = []
+    for speed in (0, 1, -1):
+        for pts in [hdr_first - 5000, hdr_first, hdr_first + 1, hdr_first + 7499, hdr_first + 7500, (hdr_first + hdr_last) // 2,
+                    hdr_last - 1, hdr_last, hdr_last + 90000, 0, 1 << 33]:
+            q.append((int(pts), speed))
+    return q

@@ -10,6 +10,7 @@ Everything in golden.json is an output of the reference itself:
              flush_picture(1)
   synthetic  the same for generator streams (TS-wrapped) of several flavours
   display    FNV of video_isr() fields with _hscroll slides and the composite() overlay / progress bar
+  index      FNV of the indexer's video.idx for synthetic titles and the clips
   sbc        FNV of sbc_decoder() PCM for synthetic frame configurations and the clips' PID 0x102 audio
   composite  FNV of video_isr() fields (NTSC and PAL, 3 fields) for LCG / random / decoded frames
   pdm        FNV of write_pcm_16() output incl. silence and beep calls
@@ -31,7 +32,7 @@ import oracle
 from espflix_amd import gen
 
 assert oracle.have_ref(), "build oracle/_ref first (make ref)"
-out = {"clips": {}, "synthetic": {}, "composite": {}, "display": {}, "pdm": {}, "sbc": {}, "tables": {}}
+out = {"clips": {}, "synthetic": {}, "composite": {}, "display": {}, "pdm": {}, "sbc": {}, "index": {}, "tables": {}}
 
 for clip in ("splash", "vmedia"):
     subprocess.run([os.path.join(oracle.REF_DIR, "efx_ref_decode"), "fixture", "@" + clip,
@@ -68,6 +69,11 @@ for name, front, hs, ov_seed, blend, progress in common.DISPLAY_CASES:
 pcm = common.pdm_pcm(0, 40)
 out["pdm"]["sine220_silence7_beep3"] = f"{common.fnv_bytes(oracle.ref_pdm(pcm, silence_every=7, beep_at=3)):016x}"
 out["pdm"]["sine220"] = f"{common.fnv_bytes(oracle.ref_pdm(pcm)):016x}"
+
+# trick-play index: video.idx as the reference indexer writes it (struct padding masked)
+clip_ts = {c: np.fromfile(os.path.join(HERE, c + ".ts"), dtype=np.uint8) for c in ("splash", "vmedia")}
+for name, streams in common.index_titles() + [("clips", [clip_ts["vmedia"], clip_ts["splash"], clip_ts["vmedia"]])]:
+    out["index"][name] = f"{oracle.fnv1a64(oracle.idx_masked(oracle.ref_make_idx(streams))):016x}"
 
 # SBC audio: PCM of the reference's sbc_decoder() on synthetic frames and on the clips' own audio
 for name, kw, n, probe in common.SBC_CASES:

@@ -278,3 +278,70 @@ def ref_sbc_tables():
         subprocess.run([os.path.join(REF_DIR, "efx_ref_sbc"), "tables", out], check=True)
         t = np.fromfile(out, dtype=np.int32)
         return t[:128], t[128:208]
+
+
+# ---- trick-play index --------------------------------------------------------------------------
+IDX_HDR_BYTES = 104
+IDX_PAD = [slice(36, 40), slice(68, 72), slice(100, 104)]   # tail padding of the three idx_rec
+
+
+def idx_masked(b) -> np.ndarray:
+    a = np.frombuffer(bytes(b), dtype=np.uint8).copy()
+    for s in IDX_PAD:
+        a[s] = 0
+    return a
+
+
+def make_idx(streams3) -> bytes:
+    """video.idx bytes for (main, fwd, rwd) transport streams via the restatement."""
+    L = lib()
+    arrs = [np.ascontiguousarray(s, dtype=np.uint8) for s in streams3]
+    ptrs = (C.c_void_p * 3)(*[a.ctypes.data for a in arrs])
+    lens = (C.c_size_t * 3)(*[a.size for a in arrs])
+    L.efxo_make_idx.restype = C.c_size_t
+    L.efxo_make_idx.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    cap = L.efxo_make_idx(ptrs, lens, None, 0)   # size query
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = L.efxo_make_idx(ptrs, lens, out.ctypes.data, out.size)
+    assert n == cap
+    return out[:n].tobytes()
+
+
+def ts_sequences(ts):
+    ts = np.ascontiguousarray(ts, dtype=np.uint8)
+    cap = ts.size // 188 + 1
+    sp, so = np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.uint32)
+    first, last = C.c_int64(0), C.c_int64(0)
+    L = lib()
+    L.efxo_ts_sequences.restype = C.c_long
+    L.efxo_ts_sequences.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+    n = L.efxo_ts_sequences(ts.ctypes.data, ts.size, C.byref(first), C.byref(last), sp.ctypes.data, so.ctypes.data, cap)
+    return first.value, last.value, sp[:n].copy(), so[:n].copy()
+
+
+def idx_query(hdr: bytes, pts: int, speed: int):
+    L = lib()
+    L.efxo_idx_pts2offset.restype = C.c_uint32
+    L.efxo_idx_pts2offset.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+    L.efxo_idx_pts2pts.restype = C.c_int64
+    L.efxo_idx_pts2pts.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+    h = np.frombuffer(hdr[:IDX_HDR_BYTES], dtype=np.uint8).copy()
+    return int(L.efxo_idx_pts2offset(h.ctypes.data, pts, speed)), int(L.efxo_idx_pts2pts(h.ctypes.data, pts, speed))
+
+
+def ref_make_idx(streams3) -> bytes:
+    with tempfile.TemporaryDirectory() as td:
+        for name, s in zip(("video.ts", "video_fwd.ts", "video_rwd.ts"), streams3):
+            np.ascontiguousarray(s, dtype=np.uint8).tofile(os.path.join(td, name))
+        subprocess.run([os.path.join(REF_DIR, "efx_ref_index"), td], check=True, timeout=120)
+        return open(os.path.join(td, "video.idx"), "rb").read()
+
+
+def ref_idx_query(idx: bytes, queries):
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "video.idx")
+        open(path, "wb").write(idx)
+        text = "".join(f"{p} {s}\n" for p, s in queries)
+        r = subprocess.run([os.path.join(REF_DIR, "efx_ref_idx"), path], input=text, capture_output=True, text=True,
+                           check=True, timeout=120)
+        return [tuple(int(x) for x in l.split()) for l in r.stdout.splitlines()]

@@ -146,3 +146,9 @@ def test_sbc_pcm_and_tables(golden, clips):
         assert es.size // fb == g["frames"] and f"{common.fnv_bytes(es):016x}" == g["audio_es_fnv"]
         pcm, _ = oracle.sbc_decode(es[:es.size // fb * fb], fb, True)
         assert f"{common.fnv_bytes(pcm):016x}" == g["pcm_fnv"]
+
+
+def test_trick_play_index(golden, clips):
+    for name, streams in common.index_titles() + [("clips", [clips["vmedia"], clips["splash"], clips["vmedia"]])]:
+        idx = oracle.make_idx(streams)
+        assert f"{oracle.fnv1a64(oracle.idx_masked(idx)):016x}" == golden["index"][name], name

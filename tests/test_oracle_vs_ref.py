@@ -133,3 +133,18 @@ def test_sbc_rejected_frames_resynthesise_state():
     pcm, ret = oracle.sbc_decode(fr.reshape(-1), fr.shape[1])
     assert ret == rret and np.array_equal(pcm, rpcm)
     assert ret[3][0] == -1 and ret[6][0] == -1 and ret[9][0] == -1
+
+
+def test_trick_play_index_file(clips):
+    """video.idx as the reference indexer writes it (indexer.cpp make_index + merge_index) and the
+    player's own idx_hdr arithmetic (espflix.cpp:589-627) on it."""
+    titles = common.index_titles() + [("clips", [clips["vmedia"], clips["splash"], clips["vmedia"]])]
+    for name, streams in titles:
+        ref = oracle.ref_make_idx(streams)
+        got = oracle.make_idx(streams)
+        assert len(got) == len(ref) > oracle.IDX_HDR_BYTES, name
+        assert np.array_equal(oracle.idx_masked(got), oracle.idx_masked(ref)), name
+        first, last = np.frombuffer(ref[8:24], dtype=np.int64)
+        q = common.index_queries(int(first), int(last))
+        want = oracle.ref_idx_query(ref, q)
+        assert [oracle.idx_query(ref, p, s) for p, s in q] == want, name
