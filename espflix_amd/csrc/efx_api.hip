@@ -41,6 +41,9 @@ __global__ void k_parse_set_prof(uint32_t*);
 
 using namespace efx;
 
+constexpr int kParseStreams = 2;  // parse halves in flight at once (latency-bound kernels: two overlap well)
+constexpr int kSlots = 3;         // parse -> recon hand-over buffer sets (one being reconstructed + two being parsed)
+
 struct efx_ctx {
     efx_config cfg{};
     hipStream_t stream = nullptr;
@@ -82,9 +85,13 @@ struct efx_ctx {
     hipEvent_t ev_demux[2] = {nullptr, nullptr};
     float demux_ms = 0.f;
     size_t ts_bytes = 0;
-    // Two sets of parse -> recon hand-over buffers: efx_decode() number n parses into slot n & 1
-    // on the parse stream while the recon stream is still reconstructing call n - 1 from the
-    // other slot, so back-to-back decodes overlap the two (differently bound) halves.
+    // kSlots sets of parse -> recon hand-over buffers: efx_decode() number n parses into slot
+    // n % kSlots on parse stream n % kParseStreams while the recon stream is still reconstructing
+    // earlier calls from the other slots.  The parse half is bound by the latency of its longest
+    // waves (3 waves per SIMD, ~1/3 of the issue slots used), so back-to-back decodes keep two parse
+    // halves and one reconstruction half on the GPU at once.  The index / slice-list scratch is
+    // shared: it is a function of the uploaded bitstreams only, so concurrent calls write the same
+    // bytes.
     struct Slot {
         uint32_t* d_pic_count = nullptr;
         uint32_t* d_status = nullptr;
@@ -96,10 +103,10 @@ struct efx_ctx {
         hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // timing: parse start, index end, parse end, recon end, recon start
         int epoch = 0;
         bool timed = false;
-    } slot[2];
+    } slot[kSlots];
     int cur = 0;        // slot of the most recent efx_decode
     uint64_t calls = 0;
-    hipStream_t parse_stream = nullptr;
+    hipStream_t parse_streams[kParseStreams] = {nullptr, nullptr};
     VideoTables* d_video[2] = {nullptr, nullptr};  // [0] PAL, [1] NTSC
     SbcTables* d_sbc_tables = nullptr;
     uint64_t* d_hash = nullptr;
@@ -218,7 +225,8 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         // workgroups are placed as soon as the reconstruction kernels of the previous call free a slot
         int lo = 0, hi = 0;
         A(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        A(hipStreamCreateWithPriority(&ctx->parse_stream, hipStreamNonBlocking, hi));
+        for (auto& ps : ctx->parse_streams)
+            A(hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, hi));
     }
     A(dalloc(&ctx->d_frames, n * D * kFrameBytes + 8192));  // slack: k_recon's window rows may over-read the last frame
     A(dalloc(&ctx->d_video[0], 1));
@@ -263,8 +271,9 @@ void efx_destroy(efx_ctx* ctx)
 {
     if (!ctx)
         return;
-    if (ctx->parse_stream)
-        (void)hipStreamSynchronize(ctx->parse_stream);
+    for (auto ps : ctx->parse_streams)
+        if (ps)
+            (void)hipStreamSynchronize(ps);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     void* bufs[] = {ctx->d_es,   ctx->d_stream_off, ctx->d_pics,  ctx->d_slices_tmp, ctx->d_qtab,     ctx->d_tables,
@@ -291,8 +300,9 @@ void efx_destroy(efx_ctx* ctx)
     }
     if (ctx->h_es)
         (void)hipHostFree(ctx->h_es);
-    if (ctx->parse_stream)
-        (void)hipStreamDestroy(ctx->parse_stream);
+    for (auto ps : ctx->parse_streams)
+        if (ps)
+            (void)hipStreamDestroy(ps);
     if (ctx->own_stream && ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -334,7 +344,8 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
         return fail(ctx, EFX_ERR_ARG, "efx_upload_streams: bad argument");
     if (n_streams > ctx->cfg.max_streams)
         return fail(ctx, EFX_ERR_CAPACITY, "efx_upload_streams: more streams than max_streams");
-    EFX_HIP(hipStreamSynchronize(ctx->parse_stream));  // the bitstream buffer may still be in use
+    for (auto ps : ctx->parse_streams)
+        EFX_HIP(hipStreamSynchronize(ps));  // the bitstream buffer may still be in use
     EFX_HIP(hipStreamSynchronize(ctx->stream));
     const bool is_ts = format == EFX_FORMAT_TS;
     if (is_ts) {
@@ -458,12 +469,12 @@ int efx_decode(efx_ctx* ctx)
     if (!ctx->uploaded)
         return fail(ctx, EFX_ERR_STATE, "efx_decode: no streams uploaded");
     const int n = ctx->n_streams, P = ctx->cfg.max_pictures, D = ctx->cfg.ring_depth;
-    hipStream_t sp = ctx->parse_stream, sr = ctx->stream;
-    ctx->cur = (int)(ctx->calls++ & 1);
+    hipStream_t sp = ctx->parse_streams[ctx->calls % kParseStreams], sr = ctx->stream;
+    ctx->cur = (int)(ctx->calls++ % kSlots);
     efx_ctx::Slot& sl = ctx->slot[ctx->cur];
 
     // ---- parse half (parse stream): index -> slice list -> VLC parse + dequantisation ---------------
-    EFX_HIP(hipStreamWaitEvent(sp, sl.recon_done, 0));  // the call two back has released this slot
+    EFX_HIP(hipStreamWaitEvent(sp, sl.recon_done, 0));  // the call kSlots back has released this slot
     // macroblock records carry the epoch that wrote them; recycle the tag space by clearing
     if (++sl.epoch > 255) {
         EFX_HIP(hipMemsetAsync(sl.d_mbrecs, 0, (size_t)ctx->cfg.max_streams * P * kMbCount * sizeof(MbRec), sp));
@@ -508,7 +519,8 @@ int efx_sync(efx_ctx* ctx)
 {
     if (!ctx)
         return EFX_ERR_ARG;
-    EFX_HIP(hipStreamSynchronize(ctx->parse_stream));
+    for (auto ps : ctx->parse_streams)
+        EFX_HIP(hipStreamSynchronize(ps));
     EFX_HIP(hipStreamSynchronize(ctx->stream));
     return EFX_OK;
 }
@@ -519,7 +531,8 @@ static int fetch_results(efx_ctx* ctx)
         return fail(ctx, EFX_ERR_STATE, "no decode has run");
     if (ctx->results_valid)
         return EFX_OK;
-    EFX_HIP(hipStreamSynchronize(ctx->parse_stream));
+    for (auto ps : ctx->parse_streams)
+        EFX_HIP(hipStreamSynchronize(ps));
     EFX_HIP(hipStreamSynchronize(ctx->stream));
     const efx_ctx::Slot& sl = ctx->slot[ctx->cur];
     ctx->h_pic_count.resize(ctx->n_streams);
@@ -712,7 +725,8 @@ int efx_index_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, con
     if (r)
         return r;
     // the TS staging buffers are shared with efx_upload_streams, which only uses them during the call
-    EFX_HIP(hipStreamSynchronize(ctx->parse_stream));
+    for (auto ps : ctx->parse_streams)
+        EFX_HIP(hipStreamSynchronize(ps));
     EFX_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<uint64_t> off((size_t)n_streams + 1);
     std::vector<uint32_t> tlen(n_streams), base(n_streams);
@@ -906,8 +920,10 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out)
 // development aid (libefx_prof.so only): per-slice {cycles, loop iterations, coefficients, bytes}
 int efx_debug_parse_profile(efx_ctx* ctx, uint32_t* dptr)
 {
-    hipLaunchKernelGGL(k_parse_set_prof, dim3(1), dim3(1), 0, ctx->parse_stream, dptr);
-    EFX_HIP(hipStreamSynchronize(ctx->parse_stream));
+    for (auto ps : ctx->parse_streams) {
+        hipLaunchKernelGGL(k_parse_set_prof, dim3(1), dim3(1), 0, ps, dptr);
+        EFX_HIP(hipStreamSynchronize(ps));
+    }
     return EFX_OK;
 }
 #endif

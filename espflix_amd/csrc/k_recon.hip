@@ -29,7 +29,13 @@ namespace {
 constexpr int kBlkPitch = 72;   // ints per block in LDS (64 + 8 pad)
 constexpr int kTilePitch = 32;  // bytes per staged window row (16-byte aligned rows)
 
-// one 8-point pass of the reference's scaled integer IDCT (player.cpp:938-995)
+// one 8-point pass of the reference's scaled integer IDCT (player.cpp:938-995).
+// The products use the full-rate 24-bit multiplier (v_mul_i32_i24 / v_mad_i32_i24; a 32-bit
+// v_mul_lo_u32 issues at quarter rate): every multiplied operand is a combination of AC
+// coefficients only -- the DC term v0 enters through x1 / x3 and is never multiplied -- and AC
+// coefficients are clamped to +-2048 and scaled by a premultiplier <= 62, which bounds the operands
+// by 2^19 in the column pass and 2^22.5 in the row pass (L1 norm of the linear map).  The low 32
+// bits of the 48-bit product equal the reference's wrapped 32-bit product.
 __device__ inline void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v5, int& v6, int& v7)
 {
     int b3 = v2 + v6;
@@ -38,16 +44,16 @@ __device__ inline void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v
     int t2 = v3 + v5;
     int b6 = v1 - v7;
     int b7 = t1 + t2;
-    int x4 = ((b6 * 473 - b4 * 196 + 128) >> 8) - b7;
-    int x0 = x4 - (((t1 - t2) * 362 + 128) >> 8);
+    int x4 = ((__mul24(b6, 473) - __mul24(b4, 196) + 128) >> 8) - b7;
+    int x0 = x4 - ((__mul24(t1 - t2, 362) + 128) >> 8);
     int x1 = v0 - v4;
-    int x2 = (((v2 - v6) * 362 + 128) >> 8) - b3;
+    int x2 = ((__mul24(v2 - v6, 362) + 128) >> 8) - b3;
     int x3 = v0 + v4;
     int y3 = x1 + x2;
     int y4 = x3 + b3;
     int y5 = x1 - x2;
     int y6 = x3 - b3;
-    int y7 = -x0 - ((b4 * 473 + b6 * 196 + 128) >> 8);
+    int y7 = -x0 - ((__mul24(b4, 473) + __mul24(b6, 196) + 128) >> 8);
     v0 = b7 + y4;
     v1 = x4 + y3;
     v2 = y5 - x0;
@@ -97,6 +103,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     // rows 17..25 "cr", rows 26..34 "cb" (12 bytes used)
     __shared__ uint32_t tile[35 * kTilePitch / 4];
     __shared__ int zflag[8];  // per block: 1 if an entry sits at raster position 0
+    __shared__ uint32_t qt[64];  // this macroblock's scan / quantiser table: one coalesced load, not a per-coefficient gather
 
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
@@ -139,6 +146,10 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
                         y0 + 16 + (Y & 1) <= EFX_FRAME_HEIGHT && cx0 >= 0 && cy0 >= 0 &&
                         cx0 + 8 + (CX & 1) <= EFX_FRAME_WIDTH / 2 && cy0 + 8 + (CY & 1) <= EFX_FRAME_HEIGHT / 2;
     const bool stage = !intra && inside && lane < 35;
+    // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
+    uint32_t qv = 0;
+    if (total > 0)
+        qv = ((rec.flags & 0x80) ? qtab_custom + ((size_t)s * max_pictures + pic) * 64 : scan_tab)[lane];
     uint4 ta = make_uint4(0, 0, 0, 0);
     uint32_t tb = 0;
     if (stage) {
@@ -156,7 +167,8 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             off = (((c >> 3) << 4) + (c & 7) + (p2 ? 8 : 0)) * kStride + EFX_FRAME_WIDTH + (cx0 & ~3);
         }
         ta = *reinterpret_cast<const uint4*>(ref + off);
-        tb = *reinterpret_cast<const uint32_t*>(ref + off + 16);
+        if (lane < 17)  // a luma row needs 20 bytes; a chroma row's 12 fit in the 16 already fetched
+            tb = *reinterpret_cast<const uint32_t*>(ref + off + 16);
     }
 
     // ---- scatter the coefficient entries ----------------------------------------------------
@@ -174,11 +186,10 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         }
         if (lane < 8)
             zflag[lane] = 0;
+        qt[lane] = qv;
         __syncthreads();
         // one lane per coefficient: dequantise (player.cpp:1110-1121) and drop it into its block.
-        // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
         const int qscale = (rec.flags >> 2) & 31;
-        const uint32_t* qt = (rec.flags & 0x80) ? qtab_custom + ((size_t)s * max_pictures + pic) * 64 : scan_tab;
         for (int i = lane; i < total; i += 64) {
             uint32_t e = (i < 64) ? ce : coefs[rec.coef_base + i];
             int b = (i >= pre1) + (i >= pre2) + (i >= pre3) + (i >= pre4) + (i >= pre5);
@@ -192,12 +203,13 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
                 val = level << 1;
                 if (!intra)
                     val += (val < 0) ? -1 : 1;
-                val = val * qscale * q;
+                // |2 level +- 1| <= 511, qscale <= 31, q <= 255: 24-bit products are exact
+                val = __mul24(__mul24(val, qscale), q);
                 val = (val + ((val >> 31) & 15)) >> 4;  // division by 16 truncating toward zero
                 if ((val & 1) == 0)
                     val -= (val > 0) ? 1 : -1;
                 val = val > 2047 ? 2047 : (val < -2048 ? -2048 : val);
-                val *= (int)((t >> 8) & 0xFF);
+                val = __mul24(val, (int)((t >> 8) & 0xFF));
             }
             cf[b * kBlkPitch + (t & 63)] = val;
             if (n == 0)
