@@ -17,6 +17,7 @@ namespace efx {
 
 constexpr int kMbW = 22, kMbH = 12, kMbCount = 264;
 constexpr int kStride = 528, kStripBytes = 8448, kFrameBytes = 101376;
+constexpr int kReconThreads = 256;         // k_recon workgroup: 4 independent waves, one macroblock each (264 = 4 x 66)
 constexpr int kMaxSlicesPerPicture = 16;   // slice start codes kept per picture
 constexpr int kMaxUnitsPerStream = 4096;   // start codes indexed per stream per decode
 constexpr int kCoefsPerEsByte = 3;         // a coefficient costs >= 3 bits (2 + EOB for singletons)

@@ -28,6 +28,7 @@ namespace {
 
 constexpr int kBlkPitch = 72;   // ints per block in LDS (64 + 8 pad)
 constexpr int kTilePitch = 32;  // bytes per staged window row (16-byte aligned rows)
+constexpr int kWavesPerGroup = kReconThreads / 64;
 
 // one 8-point pass of the reference's scaled integer IDCT (player.cpp:938-995).
 // The products use the full-rate 24-bit multiplier (v_mul_i32_i24 / v_mad_i32_i24; a 32-bit
@@ -64,6 +65,16 @@ __device__ inline void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v
     v7 = y4 - b7;
 }
 
+// Ordering of LDS traffic inside ONE wave: the LDS unit executes a wave's instructions in issue
+// order, so a write by one lane is visible to a later read by another lane of the same wave; all
+// that is needed is that the compiler keeps the order.
+__device__ inline void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // byte offset of plane row inside a frame (Frame::get_y/get_cr/get_cb, player.cpp:33-46)
@@ -88,26 +99,36 @@ __device__ inline uint32_t avg4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) 
 
 }  // namespace
 
-// grid = (streams, 264): blockIdx.x = stream, blockIdx.y = macroblock.  The linear workgroup id is
+// grid = (streams, 264 / kWavesPerGroup): blockIdx.x = stream, blockIdx.y = group of macroblocks,
+// one per wave.  The linear workgroup id is
 // y * streams + x, so with a stream count that is a multiple of 8 all macroblocks of a stream are
 // dispatched to XCD (stream % 8) and the partial 64-byte lines written by neighbouring
 // macroblocks merge in one L2.  cur_slot / ref_slot are the ring slots of this picture index.
-__global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, const uint32_t* __restrict__ coefs,
+__global__ __launch_bounds__(kReconThreads) void k_recon(const MbRec* __restrict__ mbrecs, const uint32_t* __restrict__ coefs,
                                               const uint32_t* __restrict__ scan_tab,
                                               const uint32_t* __restrict__ qtab_custom, uint8_t* __restrict__ frames,
                                               int max_pictures, int ring_depth, int pic, int cur_slot, int ref_slot,
                                               int epoch)
 {
-    __shared__ int cf[6 * kBlkPitch];
+    // Workgroups exist only to amortise dispatch: a workgroup costs the dispatcher the same whether it
+    // holds one wave or four (270 336 single-wave workgroups take 58 us to dispatch EMPTY, a quarter
+    // as many four-wave ones 16 us).  The kWavesPerGroup waves of a workgroup never communicate: each
+    // owns one macroblock, its own LDS regions, and synchronises only with itself.
+    __shared__ int cf_all[kWavesPerGroup][6 * kBlkPitch];
     // staged reference windows, one row of kTilePitch bytes per lane: rows 0..16 luma (20 bytes used),
     // rows 17..25 "cr", rows 26..34 "cb" (12 bytes used)
-    __shared__ uint32_t tile[35 * kTilePitch / 4];
-    __shared__ int zflag[8];  // per block: 1 if an entry sits at raster position 0
-    __shared__ uint32_t qt[64];  // this macroblock's scan / quantiser table: one coalesced load, not a per-coefficient gather
+    __shared__ uint32_t tile_all[kWavesPerGroup][35 * kTilePitch / 4];
+    __shared__ int zflag_all[kWavesPerGroup][8];  // per block: 1 if an entry sits at raster position 0
+    __shared__ uint32_t qt_all[kWavesPerGroup][64];  // this macroblock's scan / quantiser table: one coalesced load, not a per-coefficient gather
 
-    const int lane = threadIdx.x;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int s = blockIdx.x;
-    const int mb = blockIdx.y;
+    const int mb = blockIdx.y * kWavesPerGroup + wave;
+    int* cf = cf_all[wave];
+    uint32_t* tile = tile_all[wave];
+    int* zflag = zflag_all[wave];
+    uint32_t* qt = qt_all[wave];
 
     // The record is wave-uniform: fetch it as one 16-byte word and keep every field in scalar
     // registers (indexing the struct per lane would bounce it through memory).
@@ -145,6 +166,11 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     const bool inside = x0 >= 0 && y0 >= 0 && x0 + 16 + (X & 1) <= EFX_FRAME_WIDTH &&
                         y0 + 16 + (Y & 1) <= EFX_FRAME_HEIGHT && cx0 >= 0 && cy0 >= 0 &&
                         cx0 + 8 + (CX & 1) <= EFX_FRAME_WIDTH / 2 && cy0 + 8 + (CY & 1) <= EFX_FRAME_HEIGHT / 2;
+    // rows / bytes of the window that are really needed: the 17th luma row and the 9th chroma rows
+    // only for a vertical half-pel, bytes 16..19 of a luma row only when the 16 (+1) pixels do not
+    // start on a dword boundary -- a zero vector touches 32 lines instead of 52
+    const bool need_tb = (x0 & 3) || (X & 1);
+    const bool row_live = lane < 17 ? (lane < 16 || (Y & 1)) : (((lane - 17) % 9) < 8 || (CY & 1));
     const bool stage = !intra && inside && lane < 35;
     // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
     uint32_t qv = 0;
@@ -166,8 +192,9 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             const int j = lane - 17, p2 = j >= 9, c = cy0 + (p2 ? j - 9 : j);
             off = (((c >> 3) << 4) + (c & 7) + (p2 ? 8 : 0)) * kStride + EFX_FRAME_WIDTH + (cx0 & ~3);
         }
-        ta = *reinterpret_cast<const uint4*>(ref + off);
-        if (lane < 17)  // a luma row needs 20 bytes; a chroma row's 12 fit in the 16 already fetched
+        if (row_live)
+            ta = *reinterpret_cast<const uint4*>(ref + off);
+        if (lane < 17 && need_tb && row_live)  // a chroma row's 12 bytes fit in the 16 already fetched
             tb = *reinterpret_cast<const uint32_t*>(ref + off + 16);
     }
 
@@ -187,7 +214,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         if (lane < 8)
             zflag[lane] = 0;
         qt[lane] = qv;
-        __syncthreads();
+        wave_lds_sync();
         // one lane per coefficient: dequantise (player.cpp:1110-1121) and drop it into its block.
         const int qscale = (rec.flags >> 2) & 31;
         for (int i = lane; i < total; i += 64) {
@@ -238,7 +265,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             }
         }
     }
-    __syncthreads();
+    wave_lds_sync();
 
     // A block whose only coefficient sits at scan position 0 takes the reference's "n == 1"
     // shortcut (player.cpp:1133-1140): dc = b[0] >> 8 (floor), no IDCT; for intra blocks the
@@ -261,7 +288,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             c[48] = v6;
             c[56] = v7;
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 
     if (!worker)
@@ -294,11 +321,12 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         dst_off = mb_y * kStripBytes + ((blk - 4) * 8 + row) * kStride + EFX_FRAME_WIDTH + mb_x * 8;
     uint2* dst = reinterpret_cast<uint2*>(cur + dst_off);
 
+    uint32_t lo = 0, hi = 0;
+    bool stored = true;
     if (intra) {
         if (my_cnt == 0)
-            return;  // block abandoned by the parser: nothing is stored (player.cpp:1106-1107)
-        uint32_t lo, hi;
-        if (dc_only) {
+            stored = false;  // block abandoned by the parser: nothing is stored (player.cpp:1106-1107)
+        else if (dc_only) {
             uint32_t w = (uint32_t)r0;
             w |= w << 8;
             w |= w << 16;
@@ -309,58 +337,71 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             hi = (uint32_t)clampi(r4, 0, 248) | ((uint32_t)clampi(r5, 0, 248) << 8) | ((uint32_t)clampi(r6, 0, 248) << 16) |
                  ((uint32_t)clampi(r7, 0, 248) << 24);
         }
-        *dst = make_uint2(lo, hi);
-        return;
-    }
-
-    // ---- prediction: the four half-pel cases of mocomp(), player.cpp:767-820 ----------------------
-    uint32_t p_lo, p_hi;
-    {
-        const int pitch = kTilePitch / 4;
-        const bool luma = blk < 4;
-        const uint32_t* t = tile + (luma ? (blk >> 1) * 8 + row : 17 + (blk - 4) * 9 + row) * pitch;
-        const int col = luma ? (x0 & 3) + (blk & 1) * 8 : (cx0 & 3);
-        const int hx = (luma ? X : CX) & 1, hy = (luma ? Y : CY) & 1;
-        const int w0 = col >> 2, sh = col & 3;
-        // 12 bytes starting at the dword holding `col`, for this row and the next
-        uint32_t a0 = t[w0], a1 = t[w0 + 1], a2 = t[w0 + 2];
-        // pixels col..col+7; pixel col+8 is byte `sh` of the third dword
-        uint32_t A_lo = __builtin_amdgcn_alignbit(a1, a0, sh * 8), A_hi = __builtin_amdgcn_alignbit(a2, a1, sh * 8);
-        if (!hy) {
-            if (!hx) {
-                p_lo = A_lo;
-                p_hi = A_hi;
+    } else {
+        // ---- prediction: the four half-pel cases of mocomp(), player.cpp:767-820 ------------------
+        uint32_t p_lo, p_hi;
+        {
+            const int pitch = kTilePitch / 4;
+            const bool luma = blk < 4;
+            const uint32_t* t = tile + (luma ? (blk >> 1) * 8 + row : 17 + (blk - 4) * 9 + row) * pitch;
+            const int col = luma ? (x0 & 3) + (blk & 1) * 8 : (cx0 & 3);
+            const int hx = (luma ? X : CX) & 1, hy = (luma ? Y : CY) & 1;
+            const int w0 = col >> 2, sh = col & 3;
+            // 12 bytes starting at the dword holding `col`, for this row and the next
+            uint32_t a0 = t[w0], a1 = t[w0 + 1], a2 = t[w0 + 2];
+            // pixels col..col+7; pixel col+8 is byte `sh` of the third dword
+            uint32_t A_lo = __builtin_amdgcn_alignbit(a1, a0, sh * 8), A_hi = __builtin_amdgcn_alignbit(a2, a1, sh * 8);
+            if (!hy) {
+                if (!hx) {
+                    p_lo = A_lo;
+                    p_hi = A_hi;
+                } else {
+                    uint32_t A9 = (a2 >> (sh * 8)) & 0xFF;
+                    p_lo = avg_up(A_lo, (A_lo >> 8) | (A_hi << 24));
+                    p_hi = avg_up(A_hi, (A_hi >> 8) | (A9 << 24));
+                }
             } else {
-                uint32_t A9 = (a2 >> (sh * 8)) & 0xFF;
-                p_lo = avg_up(A_lo, (A_lo >> 8) | (A_hi << 24));
-                p_hi = avg_up(A_hi, (A_hi >> 8) | (A9 << 24));
+                uint32_t b0 = t[pitch + w0], b1 = t[pitch + w0 + 1], b2 = t[pitch + w0 + 2];
+                uint32_t B_lo = __builtin_amdgcn_alignbit(b1, b0, sh * 8), B_hi = __builtin_amdgcn_alignbit(b2, b1, sh * 8);
+                if (!hx) {
+                    p_lo = avg_up(A_lo, B_lo);
+                    p_hi = avg_up(A_hi, B_hi);
+                } else {
+                    uint32_t A9 = (a2 >> (sh * 8)) & 0xFF, B9 = (b2 >> (sh * 8)) & 0xFF;
+                    p_lo = avg4(A_lo, (A_lo >> 8) | (A_hi << 24), B_lo, (B_lo >> 8) | (B_hi << 24));
+                    p_hi = avg4(A_hi, (A_hi >> 8) | (A9 << 24), B_hi, (B_hi >> 8) | (B9 << 24));
+                }
             }
-        } else {
-            uint32_t b0 = t[pitch + w0], b1 = t[pitch + w0 + 1], b2 = t[pitch + w0 + 2];
-            uint32_t B_lo = __builtin_amdgcn_alignbit(b1, b0, sh * 8), B_hi = __builtin_amdgcn_alignbit(b2, b1, sh * 8);
-            if (!hx) {
-                p_lo = avg_up(A_lo, B_lo);
-                p_hi = avg_up(A_hi, B_hi);
-            } else {
-                uint32_t A9 = (a2 >> (sh * 8)) & 0xFF, B9 = (b2 >> (sh * 8)) & 0xFF;
-                p_lo = avg4(A_lo, (A_lo >> 8) | (A_hi << 24), B_lo, (B_lo >> 8) | (B_hi << 24));
-                p_hi = avg4(A_hi, (A_hi >> 8) | (A9 << 24), B_hi, (B_hi >> 8) | (B9 << 24));
-            }
+        }
+        if (my_cnt == 0) {  // prediction only (skipped macroblock, or block without coefficients)
+            lo = p_lo;
+            hi = p_hi;
+        } else {  // add_block / add_block_dc, player.cpp:1189-1236
+            lo = (uint32_t)clampi(r0 + (int)(p_lo & 0xFF), 0, 248) | ((uint32_t)clampi(r1 + (int)((p_lo >> 8) & 0xFF), 0, 248) << 8) |
+                 ((uint32_t)clampi(r2 + (int)((p_lo >> 16) & 0xFF), 0, 248) << 16) |
+                 ((uint32_t)clampi(r3 + (int)(p_lo >> 24), 0, 248) << 24);
+            hi = (uint32_t)clampi(r4 + (int)(p_hi & 0xFF), 0, 248) | ((uint32_t)clampi(r5 + (int)((p_hi >> 8) & 0xFF), 0, 248) << 8) |
+                 ((uint32_t)clampi(r6 + (int)((p_hi >> 16) & 0xFF), 0, 248) << 16) |
+                 ((uint32_t)clampi(r7 + (int)(p_hi >> 24), 0, 248) << 24);
         }
     }
 
-    if (my_cnt == 0) {  // prediction only (skipped macroblock, or block without coefficients)
-        *dst = make_uint2(p_lo, p_hi);
-        return;
-    }
-    // add_block / add_block_dc, player.cpp:1189-1236
-    uint32_t lo = (uint32_t)clampi(r0 + (int)(p_lo & 0xFF), 0, 248) | ((uint32_t)clampi(r1 + (int)((p_lo >> 8) & 0xFF), 0, 248) << 8) |
-                  ((uint32_t)clampi(r2 + (int)((p_lo >> 16) & 0xFF), 0, 248) << 16) |
-                  ((uint32_t)clampi(r3 + (int)(p_lo >> 24), 0, 248) << 24);
-    uint32_t hi = (uint32_t)clampi(r4 + (int)(p_hi & 0xFF), 0, 248) | ((uint32_t)clampi(r5 + (int)((p_hi >> 8) & 0xFF), 0, 248) << 8) |
-                  ((uint32_t)clampi(r6 + (int)((p_hi >> 16) & 0xFF), 0, 248) << 16) |
-                  ((uint32_t)clampi(r7 + (int)(p_hi >> 24), 0, 248) << 24);
-    *dst = make_uint2(lo, hi);
+    // ---- store --------------------------------------------------------------------------------------
+    // A luma row of the macroblock is 16 contiguous bytes (blocks 0|1, 2|3).  The lane of the left
+    // block fetches the right block's 8 bytes from lane + 8 (same 16-lane DPP row) and issues one
+    // 16-byte store: 16 + 16 row accesses per macroblock instead of 32 + 16.  Only an intra
+    // macroblock with an abandoned block falls back to per-block stores.
+    const bool all_stored = !intra || (pre1 > 0 && pre2 > pre1 && pre3 > pre2 && pre4 > pre3);  // wave-uniform (luma blocks)
+    if (all_stored) {
+        const uint32_t q_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x108, 0xF, 0xF, false);  // row_shl:8
+        const uint32_t q_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x108, 0xF, 0xF, false);
+        if (blk < 4) {
+            if (!(blk & 1))
+                *reinterpret_cast<uint4*>(dst) = make_uint4(lo, hi, q_lo, q_hi);
+        } else if (stored)
+            *dst = make_uint2(lo, hi);
+    } else if (stored)
+        *dst = make_uint2(lo, hi);
 }
 
 // FNV-1a-64 of whole ring frames, one lane per frame (verification helper, not on the timed path)
