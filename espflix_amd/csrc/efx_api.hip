@@ -42,6 +42,7 @@ __global__ void k_parse_set_prof(uint32_t*);
 using namespace efx;
 
 constexpr int kParseStreams = 2;  // parse halves in flight at once (latency-bound kernels: two overlap well)
+constexpr int kTimingRing = 64;   // efx_decode calls whose stage times efx_get_timing can average
 constexpr int kSlots = 3;         // parse -> recon hand-over buffer sets (one being reconstructed + two being parsed)
 
 struct efx_ctx {
@@ -100,10 +101,15 @@ struct efx_ctx {
         uint32_t* d_coefs = nullptr;
         int64_t* d_pts = nullptr;  // per (stream, picture): PTS latched at the picture header (TS input)
         hipEvent_t parse_done = nullptr, recon_done = nullptr;
-        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // timing: parse start, index end, parse end, recon end, recon start
         int epoch = 0;
-        bool timed = false;
     } slot[kSlots];
+    // stage timing: one event set per efx_decode call since efx_set_timing(1), so that a run of
+    // back-to-back (overlapping) calls can be averaged afterwards without a host sync in between
+    struct TimingEvents {
+        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // parse start, index end, parse end, recon end, recon start
+    };
+    std::vector<TimingEvents> timing_ring;  // kTimingRing sets, created by efx_set_timing
+    uint64_t timed_calls = 0;               // calls recorded since timing was (re-)enabled
     int cur = 0;        // slot of the most recent efx_decode
     uint64_t calls = 0;
     hipStream_t parse_streams[kParseStreams] = {nullptr, nullptr};
@@ -258,8 +264,6 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         A(hipMemset(sl.d_mbrecs, 0, n * P * kMbCount * sizeof(MbRec)));
         A(hipEventCreateWithFlags(&sl.parse_done, hipEventDisableTiming));
         A(hipEventCreateWithFlags(&sl.recon_done, hipEventDisableTiming));
-        for (auto& ev : sl.ev)
-            A(hipEventCreate(&ev));
     }
     if (e != hipSuccess)
         return bail(EFX_ERR_DEVICE);
@@ -282,6 +286,10 @@ void efx_destroy(efx_ctx* ctx)
     for (auto& ev : ctx->ev_demux)
         if (ev)
             (void)hipEventDestroy(ev);
+    for (auto& te : ctx->timing_ring)
+        for (auto& ev : te.ev)
+            if (ev)
+                (void)hipEventDestroy(ev);
     for (void* b : bufs)
         if (b)
             (void)hipFree(b);
@@ -294,9 +302,6 @@ void efx_destroy(efx_ctx* ctx)
             (void)hipEventDestroy(sl.parse_done);
         if (sl.recon_done)
             (void)hipEventDestroy(sl.recon_done);
-        for (auto& ev : sl.ev)
-            if (ev)
-                (void)hipEventDestroy(ev);
     }
     if (ctx->h_es)
         (void)hipHostFree(ctx->h_es);
@@ -480,9 +485,11 @@ int efx_decode(efx_ctx* ctx)
         EFX_HIP(hipMemsetAsync(sl.d_mbrecs, 0, (size_t)ctx->cfg.max_streams * P * kMbCount * sizeof(MbRec), sp));
         sl.epoch = 1;
     }
-    sl.timed = ctx->timing;
-    if (sl.timed)
-        EFX_HIP(hipEventRecord(sl.ev[0], sp));
+    efx_ctx::TimingEvents* te = nullptr;
+    if (ctx->timing && !ctx->timing_ring.empty())
+        te = &ctx->timing_ring[ctx->timed_calls++ % kTimingRing];
+    if (te)
+        EFX_HIP(hipEventRecord(te->ev[0], sp));
     hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, sp, ctx->d_es, ctx->d_stream_off, P, ctx->d_pics, ctx->d_slices_tmp,
                        sl.d_pic_count, sl.d_status, ctx->d_qtab, ctx->d_tables->scan, ctx->d_pes, ctx->d_pkt_base,
                        ctx->d_pes_count, ctx->ts_input ? sl.d_pts : nullptr);
@@ -490,24 +497,24 @@ int efx_decode(efx_ctx* ctx)
                        sl.d_counters);
     hipLaunchKernelGGL(k_slice_emit, dim3((n * P * kMaxSlicesPerPicture + 255) / 256), dim3(256), 0, sp, ctx->d_pics,
                        ctx->d_slices_tmp, sl.d_pic_count, ctx->d_stream_off, ctx->d_slice_base, n, P, ctx->d_descs);
-    if (sl.timed)
-        EFX_HIP(hipEventRecord(sl.ev[1], sp));
+    if (te)
+        EFX_HIP(hipEventRecord(te->ev[1], sp));
     const int max_slices = n * P * kMaxSlicesPerPicture;
     hipLaunchKernelGGL(k_parse, dim3((max_slices + 255) / 256), dim3(256), 0, sp, ctx->d_es, ctx->d_descs, sl.d_counters,
                        ctx->d_tables, sl.d_mbrecs, sl.d_coefs, sl.d_status, P, sl.epoch);
-    if (sl.timed)
-        EFX_HIP(hipEventRecord(sl.ev[2], sp));
+    if (te)
+        EFX_HIP(hipEventRecord(te->ev[2], sp));
     EFX_HIP(hipEventRecord(sl.parse_done, sp));
 
     // ---- reconstruction half (context stream): one launch per picture index ------------------------------
     EFX_HIP(hipStreamWaitEvent(sr, sl.parse_done, 0));
-    if (sl.timed)
-        EFX_HIP(hipEventRecord(sl.ev[4], sr));
+    if (te)
+        EFX_HIP(hipEventRecord(te->ev[4], sr));
     for (int p = 0; p < P; p++)
         hipLaunchKernelGGL(k_recon, dim3(n, kMbCount / (kReconThreads / 64)), dim3(kReconThreads), 0, sr, sl.d_mbrecs, sl.d_coefs, ctx->d_tables->scan,
                            ctx->d_qtab, ctx->d_frames, P, D, p, (p + 1) % D, p % D, sl.epoch);
-    if (sl.timed)
-        EFX_HIP(hipEventRecord(sl.ev[3], sr));
+    if (te)
+        EFX_HIP(hipEventRecord(te->ev[3], sr));
     EFX_HIP(hipEventRecord(sl.recon_done, sr));
     EFX_HIP(hipGetLastError());
     ctx->decoded = true;
@@ -885,7 +892,14 @@ int efx_set_timing(efx_ctx* ctx, int enable)
 {
     if (!ctx)
         return EFX_ERR_ARG;
+    if (enable && ctx->timing_ring.empty()) {
+        ctx->timing_ring.resize(kTimingRing);
+        for (auto& te : ctx->timing_ring)
+            for (auto& ev : te.ev)
+                EFX_HIP(hipEventCreate(&ev));
+    }
     ctx->timing = enable != 0;
+    ctx->timed_calls = 0;  // (re-)enabling starts a new averaging window
     return EFX_OK;
 }
 
@@ -897,14 +911,22 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out)
     if (r)
         return r;
     efx_timing t{};
-    const efx_ctx::Slot& sl = ctx->slot[ctx->cur];
-    if (sl.timed) {
-        EFX_HIP(hipEventSynchronize(sl.ev[3]));
-        EFX_HIP(hipEventElapsedTime(&t.index_ms, sl.ev[0], sl.ev[1]));
-        EFX_HIP(hipEventElapsedTime(&t.parse_ms, sl.ev[1], sl.ev[2]));
-        EFX_HIP(hipEventElapsedTime(&t.recon_ms, sl.ev[4], sl.ev[3]));
-        EFX_HIP(hipEventElapsedTime(&t.total_ms, sl.ev[0], sl.ev[3]));
+    // mean over the efx_decode calls since efx_set_timing(1) (the last kTimingRing of them);
+    // fetch_results() has synchronised both streams, so every recorded event is complete
+    const uint64_t n_timed = std::min<uint64_t>(ctx->timed_calls, kTimingRing);
+    for (uint64_t k = 0; k < n_timed; k++) {
+        const efx_ctx::TimingEvents& te = ctx->timing_ring[(ctx->timed_calls - 1 - k) % kTimingRing];
+        float a = 0, b = 0, c = 0, d = 0;
+        EFX_HIP(hipEventElapsedTime(&a, te.ev[0], te.ev[1]));
+        EFX_HIP(hipEventElapsedTime(&b, te.ev[1], te.ev[2]));
+        EFX_HIP(hipEventElapsedTime(&c, te.ev[4], te.ev[3]));
+        EFX_HIP(hipEventElapsedTime(&d, te.ev[0], te.ev[3]));
+        t.index_ms += a / n_timed;
+        t.parse_ms += b / n_timed;
+        t.recon_ms += c / n_timed;
+        t.total_ms += d / n_timed;
     }
+    t.timed_calls = (uint32_t)n_timed;
     for (int i = 0; i < ctx->n_streams; i++)
         t.pictures += ctx->h_pic_count[i];
     t.slices = ctx->h_counters.total_slices;

@@ -218,13 +218,15 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
 
 /* -- measurement -------------------------------------------------------------------------- */
 typedef struct efx_timing {
-    float index_ms, parse_ms, recon_ms, total_ms; /* HIP-event times of the last efx_decode */
+    float index_ms, parse_ms, recon_ms, total_ms; /* HIP-event stage times, mean over the efx_decode calls
+                                                     since efx_set_timing(ctx, 1) (at most the last 64) */
     uint64_t pictures, slices, coefficients, es_bytes;
     float demux_ms;    /* k_demux of the last EFX_FORMAT_TS upload (0 for ES input or timing off at upload) */
-    float reserved;
+    uint32_t timed_calls; /* efx_decode calls averaged in the stage times */
     uint64_t ts_bytes; /* transport-stream bytes of the last upload */
 } efx_timing;
-/* Enable HIP-event timing of the decode stages (off by default: events serialise the stages). */
+/* Enable HIP-event timing of the decode stages (events recorded on the kernels' own streams);
+ * enabling (again) starts a new averaging window. */
 int efx_set_timing(efx_ctx* ctx, int enable);
 int efx_get_timing(efx_ctx* ctx, efx_timing* out);
 
