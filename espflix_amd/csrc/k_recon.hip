@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kReconThreads) void k_recon(const MbRec* __restrict
     __shared__ int zflag_all[kWavesPerGroup][8];  // per block: 1 if an entry sits at raster position 0
     __shared__ uint32_t qt_all[kWavesPerGroup][64];  // this macroblock's scan / quantiser table: one coalesced load, not a per-coefficient gather
 
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep it (and everything derived) scalar
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x;
     const int mb = blockIdx.y * kWavesPerGroup + wave;
