@@ -511,7 +511,7 @@ int efx_decode(efx_ctx* ctx)
     if (te)
         EFX_HIP(hipEventRecord(te->ev[4], sr));
     for (int p = 0; p < P; p++)
-        hipLaunchKernelGGL(k_recon, dim3(n, kMbCount / (kReconThreads / 64)), dim3(kReconThreads), 0, sr, sl.d_mbrecs, sl.d_coefs, ctx->d_tables->scan,
+        hipLaunchKernelGGL(k_recon, dim3(n, (kMbCount * 6 + 63) / 64), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs, ctx->d_tables->scan,
                            ctx->d_qtab, ctx->d_frames, P, D, p, (p + 1) % D, p % D, sl.epoch);
     if (te)
         EFX_HIP(hipEventRecord(te->ev[3], sr));

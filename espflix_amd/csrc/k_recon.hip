@@ -1,7 +1,7 @@
 // k_recon.hip -- macroblock reconstruction: IDCT + half-pel motion compensation + store (gfx950).
 //
-// ONE WAVE (64-thread workgroup) PER MACROBLOCK, one launch per picture index (a P picture
-// needs the previous picture of its own stream; streams and macroblocks are independent).
+// ONE LANE PER 8x8 BLOCK, one launch per picture index (a P picture needs the previous picture of
+// its own stream; streams, macroblocks and blocks are independent).
 // Restates idct() (reference src/player.cpp:922-996), predict()/predict_zero()/mocomp()
 // (732-889) and copy_block/add_block[_dc] (1151-1236):
 //
@@ -28,7 +28,6 @@ namespace {
 
 constexpr int kBlkPitch = 72;   // ints per block in LDS (64 + 8 pad)
 constexpr int kTilePitch = 32;  // bytes per staged window row (16-byte aligned rows)
-constexpr int kWavesPerGroup = kReconThreads / 64;
 
 // one 8-point pass of the reference's scaled integer IDCT (player.cpp:938-995).
 // The products use the full-rate 24-bit multiplier (v_mul_i32_i24 / v_mad_i32_i24; a 32-bit
@@ -65,16 +64,6 @@ __device__ inline void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v
     v7 = y4 - b7;
 }
 
-// Ordering of LDS traffic inside ONE wave: the LDS unit executes a wave's instructions in issue
-// order, so a write by one lane is visible to a later read by another lane of the same wave; all
-// that is needed is that the compiler keeps the order.
-__device__ inline void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // byte offset of plane row inside a frame (Frame::get_y/get_cr/get_cb, player.cpp:33-46)
@@ -97,311 +86,276 @@ __device__ inline uint32_t avg4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) 
     return ((e >> 2) & m) | (((o >> 2) & m) << 8);
 }
 
+// per byte (a + b + c + d + 2) >> 2 from byte-wise averages (v_lerp_u8: (x + y + (z & 1)) >> 1):
+// with h1 = (a + b) >> 1, h2 = (c + d) >> 1 and l = the carry bits both halves dropped,
+// the result is (h1 + h2 + 1 + l) >> 1 = ceil_avg(h1, h2) + (l & ~(h1 ^ h2) & 1).
+__device__ inline uint32_t avg4_lerp(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const uint32_t h1 = __builtin_amdgcn_lerp(a, b, 0), h2 = __builtin_amdgcn_lerp(c, d, 0);
+    const uint32_t l = (a ^ b) & (c ^ d);
+    return __builtin_amdgcn_lerp(h1, h2, 0x01010101u) + (l & ~(h1 ^ h2) & 0x01010101u);
+}
+
 }  // namespace
 
-// grid = (streams, 264 / kWavesPerGroup): blockIdx.x = stream, blockIdx.y = group of macroblocks,
-// one per wave.  The linear workgroup id is
-// y * streams + x, so with a stream count that is a multiple of 8 all macroblocks of a stream are
-// dispatched to XCD (stream % 8) and the partial 64-byte lines written by neighbouring
-// macroblocks merge in one L2.  cur_slot / ref_slot are the ring slots of this picture index.
-__global__ __launch_bounds__(kReconThreads) void k_recon(const MbRec* __restrict__ mbrecs, const uint32_t* __restrict__ coefs,
+// IDCT pre-multiplier of raster position (r, c): round(32 s_r s_c), s_0 = 1, s_k = sqrt(2) cos(k pi / 16)
+// -- the reference's scale_dct_q (player.cpp:161-170), as efx_tables.cpp builds it for the scan
+// table; here as compile-time constants so that every register of the in-register IDCT is scaled
+// by an immediate.
+__device__ constexpr double kAan[8] = {1.0,          1.3870398453221475, 1.3065629648763766, 1.1758756024193588,
+                                       1.0,          0.7856949583871022, 0.5411961001461970, 0.2758993792829431};
+__device__ constexpr int premul_at(int r, int c) { return (int)(32.0 * kAan[r] * kAan[c] + 0.5); }
+
+constexpr int kBlocksPerPicture = kMbCount * 6;
+constexpr int kLaneHalfwords = 66;  // per-lane LDS block: 64 int16 + 2 pad = 33 dwords (odd: lanes fan out over the banks)
+
+// grid = (streams, 25): blockIdx.x = stream, blockIdx.y = group of 64 consecutive 8x8 blocks of the
+// picture (block b = macroblock b / 6, block b % 6); ONE LANE PER BLOCK.  With a stream count that
+// is a multiple of 8 all blocks of a stream are dispatched to XCD (stream % 8).
+//
+// The previous mapping (one wave per macroblock, 48 of 64 lanes in the butterflies, transposition
+// through LDS) was bound by VALU issue.  Here a lane owns a whole block: it dequantises its own
+// coefficient entries into a private 64 x int16 LDS block (the only use of LDS: a register file
+// cannot be indexed per lane), reads the block into 64 registers, runs the 16 butterflies of the
+// 2-D IDCT in registers, forms the prediction of its 8 x 8 pixels from nine 12-byte row fetches and
+// stores eight 8-byte rows.  No lane ever waits for another: no barrier, no shuffle, no scalar
+// bookkeeping, every lane busy.
+// cur_slot / ref_slot are the ring slots of this picture index.
+__global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, const uint32_t* __restrict__ coefs,
                                               const uint32_t* __restrict__ scan_tab,
                                               const uint32_t* __restrict__ qtab_custom, uint8_t* __restrict__ frames,
                                               int max_pictures, int ring_depth, int pic, int cur_slot, int ref_slot,
                                               int epoch)
 {
-    // Workgroups exist only to amortise dispatch: a workgroup costs the dispatcher the same whether it
-    // holds one wave or four (270 336 single-wave workgroups take 58 us to dispatch EMPTY, a quarter
-    // as many four-wave ones 16 us).  The kWavesPerGroup waves of a workgroup never communicate: each
-    // owns one macroblock, its own LDS regions, and synchronises only with itself.
-    __shared__ int cf_all[kWavesPerGroup][6 * kBlkPitch];
-    // staged reference windows, one row of kTilePitch bytes per lane: rows 0..16 luma (20 bytes used),
-    // rows 17..25 "cr", rows 26..34 "cb" (12 bytes used)
-    __shared__ uint32_t tile_all[kWavesPerGroup][35 * kTilePitch / 4];
-    __shared__ int zflag_all[kWavesPerGroup][8];  // per block: 1 if an entry sits at raster position 0
-    __shared__ uint32_t qt_all[kWavesPerGroup][64];  // this macroblock's scan / quantiser table: one coalesced load, not a per-coefficient gather
+    __shared__ int16_t cfh[64 * kLaneHalfwords];
+    __shared__ uint32_t qt_a[64], qt_b[64];  // default / this picture's custom scan + quantiser table
 
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep it (and everything derived) scalar
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     const int s = blockIdx.x;
-    const int mb = blockIdx.y * kWavesPerGroup + wave;
-    int* cf = cf_all[wave];
-    uint32_t* tile = tile_all[wave];
-    int* zflag = zflag_all[wave];
-    uint32_t* qt = qt_all[wave];
-
-    // The record is wave-uniform: fetch it as one 16-byte word and keep every field in scalar
-    // registers (indexing the struct per lane would bounce it through memory).
-    const uint4 rw = *reinterpret_cast<const uint4*>(mbrecs + ((size_t)s * max_pictures + pic) * kMbCount + mb);
-    const uint32_t w_base = __builtin_amdgcn_readfirstlane(rw.x);
-    const uint32_t w_cnt = __builtin_amdgcn_readfirstlane(rw.y);   // cnt[0..3]
-    const uint32_t w_misc = __builtin_amdgcn_readfirstlane(rw.z);  // cnt[4] | cnt[5] << 8 | flags << 16 | epoch << 24
-    const uint32_t w_mv = __builtin_amdgcn_readfirstlane(rw.w);    // mvx | mvy << 16
-    if ((w_misc >> 24) != (uint32_t)(epoch & 0xFF))
-        return;  // macroblock not covered by any slice (or picture absent): the slot keeps its content
-    struct {
-        uint32_t coef_base;
-        uint32_t flags;
-    } rec = {w_base, (w_misc >> 16) & 0xFF};
-
-    const int mb_y = mb / kMbW, mb_x = mb - mb_y * kMbW;
+    const int b_raw = blockIdx.y * 64 + lane;
+    const bool have = b_raw < kBlocksPerPicture;
+    const int b = have ? b_raw : kBlocksPerPicture - 1;
+    const int mb = b / 6, blk = b - mb * 6;
     uint8_t* cur = frames + ((size_t)s * ring_depth + cur_slot) * kFrameBytes;
     const uint8_t* ref = frames + ((size_t)s * ring_depth + ref_slot) * kFrameBytes;
-    const bool intra = rec.flags & 1;
 
-    const int pre1 = w_cnt & 0xFF, pre2 = pre1 + ((w_cnt >> 8) & 0xFF), pre3 = pre2 + ((w_cnt >> 16) & 0xFF),
-              pre4 = pre3 + (w_cnt >> 24), pre5 = pre4 + (w_misc & 0xFF);
-    const int total = pre5 + ((w_misc >> 8) & 0xFF);
-
-    // luma / chroma fetch geometry, predict() player.cpp:870-889
-    const int X = (mb_x << 5) + (int16_t)(w_mv & 0xFFFF), Y = (mb_y << 5) + (int16_t)(w_mv >> 16);
-    const int CX = X >> 1, CY = Y >> 1;  // chroma uses the floor of the halved POSITION
-    const int x0 = X >> 1, y0 = Y >> 1, cx0 = CX >> 1, cy0 = CY >> 1;
-
-    // ---- issue every global load up front: coefficients, then the reference window rows ------------
-    uint32_t ce = 0;
-    if (lane < total)
-        ce = coefs[rec.coef_base + lane];
-
-    const bool inside = x0 >= 0 && y0 >= 0 && x0 + 16 + (X & 1) <= EFX_FRAME_WIDTH &&
-                        y0 + 16 + (Y & 1) <= EFX_FRAME_HEIGHT && cx0 >= 0 && cy0 >= 0 &&
-                        cx0 + 8 + (CX & 1) <= EFX_FRAME_WIDTH / 2 && cy0 + 8 + (CY & 1) <= EFX_FRAME_HEIGHT / 2;
-    // rows / bytes of the window that are really needed: the 17th luma row and the 9th chroma rows
-    // only for a vertical half-pel, bytes 16..19 of a luma row only when the 16 (+1) pixels do not
-    // start on a dword boundary -- a zero vector touches 32 lines instead of 52
-    const bool need_tb = (x0 & 3) || (X & 1);
-    const bool row_live = lane < 17 ? (lane < 16 || (Y & 1)) : (((lane - 17) % 9) < 8 || (CY & 1));
-    const bool stage = !intra && inside && lane < 35;
     // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
-    uint32_t qv = 0;
-    if (total > 0)
-        qv = ((rec.flags & 0x80) ? qtab_custom + ((size_t)s * max_pictures + pic) * 64 : scan_tab)[lane];
-    uint4 ta = make_uint4(0, 0, 0, 0);
-    uint32_t tb = 0;
-    if (stage) {
-        // Every pixel that reaches the output is inside the picture.  One lane per window row, 20
-        // bytes from a 4-byte aligned address (the reference's _src_align copy, player.cpp:739-759):
-        // lanes 0..16 luma rows y0.., lanes 17..25 / 26..34 the chroma rows cy0.. of the two planes.
-        // A frame is 192 consecutive rows of 528 bytes; chroma row c of plane p sits in frame row
-        // (c >> 3) * 16 + (c & 7) + 8 * (p - 1) at byte 352.  Rows / bytes beyond the needed window
-        // may fall outside the frame; they are never used (the frame pool ends with slack).
-        int off;
-        if (lane < 17)
-            off = (y0 + lane) * kStride + (x0 & ~3);
-        else {
-            const int j = lane - 17, p2 = j >= 9, c = cy0 + (p2 ? j - 9 : j);
-            off = (((c >> 3) << 4) + (c & 7) + (p2 ? 8 : 0)) * kStride + EFX_FRAME_WIDTH + (cx0 & ~3);
+    qt_a[lane] = scan_tab[lane];
+    qt_b[lane] = qtab_custom[((size_t)s * max_pictures + pic) * 64 + lane];  // garbage unless a record says "custom": never used then
+
+    const uint4 rw = *reinterpret_cast<const uint4*>(mbrecs + ((size_t)s * max_pictures + pic) * kMbCount + mb);
+    const uint32_t w_base = rw.x, w_cnt = rw.y, w_misc = rw.z, w_mv = rw.w;
+    // a macroblock no slice covers (or an absent picture) keeps the slot's content
+    const bool live = have && (w_misc >> 24) == (uint32_t)(epoch & 0xFF);
+    const uint32_t flags = (w_misc >> 16) & 0xFF;
+    const bool intra = flags & 1;
+    const uint64_t cnts = ((uint64_t)(w_misc & 0xFFFF) << 32) | w_cnt;  // six byte counts
+    const int my_cnt = live ? (int)((cnts >> (blk * 8)) & 0xFF) : 0;
+    // entries of earlier blocks of the macroblock: sum of the lower `blk` bytes
+    uint32_t before = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+        before += (k < blk) ? (uint32_t)((cnts >> (k * 8)) & 0xFF) : 0u;
+    const uint32_t my_base = w_base + before;
+
+    // ---- geometry of this block's plane (predict(), player.cpp:870-889) -----------------------------
+    const int mb_y = mb / kMbW, mb_x = mb - mb_y * kMbW;
+    const int X = (mb_x << 5) + (int16_t)(w_mv & 0xFFFF), Y = (mb_y << 5) + (int16_t)(w_mv >> 16);
+    const bool luma = blk < 4;
+    // half-pel position of the block's first pixel in its plane; chroma uses the floor of the halved POSITION
+    const int PX = luma ? X + (blk & 1) * 16 : (X >> 1), PY = luma ? Y + (blk >> 1) * 16 : (Y >> 1);
+    const int px0 = PX >> 1, py0 = PY >> 1, hx = PX & 1, hy = PY & 1;
+    const int pw = luma ? EFX_FRAME_WIDTH : EFX_FRAME_WIDTH / 2, ph = luma ? EFX_FRAME_HEIGHT : EFX_FRAME_HEIGHT / 2;
+    const bool inside = px0 >= 0 && py0 >= 0 && px0 + 8 + hx <= pw && py0 + 8 + hy <= ph;
+    // byte offset of plane row y inside a frame: luma rows are linear; chroma row c of "cr" / "cb"
+    // sits in frame row (c >> 3) * 16 + (c & 7) [+ 8] at byte 352 (Frame, video.h:36-44)
+    const int chroma_base = (blk == 5 ? 8 : 0) * kStride + EFX_FRAME_WIDTH;
+    auto row_off = [&](int y) { return luma ? y * kStride : (((y >> 3) << 4) + (y & 7)) * kStride + chroma_base; };
+
+    // ---- issue the reference fetches first: nine rows of 12 bytes from a 4-byte aligned address ------
+    // (the reference's _src_align copy, player.cpp:739-759).  Bytes / rows beyond the 9 x 9 window
+    // may fall outside the frame; they are never used (the frame pool ends with slack).
+    uint32_t wa[9], wb[9], wc[9];
+    const bool want = live && !intra;
+    int16_t* mine = cfh + lane * kLaneHalfwords;
+    if (!__any(want && !inside)) {
+        const int xa = px0 & ~3;
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            wa[r] = wb[r] = wc[r] = 0;
+            if (want && (r < 8 || hy)) {
+                const uint32_t* p = reinterpret_cast<const uint32_t*>(ref + row_off(py0 + r) + xa);
+                wa[r] = p[0];
+                wb[r] = p[1];
+                wc[r] = p[2];
+            }
         }
-        if (row_live)
-            ta = *reinterpret_cast<const uint4*>(ref + off);
-        if (lane < 17 && need_tb && row_live)  // a chroma row's 12 bytes fit in the 16 already fetched
-            tb = *reinterpret_cast<const uint32_t*>(ref + off + 16);
+    } else {
+        // some vector of this wave points outside the picture (undefined in the reference): every lane
+        // builds its window pixel by pixel with clamped coordinates -- identical to the direct fetch
+        // for the windows that are inside -- through its private LDS block (not yet in use)
+        uint32_t* w32 = reinterpret_cast<uint32_t*>(mine);
+        for (int i = 0; i < 27; i++) {
+            const int r = i / 3, d = i - r * 3;
+            uint32_t word = 0;
+            if (want)
+                for (int k = 0; k < 4; k++) {
+                    const int yy = clampi(py0 + r, 0, ph - 1), xx = clampi((px0 & ~3) + d * 4 + k, 0, pw - 1);
+                    word |= (uint32_t)ref[row_off(yy) + xx] << (k * 8);
+                }
+            w32[i] = word;
+        }
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            wa[r] = w32[r * 3];
+            wb[r] = w32[r * 3 + 1];
+            wc[r] = w32[r * 3 + 2];
+        }
     }
 
-    // ---- scatter the coefficient entries ----------------------------------------------------
-    const int blk = lane >> 3, sub = lane & 7;  // lanes 0..47: (block, column) then (block, row)
-    const bool worker = lane < 48;
-    int my_cnt = 0;
-    if (total > 0) {  // wave-uniform: macroblocks without coefficients skip the whole residual path
-        if (worker) {
-            my_cnt = (int)(((blk < 4 ? w_cnt : w_misc) >> ((blk & 3) * 8)) & 0xFF);
-            if (my_cnt > 0) {
+    // ---- own coefficient entries -> private LDS block (dequantised, not yet pre-multiplied) ----------
+    {
+        uint32_t* z = reinterpret_cast<uint32_t*>(mine);
 #pragma unroll
-                for (int j = 0; j < 9; j++)
-                    cf[blk * kBlkPitch + sub * 9 + j] = 0;
-            }
-        }
-        if (lane < 8)
-            zflag[lane] = 0;
-        qt[lane] = qv;
-        wave_lds_sync();
-        // one lane per coefficient: dequantise (player.cpp:1110-1121) and drop it into its block.
-        const int qscale = (rec.flags >> 2) & 31;
-        for (int i = lane; i < total; i += 64) {
-            uint32_t e = (i < 64) ? ce : coefs[rec.coef_base + i];
-            int b = (i >= pre1) + (i >= pre2) + (i >= pre3) + (i >= pre4) + (i >= pre5);
-            int n = e & 63, level = (int)e >> 6;
-            uint32_t t = qt[n];
-            int val;
-            if (intra && n == 0)  // scan position 0 of an intra block is its DC entry (AC starts at 1)
-                val = level << 8;  // b[0] = dc << 8 (player.cpp:1065)
-            else {
-                int q = intra ? (int)((t >> 16) & 0xFF) : (int)(t >> 24);
-                val = level << 1;
-                if (!intra)
-                    val += (val < 0) ? -1 : 1;
-                // |2 level +- 1| <= 511, qscale <= 31, q <= 255: 24-bit products are exact
-                val = __mul24(__mul24(val, qscale), q);
-                val = (val + ((val >> 31) & 15)) >> 4;  // division by 16 truncating toward zero
-                if ((val & 1) == 0)
-                    val -= (val > 0) ? 1 : -1;
-                val = val > 2047 ? 2047 : (val < -2048 ? -2048 : val);
-                val = __mul24(val, (int)((t >> 8) & 0xFF));
-            }
-            cf[b * kBlkPitch + (t & 63)] = val;
-            if (n == 0)
-                zflag[b] = 1;
-        }
+        for (int k = 0; k < kLaneHalfwords / 2; k++)
+            z[k] = 0;
     }
-    if (stage) {
-        uint32_t* t = tile + lane * (kTilePitch / 4);
-        *reinterpret_cast<uint4*>(t) = ta;
-        t[4] = tb;
-    } else if (!intra && !inside) {
-        // vector points outside the picture (undefined in the reference): clamp per pixel
-        uint8_t* tt = reinterpret_cast<uint8_t*>(tile);
-        for (int i = lane; i < 17 * 17 + 2 * 9 * 9; i += 64) {
-            if (i < 289) {
-                int r = i / 17, c = i - r * 17;
-                int yy = clampi(y0 + r, 0, EFX_FRAME_HEIGHT - 1), xx = clampi(x0 + c, 0, EFX_FRAME_WIDTH - 1);
-                tt[r * kTilePitch + (x0 & 3) + c] = ref[luma_row_off(yy) + xx];
-            } else {
-                int j = i - 289;
-                int plane = 1 + j / 81;
-                j -= (plane - 1) * 81;
-                int r = j / 9, c = j - r * 9;
-                int yy = clampi(cy0 + r, 0, EFX_FRAME_HEIGHT / 2 - 1), xx = clampi(cx0 + c, 0, EFX_FRAME_WIDTH / 2 - 1);
-                tt[(17 + (plane - 1) * 9 + r) * kTilePitch + (cx0 & 3) + c] = ref[chroma_row_off(plane, yy) + xx];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // qt_a / qt_b written above, read below by other lanes
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t* qt = (flags & 0x80) ? qt_b : qt_a;
+    const int qscale = (flags >> 2) & 31;
+    int dc_raw = 0;       // intra DC value (entry at scan position 0), kept out of the int16 block
+    bool zf = false;      // an entry sits at scan position 0
+    for (int j0 = 0; __any(j0 < my_cnt); j0 += 4) {
+        uint32_t e[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            e[k] = (j0 + k < my_cnt) ? coefs[my_base + j0 + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (j0 + k < my_cnt) {
+                const int n = e[k] & 63, level = (int)e[k] >> 6;
+                const uint32_t t = qt[n];
+                zf |= n == 0;
+                if (intra && n == 0)
+                    dc_raw = level;  // b[0] = dc << 8 (player.cpp:1065)
+                else {
+                    // dequantise, player.cpp:1110-1121; |2 level +- 1| <= 511, qscale <= 31, q <= 255
+                    const int q = intra ? (int)((t >> 16) & 0xFF) : (int)(t >> 24);
+                    int val = level << 1;
+                    if (!intra)
+                        val += (val < 0) ? -1 : 1;
+                    val = __mul24(__mul24(val, qscale), q);
+                    val = (val + ((val >> 31) & 15)) >> 4;  // division by 16 truncating toward zero
+                    if ((val & 1) == 0)
+                        val -= (val > 0) ? 1 : -1;
+                    val = val > 2047 ? 2047 : (val < -2048 ? -2048 : val);
+                    mine[t & 63] = (int16_t)val;
+                }
             }
         }
     }
-    wave_lds_sync();
 
     // A block whose only coefficient sits at scan position 0 takes the reference's "n == 1"
     // shortcut (player.cpp:1133-1140): dc = b[0] >> 8 (floor), no IDCT; for intra blocks the
     // byte is replicated WITHOUT the 0..248 clamp (copy_block_dc, player.cpp:1175-1187).
-    const bool dc_only = my_cnt == 1 && zflag[blk] != 0;
-    const bool full = my_cnt > 0 && !dc_only;
+    const bool dc_only = my_cnt == 1 && zf;
 
-    // ---- column pass ---------------------------------------------------------------------------
-    if (total > 0) {
-        if (full) {
-            int* c = cf + blk * kBlkPitch + sub;
-            int v0 = c[0], v1 = c[8], v2 = c[16], v3 = c[24], v4 = c[32], v5 = c[40], v6 = c[48], v7 = c[56];
-            idct8(v0, v1, v2, v3, v4, v5, v6, v7);
-            c[0] = v0;
-            c[8] = v1;
-            c[16] = v2;
-            c[24] = v3;
-            c[32] = v4;
-            c[40] = v5;
-            c[48] = v6;
-            c[56] = v7;
+    // ---- 2-D IDCT in registers (idct(), player.cpp:922-996) --------------------------------------------
+    // ---- prediction of the 8 rows first: the 27 window registers die here, before the 64 IDCT
+    // registers come alive ---------------------------------------------------------------------------
+    uint32_t pr_lo[8], pr_hi[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        uint32_t p_lo = 0, p_hi = 0;
+        if (!intra) {
+            // ---- prediction: the four half-pel cases of mocomp(), player.cpp:767-820 ----------------
+            const uint32_t a0 = wa[r], a1 = wb[r], a2 = wc[r], b0 = wa[r + 1], b1 = wb[r + 1], b2 = wc[r + 1];
+            const int sh = px0 & 3;
+            // pixels 0..7 of the row (A) and of the next row (B); pixel 8 is byte `sh` of the third dword.
+            // All four half-pel cases of mocomp() are one expression, (a + b + c + d + 2) >> 2 per byte
+            // with  b = the pixel to the right if hx else a,  c = the pixel below if hy else a,
+            // d = below-right / below / right / a:  with equal operands it degenerates exactly to
+            // (a + b + 1) >> 1 and to a.  Lanes of one wave carry different vectors, so a branch per
+            // case would execute all four.
+            const uint32_t A_lo = __builtin_amdgcn_alignbit(a1, a0, sh * 8), A_hi = __builtin_amdgcn_alignbit(a2, a1, sh * 8);
+            const uint32_t B_lo = __builtin_amdgcn_alignbit(b1, b0, sh * 8), B_hi = __builtin_amdgcn_alignbit(b2, b1, sh * 8);
+            const uint32_t A9 = (a2 >> (sh * 8)) & 0xFF, B9 = (b2 >> (sh * 8)) & 0xFF;
+            const uint32_t Ar_lo = __builtin_amdgcn_alignbit(A_hi, A_lo, 8), Ar_hi = (A_hi >> 8) | (A9 << 24);
+            const uint32_t Br_lo = __builtin_amdgcn_alignbit(B_hi, B_lo, 8), Br_hi = (B_hi >> 8) | (B9 << 24);
+            const uint32_t b_lo = hx ? Ar_lo : A_lo, b_hi = hx ? Ar_hi : A_hi;
+            const uint32_t c_lo = hy ? B_lo : A_lo, c_hi = hy ? B_hi : A_hi;
+            const uint32_t d_lo = hy ? (hx ? Br_lo : B_lo) : b_lo, d_hi = hy ? (hx ? Br_hi : B_hi) : b_hi;
+            p_lo = avg4_lerp(A_lo, b_lo, c_lo, d_lo);
+            p_hi = avg4_lerp(A_hi, b_hi, c_hi, d_hi);
         }
-        wave_lds_sync();
+        pr_lo[r] = p_lo;
+        pr_hi[r] = p_hi;
     }
 
-    if (!worker)
-        return;
+    // Blocks without entries run the butterflies on zeros (which stay zero); the shortcut value of
+    // a dc_only block replaces the IDCT's afterwards.
+    int v[64];
+    int dc_short = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        // column c: eight int16 from the private block, scaled by immediates, one butterfly
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            v[r * 8 + c] = __mul24((int)mine[r * 8 + c], premul_at(r, c));
+        if (c == 0) {
+            v[0] = intra ? (dc_raw << 8) : v[0];
+            dc_short = v[0] >> 8;
+        }
+        idct8(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
+        // one butterfly at a time (volatile asm statements keep their order): with all sixteen in
+        // flight the temporaries push the kernel past 128 registers and an occupancy step
+        asm volatile("" : "+v"(v[c]), "+v"(v[8 + c]), "+v"(v[16 + c]), "+v"(v[24 + c]), "+v"(v[32 + c]), "+v"(v[40 + c]),
+                     "+v"(v[48 + c]), "+v"(v[56 + c]));
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        idct8(v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            v[r * 8 + c] = dc_only ? dc_short : (v[r * 8 + c] + 128) >> 8;
+        asm volatile("" : "+v"(v[r * 8]), "+v"(v[r * 8 + 1]), "+v"(v[r * 8 + 2]), "+v"(v[r * 8 + 3]), "+v"(v[r * 8 + 4]),
+                     "+v"(v[r * 8 + 5]), "+v"(v[r * 8 + 6]), "+v"(v[r * 8 + 7]));
+    }
 
-    // ---- row pass --------------------------------------------------------------------------------
-    int r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0;
-    if (full) {
-        const int4* c = reinterpret_cast<const int4*>(cf + blk * kBlkPitch + sub * 8);
-        int4 a = c[0], b = c[1];
-        r0 = a.x, r1 = a.y, r2 = a.z, r3 = a.w, r4 = b.x, r5 = b.y, r6 = b.z, r7 = b.w;
-        idct8(r0, r1, r2, r3, r4, r5, r6, r7);
-        r0 = (r0 + 128) >> 8;
-        r1 = (r1 + 128) >> 8;
-        r2 = (r2 + 128) >> 8;
-        r3 = (r3 + 128) >> 8;
-        r4 = (r4 + 128) >> 8;
-        r5 = (r5 + 128) >> 8;
-        r6 = (r6 + 128) >> 8;
-        r7 = (r7 + 128) >> 8;
-    } else if (dc_only)
-        r0 = r1 = r2 = r3 = r4 = r5 = r6 = r7 = cf[blk * kBlkPitch] >> 8;
+    // destination rows of the block (block(), player.cpp:1124-1131)
+    const int dst0 = luma ? (mb_y * 16 + (blk >> 1) * 8) * kStride + mb_x * 16 + (blk & 1) * 8
+                          : mb_y * kStripBytes + (blk - 4) * 8 * kStride + EFX_FRAME_WIDTH + mb_x * 8;
+    // an intra block the parser abandoned is not stored (player.cpp:1106-1107)
+    const bool stored = live && !(intra && my_cnt == 0);
+    const bool clamped = !(intra && dc_only);
 
-    // destination of this lane's 8 pixels (block(), player.cpp:1124-1131)
-    const int row = sub;
-    int dst_off;
-    if (blk < 4)
-        dst_off = mb_y * kStripBytes + ((blk >> 1) * 8 + row) * kStride + mb_x * 16 + (blk & 1) * 8;
-    else
-        dst_off = mb_y * kStripBytes + ((blk - 4) * 8 + row) * kStride + EFX_FRAME_WIDTH + mb_x * 8;
-    uint2* dst = reinterpret_cast<uint2*>(cur + dst_off);
-
-    uint32_t lo = 0, hi = 0;
-    bool stored = true;
-    if (intra) {
-        if (my_cnt == 0)
-            stored = false;  // block abandoned by the parser: nothing is stored (player.cpp:1106-1107)
-        else if (dc_only) {
-            uint32_t w = (uint32_t)r0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t p_lo = pr_lo[r], p_hi = pr_hi[r];
+        // copy_block[_dc] / add_block[_dc], player.cpp:1151-1236
+        uint32_t lo, hi;
+        if (my_cnt == 0) {  // prediction only (skipped macroblock, or block without coefficients)
+            lo = p_lo;
+            hi = p_hi;
+        } else if (!clamped) {
+            uint32_t w = (uint32_t)v[0];
             w |= w << 8;
             w |= w << 16;
             lo = hi = w;
         } else {
-            lo = (uint32_t)clampi(r0, 0, 248) | ((uint32_t)clampi(r1, 0, 248) << 8) | ((uint32_t)clampi(r2, 0, 248) << 16) |
-                 ((uint32_t)clampi(r3, 0, 248) << 24);
-            hi = (uint32_t)clampi(r4, 0, 248) | ((uint32_t)clampi(r5, 0, 248) << 8) | ((uint32_t)clampi(r6, 0, 248) << 16) |
-                 ((uint32_t)clampi(r7, 0, 248) << 24);
+            const int* q = v + r * 8;
+            lo = (uint32_t)clampi(q[0] + (int)(p_lo & 0xFF), 0, 248) | ((uint32_t)clampi(q[1] + (int)((p_lo >> 8) & 0xFF), 0, 248) << 8) |
+                 ((uint32_t)clampi(q[2] + (int)((p_lo >> 16) & 0xFF), 0, 248) << 16) |
+                 ((uint32_t)clampi(q[3] + (int)(p_lo >> 24), 0, 248) << 24);
+            hi = (uint32_t)clampi(q[4] + (int)(p_hi & 0xFF), 0, 248) | ((uint32_t)clampi(q[5] + (int)((p_hi >> 8) & 0xFF), 0, 248) << 8) |
+                 ((uint32_t)clampi(q[6] + (int)((p_hi >> 16) & 0xFF), 0, 248) << 16) |
+                 ((uint32_t)clampi(q[7] + (int)(p_hi >> 24), 0, 248) << 24);
         }
-    } else {
-        // ---- prediction: the four half-pel cases of mocomp(), player.cpp:767-820 ------------------
-        uint32_t p_lo, p_hi;
-        {
-            const int pitch = kTilePitch / 4;
-            const bool luma = blk < 4;
-            const uint32_t* t = tile + (luma ? (blk >> 1) * 8 + row : 17 + (blk - 4) * 9 + row) * pitch;
-            const int col = luma ? (x0 & 3) + (blk & 1) * 8 : (cx0 & 3);
-            const int hx = (luma ? X : CX) & 1, hy = (luma ? Y : CY) & 1;
-            const int w0 = col >> 2, sh = col & 3;
-            // 12 bytes starting at the dword holding `col`, for this row and the next
-            uint32_t a0 = t[w0], a1 = t[w0 + 1], a2 = t[w0 + 2];
-            // pixels col..col+7; pixel col+8 is byte `sh` of the third dword
-            uint32_t A_lo = __builtin_amdgcn_alignbit(a1, a0, sh * 8), A_hi = __builtin_amdgcn_alignbit(a2, a1, sh * 8);
-            if (!hy) {
-                if (!hx) {
-                    p_lo = A_lo;
-                    p_hi = A_hi;
-                } else {
-                    uint32_t A9 = (a2 >> (sh * 8)) & 0xFF;
-                    p_lo = avg_up(A_lo, (A_lo >> 8) | (A_hi << 24));
-                    p_hi = avg_up(A_hi, (A_hi >> 8) | (A9 << 24));
-                }
-            } else {
-                uint32_t b0 = t[pitch + w0], b1 = t[pitch + w0 + 1], b2 = t[pitch + w0 + 2];
-                uint32_t B_lo = __builtin_amdgcn_alignbit(b1, b0, sh * 8), B_hi = __builtin_amdgcn_alignbit(b2, b1, sh * 8);
-                if (!hx) {
-                    p_lo = avg_up(A_lo, B_lo);
-                    p_hi = avg_up(A_hi, B_hi);
-                } else {
-                    uint32_t A9 = (a2 >> (sh * 8)) & 0xFF, B9 = (b2 >> (sh * 8)) & 0xFF;
-                    p_lo = avg4(A_lo, (A_lo >> 8) | (A_hi << 24), B_lo, (B_lo >> 8) | (B_hi << 24));
-                    p_hi = avg4(A_hi, (A_hi >> 8) | (A9 << 24), B_hi, (B_hi >> 8) | (B9 << 24));
-                }
-            }
-        }
-        if (my_cnt == 0) {  // prediction only (skipped macroblock, or block without coefficients)
-            lo = p_lo;
-            hi = p_hi;
-        } else {  // add_block / add_block_dc, player.cpp:1189-1236
-            lo = (uint32_t)clampi(r0 + (int)(p_lo & 0xFF), 0, 248) | ((uint32_t)clampi(r1 + (int)((p_lo >> 8) & 0xFF), 0, 248) << 8) |
-                 ((uint32_t)clampi(r2 + (int)((p_lo >> 16) & 0xFF), 0, 248) << 16) |
-                 ((uint32_t)clampi(r3 + (int)(p_lo >> 24), 0, 248) << 24);
-            hi = (uint32_t)clampi(r4 + (int)(p_hi & 0xFF), 0, 248) | ((uint32_t)clampi(r5 + (int)((p_hi >> 8) & 0xFF), 0, 248) << 8) |
-                 ((uint32_t)clampi(r6 + (int)((p_hi >> 16) & 0xFF), 0, 248) << 16) |
-                 ((uint32_t)clampi(r7 + (int)(p_hi >> 24), 0, 248) << 24);
-        }
+        if (stored)
+            *reinterpret_cast<uint2*>(cur + dst0 + r * kStride) = make_uint2(lo, hi);
     }
-
-    // ---- store --------------------------------------------------------------------------------------
-    // A luma row of the macroblock is 16 contiguous bytes (blocks 0|1, 2|3).  The lane of the left
-    // block fetches the right block's 8 bytes from lane + 8 (same 16-lane DPP row) and issues one
-    // 16-byte store: 16 + 16 row accesses per macroblock instead of 32 + 16.  Only an intra
-    // macroblock with an abandoned block falls back to per-block stores.
-    const bool all_stored = !intra || (pre1 > 0 && pre2 > pre1 && pre3 > pre2 && pre4 > pre3);  // wave-uniform (luma blocks)
-    if (all_stored) {
-        const uint32_t q_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x108, 0xF, 0xF, false);  // row_shl:8
-        const uint32_t q_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x108, 0xF, 0xF, false);
-        if (blk < 4) {
-            if (!(blk & 1))
-                *reinterpret_cast<uint4*>(dst) = make_uint4(lo, hi, q_lo, q_hi);
-        } else if (stored)
-            *dst = make_uint2(lo, hi);
-    } else if (stored)
-        *dst = make_uint2(lo, hi);
 }
 
 // FNV-1a-64 of whole ring frames, one lane per frame (verification helper, not on the timed path)
