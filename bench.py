@@ -223,6 +223,7 @@ def main():
                                    f"ids {first}..{first + S - 1} per rank (BASELINE configs[2]; shard of configs[4])",
                        "streams_per_gpu": S, "pictures_per_stream": P, "es_bytes_per_gpu": es_bytes,
                        "mean_bytes_per_picture": es_bytes / (S * P), "parallelism": f"stream-partition x{world}",
+                       "coefficients_per_gpu": int(n_coefs),
                        "ring_depth": 2},
             "roofline": {"bound": "hbm", "kernel": names[k], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -294,10 +294,10 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         pr_hi[r] = p_hi;
     }
 
-    // Blocks without entries run the butterflies on zeros (which stay zero); the shortcut value of
-    // a dc_only block replaces the IDCT's afterwards.
+    // Blocks without entries run the butterflies on zeros (which stay zero).  A dc_only block has its
+    // single value X at raster position 0; the butterflies turn that into X at all 64 positions
+    // exactly, so clearing X's low byte makes the final (x + 128) >> 8 deliver X >> 8, the shortcut.
     int v[64];
-    int dc_short = 0;
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         // column c: eight int16 from the private block, scaled by immediates, one butterfly
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             v[r * 8 + c] = __mul24((int)mine[r * 8 + c], premul_at(r, c));
         if (c == 0) {
             v[0] = intra ? (dc_raw << 8) : v[0];
-            dc_short = v[0] >> 8;
+            v[0] = dc_only ? (v[0] & ~0xFF) : v[0];
         }
         idct8(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
         // one butterfly at a time (volatile asm statements keep their order): with all sixteen in
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         idct8(v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
 #pragma unroll
         for (int c = 0; c < 8; c++)
-            v[r * 8 + c] = dc_only ? dc_short : (v[r * 8 + c] + 128) >> 8;
+            v[r * 8 + c] = (v[r * 8 + c] + 128) >> 8;
         asm volatile("" : "+v"(v[r * 8]), "+v"(v[r * 8 + 1]), "+v"(v[r * 8 + 2]), "+v"(v[r * 8 + 3]), "+v"(v[r * 8 + 4]),
                      "+v"(v[r * 8 + 5]), "+v"(v[r * 8 + 6]), "+v"(v[r * 8 + 7]));
     }
