@@ -8,7 +8,7 @@
 //   k_slice_emit   dense slice descriptors
 //   k_parse        one lane per slice: VLC parse + dequant -> macroblock records + coefficient list
 //                                                                            (player.cpp:1238-1316,999-1122,891-920)
-//   k_recon        one wave per macroblock, one launch per picture index: IDCT + half-pel
+//   k_recon        one lane per 8x8 block, one launch per picture index: IDCT + half-pel
 //                  motion compensation + clamp + strip-layout store          (player.cpp:922-996,732-889,1151-1236)
 #pragma once
 #include <cstdint>
@@ -17,7 +17,6 @@ namespace efx {
 
 constexpr int kMbW = 22, kMbH = 12, kMbCount = 264;
 constexpr int kStride = 528, kStripBytes = 8448, kFrameBytes = 101376;
-constexpr int kReconThreads = 256;         // k_recon workgroup: 4 independent waves, one macroblock each (264 = 4 x 66)
 constexpr int kMaxSlicesPerPicture = 16;   // slice start codes kept per picture
 constexpr int kMaxUnitsPerStream = 4096;   // start codes indexed per stream per decode
 constexpr int kCoefsPerEsByte = 3;         // a coefficient costs >= 3 bits (2 + EOB for singletons)

@@ -5,16 +5,15 @@
 // Restates idct() (reference src/player.cpp:922-996), predict()/predict_zero()/mocomp()
 // (732-889) and copy_block/add_block[_dc] (1151-1236):
 //
-//   * the macroblock's compact coefficient entries (k_parse) are scattered into a 6 x 64 int32
-//     LDS tile (row pitch padded to 72 words: conflict-free column reads);
-//   * lanes 0..47 each run one 8-point column butterfly, then one 8-point row butterfly
-//     (6 blocks x 8) -- the same scaled integer AAN arithmetic as the reference, transposition
-//     through LDS;
-//   * for predicted macroblocks the 17 x 20-byte luma and two 9 x 12-byte chroma reference
-//     windows are staged in LDS with aligned dword loads (the reference's _src_align staging,
-//     player.cpp:739-759) and the four half-pel cases are evaluated with packed-byte arithmetic;
-//   * each lane adds its 8 residuals to its 8 predicted pixels, clamps to 0..248 (PIN,
-//     player.cpp:183-236) and issues one 8-byte store into the 16-line strip layout
+//   * a lane dequantises its block's compact coefficient entries (k_parse) into a private
+//     64 x int16 LDS block, reads them back into 64 registers (scaled by the pre-multipliers) and
+//     runs 8 column + 8 row butterflies there -- the same scaled integer AAN arithmetic as the
+//     reference;
+//   * for predicted blocks nine 12-byte reference rows are fetched with aligned dword loads (the
+//     reference's _src_align staging, player.cpp:739-759) and the four half-pel cases are one
+//     branch-free packed-byte expression;
+//   * the lane adds its 64 residuals to its 64 predicted pixels, clamps to 0..248 (PIN,
+//     player.cpp:183-236) and issues eight 8-byte stores into the 16-line strip layout
 //     (Frame, src/video.h:36-44).
 //
 #include <hip/hip_runtime.h>
@@ -26,8 +25,6 @@ namespace efx {
 
 namespace {
 
-constexpr int kBlkPitch = 72;   // ints per block in LDS (64 + 8 pad)
-constexpr int kTilePitch = 32;  // bytes per staged window row (16-byte aligned rows)
 
 // one 8-point pass of the reference's scaled integer IDCT (player.cpp:938-995).
 // The products use the full-rate 24-bit multiplier (v_mul_i32_i24 / v_mad_i32_i24; a 32-bit
