@@ -126,6 +126,9 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
 {
     __shared__ int16_t cfh[64 * kLaneHalfwords];
     __shared__ uint32_t qt_a[64], qt_b[64];  // default / this picture's custom scan + quantiser table
+    __shared__ uint32_t s_pre[64], s_base[64], s_info[64];  // per block: entries before it in the wave, first entry, flags
+    __shared__ int s_dc[64];
+    __shared__ uint32_t s_zf[64];
 
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
@@ -220,39 +223,60 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // qt_a / qt_b written above, read below by other lanes
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t* qt = (flags & 0x80) ? qt_b : qt_a;
-    const int qscale = (flags >> 2) & 31;
-    int dc_raw = 0;       // intra DC value (entry at scan position 0), kept out of the int16 block
-    bool zf = false;      // an entry sits at scan position 0
-    for (int j0 = 0; __any(j0 < my_cnt); j0 += 4) {
-        uint32_t e[4];
+    // The 64 blocks of the wave hold very different numbers of entries (3 on average, a dozen at the
+    // maximum), so a loop in which every lane walks its own list runs at a quarter of the lanes.
+    // Instead the wave's entries are dealt out one per lane: entry i belongs to the last lane whose
+    // exclusive prefix count is <= i (six-step search in the prefix array), is dequantised with that
+    // lane's parameters and lands in that lane's block.
+    uint32_t incl = (uint32_t)my_cnt;
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            e[k] = (j0 + k < my_cnt) ? coefs[my_base + j0 + k] : 0u;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        incl += lane >= d ? o : 0u;
+    }
+    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    s_pre[lane] = incl - (uint32_t)my_cnt;
+    s_base[lane] = my_base;
+    s_info[lane] = flags;  // bit0 intra, bits 2-6 quantiser_scale, bit7 custom matrices
+    s_dc[lane] = 0;
+    s_zf[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t i = lane; i < total; i += 64) {
+        int L = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (j0 + k < my_cnt) {
-                const int n = e[k] & 63, level = (int)e[k] >> 6;
-                const uint32_t t = qt[n];
-                zf |= n == 0;
-                if (intra && n == 0)
-                    dc_raw = level;  // b[0] = dc << 8 (player.cpp:1065)
-                else {
-                    // dequantise, player.cpp:1110-1121; |2 level +- 1| <= 511, qscale <= 31, q <= 255
-                    const int q = intra ? (int)((t >> 16) & 0xFF) : (int)(t >> 24);
-                    int val = level << 1;
-                    if (!intra)
-                        val += (val < 0) ? -1 : 1;
-                    val = __mul24(__mul24(val, qscale), q);
-                    val = (val + ((val >> 31) & 15)) >> 4;  // division by 16 truncating toward zero
-                    if ((val & 1) == 0)
-                        val -= (val > 0) ? 1 : -1;
-                    val = val > 2047 ? 2047 : (val < -2048 ? -2048 : val);
-                    mine[t & 63] = (int16_t)val;
-                }
-            }
+        for (int step = 32; step > 0; step >>= 1)
+            L += s_pre[L + step] <= i ? step : 0;
+        const uint32_t e = coefs[s_base[L] + (i - s_pre[L])];
+        const uint32_t f = s_info[L];
+        const bool o_intra = f & 1;
+        const int n = e & 63, level = (int)e >> 6;
+        // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
+        const uint32_t t = ((f & 0x80) ? qt_b : qt_a)[n];
+        if (n == 0)
+            s_zf[L] = 1;
+        if (o_intra && n == 0)
+            s_dc[L] = level;  // b[0] = dc << 8 (player.cpp:1065); kept out of the int16 block
+        else {
+            // dequantise, player.cpp:1110-1121; |2 level +- 1| <= 511, qscale <= 31, q <= 255
+            const int q = o_intra ? (int)((t >> 16) & 0xFF) : (int)(t >> 24);
+            int val = level << 1;
+            if (!o_intra)
+                val += (val < 0) ? -1 : 1;
+            val = __mul24(__mul24(val, (int)((f >> 2) & 31)), q);
+            val = (val + ((val >> 31) & 15)) >> 4;  // division by 16 truncating toward zero
+            if ((val & 1) == 0)
+                val -= (val > 0) ? 1 : -1;
+            val = val > 2047 ? 2047 : (val < -2048 ? -2048 : val);
+            cfh[L * kLaneHalfwords + (t & 63)] = (int16_t)val;
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int dc_raw = s_dc[lane];   // intra DC value (entry at scan position 0)
+    const bool zf = s_zf[lane] != 0;  // an entry sits at scan position 0
 
     // A block whose only coefficient sits at scan position 0 takes the reference's "n == 1"
     // shortcut (player.cpp:1133-1140): dc = b[0] >> 8 (floor), no IDCT; for intra blocks the
