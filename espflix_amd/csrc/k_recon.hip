@@ -126,9 +126,12 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
 {
     __shared__ int16_t cfh[64 * kLaneHalfwords];
     __shared__ uint32_t qt_a[64], qt_b[64];  // default / this picture's custom scan + quantiser table
-    __shared__ uint32_t s_pre[64], s_base[64], s_info[64];  // per block: entries before it in the wave, first entry, flags
+    // per block: entries before it in the wave (<= 64 * 64), first entry, flags, DC level, "entry at scan position 0".
+    // Kept narrow: LDS, not registers, bounds the occupancy (9.7 KB per wave -> 16 waves per CU)
+    __shared__ uint16_t s_pre[64];
+    __shared__ uint32_t s_base[64];
+    __shared__ uint8_t s_info[64], s_zf[64];
     __shared__ int s_dc[64];
-    __shared__ uint32_t s_zf[64];
 
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
@@ -235,9 +238,9 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         incl += lane >= d ? o : 0u;
     }
     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-    s_pre[lane] = incl - (uint32_t)my_cnt;
+    s_pre[lane] = (uint16_t)(incl - (uint32_t)my_cnt);
     s_base[lane] = my_base;
-    s_info[lane] = flags;  // bit0 intra, bits 2-6 quantiser_scale, bit7 custom matrices
+    s_info[lane] = (uint8_t)flags;  // bit0 intra, bits 2-6 quantiser_scale, bit7 custom matrices
     s_dc[lane] = 0;
     s_zf[lane] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -247,8 +250,8 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         int L = 0;
 #pragma unroll
         for (int step = 32; step > 0; step >>= 1)
-            L += s_pre[L + step] <= i ? step : 0;
-        const uint32_t e = coefs[s_base[L] + (i - s_pre[L])];
+            L += (uint32_t)s_pre[L + step] <= i ? step : 0;
+        const uint32_t e = coefs[s_base[L] + (i - (uint32_t)s_pre[L])];
         const uint32_t f = s_info[L];
         const bool o_intra = f & 1;
         const int n = e & 63, level = (int)e >> 6;
