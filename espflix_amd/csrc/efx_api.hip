@@ -31,7 +31,7 @@ __global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const
 __global__ void k_recon(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, int, int, int);
 __global__ void k_frame_hash(const uint8_t*, int, uint64_t*);
 __global__ void k_fill(uint32_t*, uint32_t, size_t);
-__global__ void k_composite(const uint8_t*, const VideoTables*, FieldArgs, uint16_t*);
+__global__ void k_composite(const uint8_t*, const VideoTables*, const VideoLineTemplates*, FieldArgs, uint16_t*);
 __global__ void k_pdm(const int16_t*, int, int, int32_t*, uint16_t*);
 __global__ void k_sbc(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int);
 #ifdef EFX_PARSE_PROFILE
@@ -114,6 +114,7 @@ struct efx_ctx {
     uint64_t calls = 0;
     hipStream_t parse_streams[kParseStreams] = {nullptr, nullptr};
     VideoTables* d_video[2] = {nullptr, nullptr};  // [0] PAL, [1] NTSC
+    VideoLineTemplates* d_video_lines[2] = {nullptr, nullptr};
     SbcTables* d_sbc_tables = nullptr;
     uint64_t* d_hash = nullptr;
 
@@ -237,6 +238,8 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     A(dalloc(&ctx->d_frames, n * D * kFrameBytes + 8192));  // slack: k_recon's window rows may over-read the last frame
     A(dalloc(&ctx->d_video[0], 1));
     A(dalloc(&ctx->d_video[1], 1));
+    A(dalloc(&ctx->d_video_lines[0], 1));
+    A(dalloc(&ctx->d_video_lines[1], 1));
     A(dalloc(&ctx->d_hash, n * D));
     A(dalloc(&ctx->d_sbc_tables, 1));
     A(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_es), ctx->es_cap, hipHostMallocDefault));
@@ -252,6 +255,10 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         VideoTables vt;
         build_video_tables(ntsc, &vt);
         A(hipMemcpy(ctx->d_video[ntsc], &vt, sizeof(vt), hipMemcpyHostToDevice));
+        VideoLineTemplates* lt = new VideoLineTemplates;
+        build_video_line_templates(&vt, lt);
+        A(hipMemcpy(ctx->d_video_lines[ntsc], lt, sizeof(*lt), hipMemcpyHostToDevice));
+        delete lt;
     }
     {
         SbcTables st;
@@ -281,7 +288,7 @@ void efx_destroy(efx_ctx* ctx)
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     void* bufs[] = {ctx->d_es,   ctx->d_stream_off, ctx->d_pics,  ctx->d_slices_tmp, ctx->d_qtab,     ctx->d_tables,
-                    ctx->d_slice_base, ctx->d_descs, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_hash,
+                    ctx->d_slice_base, ctx->d_descs, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0], ctx->d_video_lines[1], ctx->d_hash,
                     ctx->d_ts, ctx->d_ts_len, ctx->d_pkt_base, ctx->d_es_len, ctx->d_pes_count, ctx->d_pes, ctx->d_sbc_tables, ctx->d_idx_info, ctx->d_ts_off, ctx->d_idx_len, ctx->d_idx_base, ctx->d_idx_seq};
     for (auto& ev : ctx->ev_demux)
         if (ev)
@@ -690,8 +697,8 @@ int efx_composite_fields_ex(efx_ctx* ctx, const efx_field_opts* o, uint16_t* dst
     a.overlay_progress = o->overlay_progress;
     const int lines = o->ntsc ? 262 : 312;
     const int blocks = o->n_streams * ((lines + 7) / 8);
-    hipLaunchKernelGGL(k_composite, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_frames, ctx->d_video[o->ntsc ? 1 : 0], a,
-                       dst_device);
+    hipLaunchKernelGGL(k_composite, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_frames, ctx->d_video[o->ntsc ? 1 : 0],
+                       ctx->d_video_lines[o->ntsc ? 1 : 0], a, dst_device);
     EFX_HIP(hipGetLastError());
     return EFX_OK;
 }

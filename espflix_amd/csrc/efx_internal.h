@@ -98,6 +98,16 @@ struct VideoTables {
     uint32_t color_tab[768];
 };
 
+// Every sample of a field that is not picture or overlay: whole lines as video_isr leaves them in
+// the DMA buffers (sync, burst, black; vertical blanking; the PAL half-line syncs), one template per
+// line kind.  k_composite copies 16 bytes from here instead of re-deriving eight samples.
+constexpr int kLineTemplates = 6;      // 0/1 normal line (PAL: _line_counter odd / even), 2 NTSC vertical blanking, 3..5 PAL sync types 0, 2, 3
+constexpr int kLineTemplateWidth = 1152;  // >= 1136 samples, 16-byte multiple
+struct VideoLineTemplates {
+    uint16_t tpl[kLineTemplates][kLineTemplateWidth];
+};
+void build_video_line_templates(const VideoTables* v, VideoLineTemplates* out);
+
 // per-stream result of k_ts_sequences
 struct IdxInfo {
     int64_t first_pts, last_pts;  // origin (PTS of the first sequence start), PTS of the last video PES

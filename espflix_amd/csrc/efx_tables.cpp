@@ -156,6 +156,55 @@ void build_video_tables(int ntsc, VideoTables* t)
     }
 }
 
+// One sample of a line that carries no picture data at that position (sync 889-893, burst 806-837,
+// burst_pal 636-644, blanking 904-914, pal_sync 918-934 of src/video.cpp), as a function of the line
+// kind: 0 normal line (sync, burst, black), 1 NTSC vertical blanking, 2 PAL sync lines 304..311.
+static uint32_t line_sample(const VideoTables& v, int kind, int i, int line_counter)
+{
+    if (kind == 0) {
+        if (i < v.hsync)
+            return v.sync_level;
+        if (v.pal) {
+            int j = i - v.burst_start;
+            if (j >= 0 && j < v.burst_width) {
+                const int16_t* b = (line_counter & 1) ? v.burst0 : v.burst1;
+                return (uint16_t)b[j ^ 1];
+            }
+        } else {
+            int j = i - v.hsync;
+            if (j < 40) {  // 10 cycles of burst, 4 samples per cycle (video.cpp:817-822)
+                int ph = j & 3;
+                uint32_t bl = v.blanking_level;
+                return ph == 0 ? bl + bl / 2 : (ph == 2 ? bl - bl / 2 : bl);
+            }
+        }
+        return v.black_level;
+    }
+    if (kind == 1)
+        return i < v.hsync_long ? v.sync_level : v.blanking_level;
+    const uint32_t types = 0x00233000u;  // _sync_type[8] = {0,0,0,3,3,2,0,0}, one nibble each
+    int t = (types >> ((line_counter - 1 - 304) * 4)) & 0xF;
+    int half = v.line_width / 2;
+    int h = i >= half;
+    int sw = (t & (h ? 1 : 2)) ? v.hsync_long : v.hsync_short;
+    return (i - h * half) < sw ? v.sync_level : v.blanking_level;
+}
+
+void build_video_line_templates(const VideoTables* v, VideoLineTemplates* out)
+{
+    std::memset(out, 0, sizeof(*out));
+    for (int i = 0; i < v->line_width; i++) {
+        out->tpl[0][i] = (uint16_t)line_sample(*v, 0, i, 1);  // _line_counter odd
+        out->tpl[1][i] = (uint16_t)line_sample(*v, 0, i, 2);  // even (differs for PAL only)
+        out->tpl[2][i] = (uint16_t)line_sample(*v, 1, i, 0);
+        if (v->pal) {
+            out->tpl[3][i] = (uint16_t)line_sample(*v, 2, i, 304 + 1);      // type 0
+            out->tpl[4][i] = (uint16_t)line_sample(*v, 2, i, 304 + 5 + 1);  // type 2
+            out->tpl[5][i] = (uint16_t)line_sample(*v, 2, i, 304 + 3 + 1);  // type 3
+        }
+    }
+}
+
 // SBC synthesis matrix and prototype window (sbc_decoder.cpp:41-71) from their A2DP Appendix B
 // definitions: N[i][k] = cos((i + 4)(2k + 1) pi / 16) in 16.16, and the 80-tap prototype filter
 // Proto_8_80 scaled by -8 in 1.15, both rounded toward minus infinity.  The filter is symmetric

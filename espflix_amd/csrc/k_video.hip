@@ -36,44 +36,11 @@ __device__ inline int chroma_row_off(int plane, int c)
 __constant__ uint32_t c_dither[8] = {  // dither4x4, video.cpp:673-683: 4 lines x 2 frame phases
     0x00020301, 0x03010002, 0x02030100, 0x01000203, 0x03010002, 0x00020301, 0x01000203, 0x02030100};
 
-// sample i of a line that carries no picture data at that position
-__device__ inline uint32_t line_sample(const VideoTables& v, int kind, int i, int line_counter)
-{
-    // kind 0: normal line (sync, burst, black)   1: NTSC vertical blanking   2: PAL sync lines
-    if (kind == 0) {
-        if (i < v.hsync)
-            return v.sync_level;
-        if (v.pal) {
-            int j = i - v.burst_start;
-            if (j >= 0 && j < v.burst_width) {
-                const int16_t* b = (line_counter & 1) ? v.burst0 : v.burst1;
-                return (uint16_t)b[j ^ 1];
-            }
-        } else {
-            int j = i - v.hsync;
-            if (j < 40) {  // 10 cycles of burst, 4 samples per cycle (video.cpp:817-822)
-                int ph = j & 3;
-                uint32_t bl = v.blanking_level;
-                return ph == 0 ? bl + bl / 2 : (ph == 2 ? bl - bl / 2 : bl);
-            }
-        }
-        return v.black_level;
-    }
-    if (kind == 1)
-        return i < v.hsync_long ? v.sync_level : v.blanking_level;
-    // PAL lines 304..311: two half lines with long or short sync (video.cpp:918-934)
-    const uint32_t types = 0x00233000u;  // _sync_type[8] = {0,0,0,3,3,2,0,0}, one nibble each
-    int t = (types >> ((line_counter - 1 - 304) * 4)) & 0xF;
-    int half = v.line_width / 2;
-    int h = i >= half;
-    int sw = (t & (h ? 1 : 2)) ? v.hsync_long : v.hsync_short;
-    return (i - h * half) < sw ? v.sync_level : v.blanking_level;
-}
-
 }  // namespace
 
 __global__ __launch_bounds__(256) void k_composite(const uint8_t* __restrict__ frames, const VideoTables* __restrict__ vt,
-                                                   FieldArgs a, uint16_t* __restrict__ out)
+                                                   const VideoLineTemplates* __restrict__ lt, FieldArgs a,
+                                                   uint16_t* __restrict__ out)
 {
     const int first_stream = a.first_stream, ring_depth = a.ring_depth, frame_counter = a.frame_counter;
     __shared__ VideoTables v;
@@ -155,14 +122,18 @@ __global__ __launch_bounds__(256) void k_composite(const uint8_t* __restrict__ f
             o.z = ((p1 << 16) | (p0 >> 8)) + c;
             o.w = (((p1 << 8) & 0xFF000000u) | (p0 >> 16)) + (c << 8);
         } else {
-            const int kind = (active || i < vsync_start) ? 0 : (v.pal ? 2 : 1);
-            uint32_t w[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                uint32_t lo = line_sample(v, kind, g * 8 + 2 * k, i + 1) & 0xFFFF;
-                uint32_t hi = line_sample(v, kind, g * 8 + 2 * k + 1, i + 1) & 0xFFFF;
-                w[k] = lo | (hi << 16);
+            // everything that is not picture: a 16-byte copy from the line's template
+            int tpl;
+            if (active || i < vsync_start)
+                tpl = i & 1;  // template 0: _line_counter = i + 1 odd
+            else if (!v.pal)
+                tpl = 2;
+            else {
+                const int t = (0x00233000u >> ((i - 304) * 4)) & 0xF;  // _sync_type[8] = {0,0,0,3,3,2,0,0}
+                tpl = t == 0 ? 3 : (t == 2 ? 4 : 5);
             }
+            const uint4 tv = *reinterpret_cast<const uint4*>(&lt->tpl[tpl][g * 8]);
+            uint32_t w[4] = {tv.x, tv.y, tv.z, tv.w};
             // composite(), video.cpp:845-887: overlay text = 80 bytes -> 160 samples starting 16
             // samples into the picture window; on overlay lines 3..8 a 240-step progress bar
             // follows after another 16 samples.  One overlay byte / bar step = one dword.
