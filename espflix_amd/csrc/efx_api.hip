@@ -696,7 +696,7 @@ int efx_composite_fields_ex(efx_ctx* ctx, const efx_field_opts* o, uint16_t* dst
     a.overlay_scale = scale;
     a.overlay_progress = o->overlay_progress;
     const int lines = o->ntsc ? 262 : 312;
-    const int blocks = o->n_streams * ((lines + 7) / 8);
+    const int blocks = o->n_streams * ((lines + kCompositeLinesPerBlock - 1) / kCompositeLinesPerBlock);
     hipLaunchKernelGGL(k_composite, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_frames, ctx->d_video[o->ntsc ? 1 : 0],
                        ctx->d_video_lines[o->ntsc ? 1 : 0], a, dst_device);
     EFX_HIP(hipGetLastError());

@@ -25,7 +25,7 @@ namespace efx {
 
 namespace {
 
-constexpr int kLinesPerBlock = 8;
+constexpr int kLinesPerBlock = kCompositeLinesPerBlock;
 
 __device__ inline int luma_row_off(int y) { return (y >> 4) * kStripBytes + (y & 15) * kStride; }
 __device__ inline int chroma_row_off(int plane, int c)
