@@ -36,7 +36,7 @@ __global__ void k_parse_set_prof(uint32_t* p) { g_parse_prof = p; }
 
 namespace {
 
-constexpr int kRingDwords = 32;  // per-lane bitstream ring in LDS (128 bytes)
+constexpr int kRingDwords = 16;  // per-lane bitstream ring in LDS (64 bytes)
 constexpr int kRingLow = 8;      // top up when any lane of the wave has fewer dwords than this ahead
 
 // Bit reader.  Each lane owns a ring of kRingDwords big-endian dwords of ITS slice in LDS, laid
