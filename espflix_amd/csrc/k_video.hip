@@ -170,41 +170,71 @@ __global__ __launch_bounds__(256) void k_composite(const uint8_t* __restrict__ f
 
 // pdm_second_order(), espflix.ino:73-107: two half-steps per PCM sample, 16 delta-sigma steps
 // per half-step, one 16-bit word (MSB first) per half-step.
+//
+// The recurrence is serial, so the only costs worth fighting are the ones around it: PCM is read
+// eight samples (16 bytes) at a time with the next group already in flight, the words of eight
+// samples leave as two 16-byte stores, and a step is select arithmetic (no branch):
+//   i1 += i0 - sign * a1 - (i2 >> 7);   i2 += i1 - sign * a2;   with sign = i2 >= 0 ? 1 : -1.
+namespace {
+
+__device__ __forceinline__ uint32_t pdm_sample(int32_t pcm, uint32_t& i0, uint32_t& i1, uint32_t& i2)
+{
+    const uint32_t a1 = 38973;  // int32(0x7FFF * 1.18940)
+    const uint32_t a2 = 69577;  // int(0x7FFF * 2.12340)
+    const uint32_t x = (uint32_t)(pcm * 2);
+    uint32_t word = 0;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        i0 = (uint32_t)(((int32_t)(i0 + x)) >> 1);
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const bool pos = (int32_t)i2 >= 0;
+            const uint32_t fb = (uint32_t)(((int32_t)i2) >> 7);
+            i1 += i0 - fb + (pos ? 0u - a1 : a1);
+            i2 += i1 + (pos ? 0u - a2 : a2);
+            bits = (bits << 1) | (pos ? 1u : 0u);
+        }
+        word |= (bits & 0xFFFF) << (16 * half);  // consecutive uint16 words, little endian
+    }
+    return word;
+}
+
+}  // namespace
+
 __global__ void k_pdm(const int16_t* __restrict__ pcm, int n_streams, int n_samples, int32_t* __restrict__ state,
                       uint16_t* __restrict__ dst)
 {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_streams)
         return;
-    const int32_t a1 = 38973;  // int32(0x7FFF * 1.18940)
-    const int32_t a2 = 69577;  // int(0x7FFF * 2.12340)
     uint32_t i0 = (uint32_t)state[s * 3 + 0], i1 = (uint32_t)state[s * 3 + 1], i2 = (uint32_t)state[s * 3 + 2];
     const int16_t* src = pcm + (size_t)s * n_samples;
     uint32_t* out = reinterpret_cast<uint32_t*>(dst + (size_t)s * 2 * n_samples);
-    for (int n = 0; n < n_samples; n++) {
-        int32_t x = (int32_t)src[n] * 2;
-        uint32_t word = 0;
+    int n = 0;
+    // groups of eight samples when this stream's PCM and output are 16-byte aligned
+    if ((((uintptr_t)src | (uintptr_t)out) & 15) == 0 && n_samples >= 8) {
+        const int groups = n_samples / 8;
+        const uint4* src4 = reinterpret_cast<const uint4*>(src);
+        uint4* out4 = reinterpret_cast<uint4*>(out);
+        uint4 cur = src4[0];
+        for (int g = 0; g < groups; g++) {
+            const uint4 nxt = src4[g + 1 < groups ? g + 1 : g];  // in flight while this group is modulated
+            const uint32_t in[4] = {cur.x, cur.y, cur.z, cur.w};
+            uint32_t w[8];
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            i0 = (uint32_t)(((int32_t)(i0 + (uint32_t)x)) >> 1);
-            uint32_t bits = 0;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                bits <<= 1;
-                uint32_t fb = (uint32_t)(((int32_t)i2) >> 7);
-                if ((int32_t)i2 >= 0) {
-                    i1 += i0 - (uint32_t)a1 - fb;
-                    i2 += i1 - (uint32_t)a2;
-                    bits |= 1;
-                } else {
-                    i1 += i0 + (uint32_t)a1 - fb;
-                    i2 += i1 + (uint32_t)a2;
-                }
+            for (int k = 0; k < 4; k++) {
+                w[2 * k] = pdm_sample((int16_t)(in[k] & 0xFFFF), i0, i1, i2);
+                w[2 * k + 1] = pdm_sample((int16_t)(in[k] >> 16), i0, i1, i2);
             }
-            word |= (bits & 0xFFFF) << (16 * half);  // consecutive uint16 words, little endian
+            out4[2 * g] = make_uint4(w[0], w[1], w[2], w[3]);
+            out4[2 * g + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+            cur = nxt;
         }
-        out[n] = word;
+        n = groups * 8;
     }
+    for (; n < n_samples; n++)
+        out[n] = pdm_sample(src[n], i0, i1, i2);
     state[s * 3 + 0] = (int32_t)i0;
     state[s * 3 + 1] = (int32_t)i1;
     state[s * 3 + 2] = (int32_t)i2;
