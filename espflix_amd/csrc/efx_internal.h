@@ -79,8 +79,9 @@ struct ParseTables {
     uint8_t type_p[64];      // index: 6-bit peek  -> len | value << 3
     uint32_t scan[64];       // scan position n -> zz | premul << 8 | default intra q << 16 | 16 << 24
 };
-// dct entry: len (5 bits) | run << 5 (5 bits) | level << 10 (6 bits); level 0 = escape, level 63 =
-// end_of_block; len 0 = invalid
+// dct entry: bits consumed (5 bits: code + sign; 2 for end_of_block; 20 for an escape with an 8-bit
+// level) | run << 5 (5 bits) | level << 10 (6 bits); level 0 = escape, level 63 = end_of_block;
+// 0 bits = invalid code
 
 struct DecodeCounters {
     uint32_t total_slices;

@@ -37,17 +37,18 @@ void build_parse_tables(ParseTables* t)
     // longer words all start with six zero bits and are resolved through dct_lo, indexed by
     // bits 6..15 of a 16-bit peek.
     for (const DctCode& c : kDctCodes) {
-        uint16_t e = (uint16_t)(c.len | (c.run << 5) | (c.level << 10));
+        uint16_t e = (uint16_t)((c.len + 1) | (c.run << 5) | (c.level << 10));  // length incl. the sign bit
         if (c.len <= 8)
             expand(t->dct_hi, 8, c.code, c.len, [&] { return e; });
         else
             expand(t->dct_lo, 10, c.code & ((1 << (c.len - 6)) - 1), c.len - 6, [&] { return e; });
     }
-    expand(t->dct_hi, 8, kDctEscapeCode, kDctEscapeLen, [&] { return (uint16_t)kDctEscapeLen; });  // level 0 = escape
+    // level 0 = escape: 6-bit code + 6-bit run + 8-bit level (the 16-bit level form adds 8, in the parser)
+    expand(t->dct_hi, 8, kDctEscapeCode, kDctEscapeLen, [&] { return (uint16_t)(kDctEscapeLen + 14); });
     // the two codes starting with 1 (not in the first position of a non-intra block, which the
     // parser handles before its loop): "10" = end_of_block (level 63 marks it), "11s" = (0, +-1)
     expand(t->dct_hi, 8, 0x2, 2, [&] { return (uint16_t)(2 | (63 << 10)); });
-    expand(t->dct_hi, 8, 0x3, 2, [&] { return (uint16_t)(2 | (0 << 5) | (1 << 10)); });
+    expand(t->dct_hi, 8, 0x3, 2, [&] { return (uint16_t)(3 | (0 << 5) | (1 << 10)); });
 
     for (const VlcCode& c : kMbaCodes)
         expand(t->mba, 11, c.code, c.len, [&] { return (uint16_t)(c.len | (c.value << 4)); });

@@ -187,19 +187,19 @@ struct DctSymbol {
 __device__ inline DctSymbol decode_symbol(uint32_t win, uint32_t ent)
 {
     DctSymbol y;
+    // the table carries the bits consumed (code + sign; 2 for end_of_block; 0 for an invalid code), so
+    // the chain  entry -> length -> position  is one mask and one select long
     const uint32_t len_f = ent & 31, run_f = (ent >> 5) & 31, lev_f = ent >> 10;
     y.bad = len_f == 0;           // invalid code
     y.eob = lev_f == 63;          // "10": end_of_block
     const bool esc = lev_f == 0;  // escape: 6-bit run, 8- or 16-bit level (player.cpp:1092-1099)
-    const int lvl_n = ((win << len_f) >> 31) ? -(int)lev_f : (int)lev_f;
+    const int lvl_n = ((win << (len_f - 1)) >> 31) ? -(int)lev_f : (int)lev_f;  // sign = last bit of the code
     const uint32_t lv8 = (win << 12) >> 24, ext = (win << 20) >> 24;
     const bool two = (lv8 & 0x7F) == 0;
     const int lvl_e = two ? (lv8 ? (int)ext - 256 : (int)ext) : (lv8 > 128 ? (int)lv8 - 256 : (int)lv8);
     y.level = esc ? lvl_e : lvl_n;
     y.run = esc ? (win << 6) >> 26 : run_f;
-    uint32_t len = esc ? (two ? 28u : 20u) : len_f + 1;
-    len = y.eob ? 2u : len;
-    y.len = y.bad ? 0u : len;
+    y.len = (esc && two) ? 28u : len_f;
     return y;
 }
 
