@@ -60,12 +60,7 @@ struct efx_ctx {
     // device buffers
     uint8_t* d_es = nullptr;
     uint64_t* d_stream_off = nullptr;
-    PicInfo* d_pics = nullptr;
-    SliceTmp* d_slices_tmp = nullptr;
-    uint32_t* d_qtab = nullptr;
     ParseTables* d_tables = nullptr;
-    uint32_t* d_slice_base = nullptr;
-    SliceDesc* d_descs = nullptr;
     uint8_t* d_frames = nullptr;
     // transport-stream input (allocated on the first EFX_FORMAT_TS upload)
     uint8_t* d_ts = nullptr;
@@ -90,15 +85,20 @@ struct efx_ctx {
     // n % kSlots on parse stream n % kParseStreams while the recon stream is still reconstructing
     // earlier calls from the other slots.  The parse half is bound by the latency of its longest
     // waves (3 waves per SIMD, ~1/3 of the issue slots used), so back-to-back decodes keep two parse
-    // halves and one reconstruction half on the GPU at once.  The index / slice-list scratch is
-    // shared: it is a function of the uploaded bitstreams only, so concurrent calls write the same
-    // bytes.
+    // halves and one reconstruction half on the GPU at once.  Every slot carries its own
+    // index / slice-list scratch.
     struct Slot {
         uint32_t* d_pic_count = nullptr;
         uint32_t* d_status = nullptr;
         DecodeCounters* d_counters = nullptr;
         MbRec* d_mbrecs = nullptr;
         uint32_t* d_coefs = nullptr;
+        // index / slice-list scratch of this call (per slot: two parse halves run concurrently)
+        PicInfo* d_pics = nullptr;
+        SliceTmp* d_slices_tmp = nullptr;
+        uint32_t* d_qtab = nullptr;  // per (stream, picture) custom quantiser tables, read by k_recon
+        uint32_t* d_slice_base = nullptr;
+        SliceDesc* d_descs = nullptr;
         int64_t* d_pts = nullptr;  // per (stream, picture): PTS latched at the picture header (TS input)
         hipEvent_t parse_done = nullptr, recon_done = nullptr;
         int epoch = 0;
@@ -214,18 +214,18 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     };
     A(dalloc(&ctx->d_es, ctx->es_cap));
     A(dalloc(&ctx->d_stream_off, n + 1));
-    A(dalloc(&ctx->d_pics, n * P));
-    A(dalloc(&ctx->d_slices_tmp, n * P * kMaxSlicesPerPicture));
-    A(dalloc(&ctx->d_qtab, n * P * 64));
     A(dalloc(&ctx->d_tables, 1));
-    A(dalloc(&ctx->d_slice_base, n * P + 1));
-    A(dalloc(&ctx->d_descs, n * P * kMaxSlicesPerPicture));
     for (auto& sl : ctx->slot) {
         A(dalloc(&sl.d_pic_count, n));
         A(dalloc(&sl.d_status, n));
         A(dalloc(&sl.d_counters, 1));
         A(dalloc(&sl.d_mbrecs, n * P * kMbCount));
         A(dalloc(&sl.d_coefs, ctx->es_cap * kCoefsPerEsByte));
+        A(dalloc(&sl.d_pics, n * P));
+        A(dalloc(&sl.d_slices_tmp, n * P * kMaxSlicesPerPicture));
+        A(dalloc(&sl.d_qtab, n * P * 64));
+        A(dalloc(&sl.d_slice_base, n * P + 1));
+        A(dalloc(&sl.d_descs, n * P * kMaxSlicesPerPicture));
     }
     {
         // the parse kernel is a few thousand long-running waves: give it the higher priority so its
@@ -287,8 +287,8 @@ void efx_destroy(efx_ctx* ctx)
             (void)hipStreamSynchronize(ps);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
-    void* bufs[] = {ctx->d_es,   ctx->d_stream_off, ctx->d_pics,  ctx->d_slices_tmp, ctx->d_qtab,     ctx->d_tables,
-                    ctx->d_slice_base, ctx->d_descs, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0], ctx->d_video_lines[1], ctx->d_hash,
+    void* bufs[] = {ctx->d_es,   ctx->d_stream_off, ctx->d_tables,
+                    ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0], ctx->d_video_lines[1], ctx->d_hash,
                     ctx->d_ts, ctx->d_ts_len, ctx->d_pkt_base, ctx->d_es_len, ctx->d_pes_count, ctx->d_pes, ctx->d_sbc_tables, ctx->d_idx_info, ctx->d_ts_off, ctx->d_idx_len, ctx->d_idx_base, ctx->d_idx_seq};
     for (auto& ev : ctx->ev_demux)
         if (ev)
@@ -301,7 +301,8 @@ void efx_destroy(efx_ctx* ctx)
         if (b)
             (void)hipFree(b);
     for (auto& sl : ctx->slot) {
-        void* sb[] = {sl.d_pic_count, sl.d_status, sl.d_counters, sl.d_mbrecs, sl.d_coefs, sl.d_pts};
+        void* sb[] = {sl.d_pic_count, sl.d_status, sl.d_counters, sl.d_mbrecs, sl.d_coefs, sl.d_pts,
+                      sl.d_pics,      sl.d_slices_tmp, sl.d_qtab, sl.d_slice_base, sl.d_descs};
         for (void* b : sb)
             if (b)
                 (void)hipFree(b);
@@ -497,17 +498,17 @@ int efx_decode(efx_ctx* ctx)
         te = &ctx->timing_ring[ctx->timed_calls++ % kTimingRing];
     if (te)
         EFX_HIP(hipEventRecord(te->ev[0], sp));
-    hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, sp, ctx->d_es, ctx->d_stream_off, P, ctx->d_pics, ctx->d_slices_tmp,
-                       sl.d_pic_count, sl.d_status, ctx->d_qtab, ctx->d_tables->scan, ctx->d_pes, ctx->d_pkt_base,
+    hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, sp, ctx->d_es, ctx->d_stream_off, P, sl.d_pics, sl.d_slices_tmp,
+                       sl.d_pic_count, sl.d_status, sl.d_qtab, ctx->d_tables->scan, ctx->d_pes, ctx->d_pkt_base,
                        ctx->d_pes_count, ctx->ts_input ? sl.d_pts : nullptr);
-    hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, ctx->d_pics, sl.d_pic_count, n, P, ctx->d_slice_base,
+    hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, sl.d_pics, sl.d_pic_count, n, P, sl.d_slice_base,
                        sl.d_counters);
-    hipLaunchKernelGGL(k_slice_emit, dim3((n * P * kMaxSlicesPerPicture + 255) / 256), dim3(256), 0, sp, ctx->d_pics,
-                       ctx->d_slices_tmp, sl.d_pic_count, ctx->d_stream_off, ctx->d_slice_base, n, P, ctx->d_descs);
+    hipLaunchKernelGGL(k_slice_emit, dim3((n * P * kMaxSlicesPerPicture + 255) / 256), dim3(256), 0, sp, sl.d_pics,
+                       sl.d_slices_tmp, sl.d_pic_count, ctx->d_stream_off, sl.d_slice_base, n, P, sl.d_descs);
     if (te)
         EFX_HIP(hipEventRecord(te->ev[1], sp));
     const int max_slices = n * P * kMaxSlicesPerPicture;
-    hipLaunchKernelGGL(k_parse, dim3((max_slices + 255) / 256), dim3(256), 0, sp, ctx->d_es, ctx->d_descs, sl.d_counters,
+    hipLaunchKernelGGL(k_parse, dim3((max_slices + 255) / 256), dim3(256), 0, sp, ctx->d_es, sl.d_descs, sl.d_counters,
                        ctx->d_tables, sl.d_mbrecs, sl.d_coefs, sl.d_status, P, sl.epoch);
     if (te)
         EFX_HIP(hipEventRecord(te->ev[2], sp));
@@ -519,7 +520,7 @@ int efx_decode(efx_ctx* ctx)
         EFX_HIP(hipEventRecord(te->ev[4], sr));
     for (int p = 0; p < P; p++)
         hipLaunchKernelGGL(k_recon, dim3(n, (kMbCount * 6 + 63) / 64), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs, ctx->d_tables->scan,
-                           ctx->d_qtab, ctx->d_frames, P, D, p, (p + 1) % D, p % D, sl.epoch);
+                           sl.d_qtab, ctx->d_frames, P, D, p, (p + 1) % D, p % D, sl.epoch);
     if (te)
         EFX_HIP(hipEventRecord(te->ev[3], sr));
     EFX_HIP(hipEventRecord(sl.recon_done, sr));
