@@ -101,6 +101,7 @@ _SYMBOLS = {
     "efx_video_get_params": (C.c_int, [C.c_int, C.POINTER(_VideoParams)]),
     "efx_composite_fields": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "efx_composite_fields_ex": (C.c_int, [_P, C.POINTER(_FieldOpts), _P]),
+    "efx_demux_audio": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t), _P, C.c_size_t, _P]),
     "efx_index_streams": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t), _P, C.c_uint32, _P, _P, C.c_size_t]),
     "efx_idx_build": (C.c_size_t, [_P, C.POINTER(_P), _P, C.c_size_t]),
     "efx_idx_pts2offset": (C.c_uint32, [_P, C.c_int64, C.c_int]),
@@ -346,6 +347,16 @@ class Decoder:
         o = _FieldOpts(first_stream, n_streams, slot, slot if other_slot is None else other_slot, 1 if ntsc else 0,
                        frame_counter, hscroll, g(overlay), overlay_stride, overlay_blend, overlay_progress)
         _check(self._ctx, self._lib.efx_composite_fields_ex(self._ctx, C.byref(o), g(dst)))
+
+    def demux_audio(self, streams, audio: DeviceBuffer | int, stride: int, audio_len: DeviceBuffer | int):
+        """Audio elementary streams (push_audio's input) of a batch of transport streams, on the device."""
+        arrs = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray, memoryview))
+                else np.ascontiguousarray(s, dtype=np.uint8) for s in streams]
+        n = len(arrs)
+        ptrs = (_P * n)(*[a.ctypes.data for a in arrs])
+        lens = (C.c_size_t * n)(*[a.size for a in arrs])
+        g = lambda b: b.ptr if isinstance(b, DeviceBuffer) else b
+        _check(self._ctx, self._lib.efx_demux_audio(self._ctx, n, ptrs, lens, g(audio), stride, g(audio_len)))
 
     def index_streams(self, streams, trick_speed=None, bin_size: int = 7500, samples_cap: int = 0):
         """make_index + pts2seq for a batch of transport streams.  Returns [(rec dict, samples)]."""

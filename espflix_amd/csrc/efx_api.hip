@@ -19,6 +19,7 @@ namespace efx {
 // kernels (k_demux.hip, k_index.hip, k_parse.hip, k_recon.hip, k_video.hip)
 __global__ void k_demux(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, uint8_t*, uint32_t*, PesEntry*,
                         uint32_t*);
+__global__ void k_demux_audio(const uint8_t*, const uint64_t*, const uint32_t*, uint8_t*, const uint64_t*, uint32_t*);
 __global__ void k_ts_sequences(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, PesEntry*, IdxInfo*);
 __global__ void k_idx_bins(const PesEntry*, const uint32_t*, const IdxInfo*, uint32_t, uint32_t*, size_t);
 __global__ void k_index(const uint8_t*, const uint64_t*, int, PicInfo*, SliceTmp*, uint32_t*, uint32_t*, uint32_t*,
@@ -726,6 +727,62 @@ int efx_pdm(efx_ctx* ctx, int n_streams, const int16_t* pcm_device, int n_sample
     return EFX_OK;
 }
 
+
+// ---- audio elementary stream of a batch of transport streams (push_audio's input) ------------------
+
+int efx_demux_audio(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, const size_t* len, uint8_t* audio_device,
+                    size_t stride, uint32_t* audio_len_device)
+{
+    if (!ctx || !ts || !len || !audio_device || !audio_len_device || n_streams <= 0)
+        return fail(ctx, EFX_ERR_ARG, "efx_demux_audio: bad argument");
+    if (n_streams > ctx->cfg.max_streams)
+        return fail(ctx, EFX_ERR_CAPACITY, "efx_demux_audio: more streams than max_streams");
+    int r = ensure_ts_buffers(ctx);
+    if (r)
+        return r;
+    // the TS staging buffers are shared with efx_upload_streams, which only uses them during the call
+    for (auto ps : ctx->parse_streams)
+        EFX_HIP(hipStreamSynchronize(ps));
+    EFX_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> off((size_t)n_streams + 1), out_off((size_t)n_streams + 1);
+    std::vector<uint32_t> tlen(n_streams);
+    size_t pos = 0;
+    for (int i = 0; i < n_streams; i++) {
+        if (!ts[i] && len[i])
+            return fail(ctx, EFX_ERR_ARG, "efx_demux_audio: null stream");
+        if (len[i] > stride)
+            return fail(ctx, EFX_ERR_CAPACITY, "efx_demux_audio: stride smaller than a transport stream");
+        const size_t padded = (len[i] + 15) & ~(size_t)15;
+        if (pos + padded + kEsGuardBytes > ctx->es_cap)
+            return fail(ctx, EFX_ERR_CAPACITY, "efx_demux_audio: more bytes than max_stream_bytes");
+        off[i] = pos;
+        out_off[i] = (uint64_t)i * stride;
+        if (len[i])
+            memcpy(ctx->h_es + pos, ts[i], len[i]);
+        memset(ctx->h_es + pos + len[i], 0, padded - len[i]);
+        tlen[i] = (uint32_t)len[i];
+        pos += padded;
+    }
+    off[n_streams] = pos;
+    out_off[n_streams] = (uint64_t)n_streams * stride;
+    hipStream_t st = ctx->stream;
+    uint64_t* d_out_off = nullptr;
+    EFX_HIP(dalloc(&d_out_off, (size_t)n_streams + 1));
+    hipError_t e = hipMemcpyAsync(ctx->d_ts, ctx->h_es, pos, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_ts_off, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_out_off, out_off.data(), out_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_idx_len, tlen.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_demux_audio, dim3(n_streams), dim3(256), 0, st, ctx->d_ts, ctx->d_ts_off, ctx->d_idx_len,
+                           audio_device, d_out_off, audio_len_device);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // the host staging buffer and d_out_off are free again
+    (void)hipFree(d_out_off);
+    if (e != hipSuccess)
+        return fail(ctx, EFX_ERR_DEVICE, "efx_demux_audio", e);
+    return EFX_OK;
+}
 
 // ---- trick-play index (indexer/indexer.cpp, espflix.cpp:573-629) -------------------------------------
 

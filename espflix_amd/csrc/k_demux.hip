@@ -44,26 +44,36 @@ __device__ inline uint32_t wave_incl_scan(uint32_t v)
 
 }  // namespace
 
-// grid = streams, block = 256.  stream_off[s] .. stream_off[s+1] is the stream's region in BOTH
-// the TS buffer (first ts_len[s] bytes used) and the ES buffer (fully written here).
-__global__ __launch_bounds__(kThreads) void k_demux(const uint8_t* __restrict__ ts, const uint64_t* __restrict__ stream_off,
-                                                    const uint32_t* __restrict__ ts_len,
-                                                    const uint32_t* __restrict__ pkt_base, uint8_t* __restrict__ es,
-                                                    uint32_t* __restrict__ es_len, PesEntry* __restrict__ pes,
-                                                    uint32_t* __restrict__ pes_count)
+// grid = streams, block = 256.  The TS of stream s is the first ts_len[s] bytes at ts + ts_off[s];
+// its output goes to es + out_off[s] (for video: the same region, which is fully written: ES, tail,
+// zero fill up to out_off[s + 1]).
+//
+// AUDIO = true extracts what push_audio() receives instead (MpegDecoder::demux, player.cpp:421-433):
+// the payloads of PID 0x101 / 0x102 behind the PES header, but only while the LATEST audio PES header
+// carried a PTS (_audio_pts != -1).  That gate is a "last defined value" scan over the packets: a
+// PES start sets it (open / closed), every other packet inherits it, across chunk boundaries too.
+// No lost-sync byte, no end-of-data tail, no PES list.
+template <bool AUDIO>
+__device__ __forceinline__ void demux_body(const uint8_t* __restrict__ ts, const uint64_t* __restrict__ ts_off,
+                                           const uint32_t* __restrict__ ts_len, const uint32_t* __restrict__ pkt_base,
+                                           uint8_t* __restrict__ es, const uint64_t* __restrict__ out_off,
+                                           uint32_t* __restrict__ es_len, PesEntry* __restrict__ pes,
+                                           uint32_t* __restrict__ pes_count)
 {
     __shared__ uint4 sh_pkt4[kChunk * kTsPacket / 16 + 1];
     __shared__ uint32_t sh_prefix[kChunk + 1];  // exclusive prefix of payload bytes; [npk] = chunk total
     __shared__ int32_t sh_src[kChunk];          // LDS byte offset of the payload (-1: emit a zero byte)
     __shared__ uint32_t sh_wave[2][4];          // per-wave totals: payload bytes, PTS flags
+    __shared__ uint32_t sh_gate[2];             // audio: last defined gate value of waves 0 and 1
 
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
-    const uint8_t* src = ts + stream_off[s];
-    uint8_t* dst = es + stream_off[s];
-    const uint32_t region = (uint32_t)(stream_off[s + 1] - stream_off[s]);
+    const uint8_t* src = ts + ts_off[s];
+    uint8_t* dst = es + out_off[s];
+    const uint32_t region = AUDIO ? 0u : (uint32_t)(out_off[s + 1] - out_off[s]);
     const uint32_t n_packets = ts_len[s] / kTsPacket;  // a trailing partial packet is never read (player.cpp:459-468)
-    PesEntry* my_pes = pes + pkt_base[s];
+    PesEntry* my_pes = AUDIO ? nullptr : pes + pkt_base[s];
+    uint32_t gate_carry = 1;  // audio: 1 = closed (_audio_pts == -1 at the start), 2 = open
     const uint8_t* pk = reinterpret_cast<const uint8_t*>(sh_pkt4);
 
     uint32_t es_pos = 0, n_pes = 0;
@@ -78,13 +88,13 @@ __global__ __launch_bounds__(kThreads) void k_demux(const uint8_t* __restrict__ 
         }
         __syncthreads();
         // ---- 2. one thread per packet --------------------------------------------------------
-        uint32_t n = 0, has_pts = 0;
+        uint32_t n = 0, has_pts = 0, gate = 0;
         int32_t from = 0;
         int64_t pts = -1;
         if ((uint32_t)tid < npk) {
             const uint8_t* p = pk + tid * kTsPacket;
             if (p[0] != 0x47) {
-                n = 1;  // "ts lost sync": the bit reader is handed one zero byte (player.cpp:465-467)
+                n = AUDIO ? 0 : 1;  // "ts lost sync": the VIDEO bit reader is handed one zero byte (player.cpp:465-467)
                 from = -1;
             } else {
                 const uint32_t pid = ((p[1] << 8) + p[2]) & 0x1FFF;
@@ -107,8 +117,10 @@ __global__ __launch_bounds__(kThreads) void k_demux(const uint8_t* __restrict__ 
                         }
                     }
                 }
-                if (keep && pid == 0x100) {
-                    has_pts = pts != -1;
+                if (keep && (AUDIO ? (pid == 0x101 || pid == 0x102) : pid == 0x100)) {
+                    has_pts = !AUDIO && pts != -1;
+                    if (AUDIO && (p[1] & 0x40))
+                        gate = pts != -1 ? 2 : 1;  // _audio_pts = pts at every audio PES start
                     if (pay < kTsPacket) {
                         n = kTsPacket - pay;
                         from = tid * kTsPacket + pay;
@@ -116,8 +128,31 @@ __global__ __launch_bounds__(kThreads) void k_demux(const uint8_t* __restrict__ 
                 }
             }
         }
-        // ---- 3. prefix sums over the chunk (packets live in waves 0 and 1) -------------------
         const int wave = tid >> 6, lane = tid & 63;
+        if (AUDIO) {
+            // the gate in force at each packet: the last value defined at or before it
+            if (wave < 2) {
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(gate, d, 64);
+                    if (lane >= d && gate == 0)
+                        gate = o;
+                }
+                if (lane == 63)
+                    sh_gate[wave] = gate;
+            }
+            __syncthreads();
+            if (wave == 1 && gate == 0)
+                gate = sh_gate[0];
+            if (gate == 0)
+                gate = gate_carry;
+            if (gate != 2)
+                n = 0;  // push_audio() is not called while _audio_pts == -1
+            const uint32_t last = sh_gate[1] ? sh_gate[1] : sh_gate[0];
+            gate_carry = last ? last : gate_carry;
+            __syncthreads();
+        }
+        // ---- 3. prefix sums over the chunk (packets live in waves 0 and 1) -------------------
         uint32_t incl_n = 0, incl_f = 0;
         if (wave < 2) {
             incl_n = wave_incl_scan(n);
@@ -135,7 +170,7 @@ __global__ __launch_bounds__(kThreads) void k_demux(const uint8_t* __restrict__ 
             const uint32_t excl_f = incl_f - has_pts + (wave ? sh_wave[1][0] : 0);
             sh_prefix[tid] = (uint32_t)tid < npk ? excl_n : total;
             sh_src[tid] = from;
-            if (has_pts) {
+            if (!AUDIO && has_pts) {
                 PesEntry e;
                 e.es_off = es_pos + excl_n;
                 e.reserved = 0;
@@ -184,9 +219,9 @@ __global__ __launch_bounds__(kThreads) void k_demux(const uint8_t* __restrict__ 
         __syncthreads();
     }
 
-    // ---- end of data: tail + zero fill up to the region end (16-byte aligned) ---------------------
+    // ---- end of data: tail + zero fill up to the region end (16-byte aligned); video only ------------
     const uint32_t tail_lo = es_pos;
-    for (uint32_t d = (tail_lo >> 2) + tid; d * 4 < region; d += kThreads) {
+    for (uint32_t d = (tail_lo >> 2) + tid; !AUDIO && d * 4 < region; d += kThreads) {
         const uint32_t o0 = d * 4;
         uint32_t word = 0;
 #pragma unroll
@@ -206,8 +241,28 @@ __global__ __launch_bounds__(kThreads) void k_demux(const uint8_t* __restrict__ 
     }
     if (tid == 0) {
         es_len[s] = es_pos;
-        pes_count[s] = n_pes;
+        if (!AUDIO)
+            pes_count[s] = n_pes;
     }
+}
+
+// video: MpegDecoder::more() / demux() for PID 0x100; TS and ES of a stream share one region
+__global__ __launch_bounds__(kThreads) void k_demux(const uint8_t* __restrict__ ts, const uint64_t* __restrict__ stream_off,
+                                                    const uint32_t* __restrict__ ts_len,
+                                                    const uint32_t* __restrict__ pkt_base, uint8_t* __restrict__ es,
+                                                    uint32_t* __restrict__ es_len, PesEntry* __restrict__ pes,
+                                                    uint32_t* __restrict__ pes_count)
+{
+    demux_body<false>(ts, stream_off, ts_len, pkt_base, es, stream_off, es_len, pes, pes_count);
+}
+
+// audio: the byte stream push_audio() receives (PID 0x101 / 0x102)
+__global__ __launch_bounds__(kThreads) void k_demux_audio(const uint8_t* __restrict__ ts, const uint64_t* __restrict__ ts_off,
+                                                          const uint32_t* __restrict__ ts_len, uint8_t* __restrict__ out,
+                                                          const uint64_t* __restrict__ out_off,
+                                                          uint32_t* __restrict__ out_len)
+{
+    demux_body<true>(ts, ts_off, ts_len, nullptr, out, out_off, out_len, nullptr, nullptr);
 }
 
 }  // namespace efx

@@ -171,6 +171,15 @@ int efx_composite_fields_ex(efx_ctx* ctx, const efx_field_opts* opts, uint16_t* 
 int efx_pdm(efx_ctx* ctx, int n_streams, const int16_t* pcm_device, int n_samples, int32_t* state_device,
             uint16_t* dst_device);
 
+/* The audio half of MpegDecoder::demux (src/player.cpp:421-433) for a batch of transport streams:
+ * the bytes push_audio() (src/video.h:50, src/video.cpp:1006-1019) would receive -- payloads of PID
+ * 0x101 / 0x102 behind the PES header, only while the latest audio PES header carried a PTS -- are
+ * written to audio_device + i * stride (device memory, stride >= the longest transport stream) and
+ * their count to audio_len_device[i].  Feed efx_sbc_decode from there.  ts / len are host pointers;
+ * synchronous. */
+int efx_demux_audio(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, const size_t* len, uint8_t* audio_device,
+                    size_t stride, uint32_t* audio_len_device);
+
 /* -- trick-play index (indexer/indexer.cpp; ESPFlix::idx_hdr, src/espflix.cpp:573-629) -------- */
 /* idx_rec as the indexer writes it (indexer/indexer.cpp:22-28): 28 bytes of fields + 4 of padding */
 typedef struct efx_idx_rec {

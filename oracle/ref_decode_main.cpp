@@ -77,7 +77,14 @@ void push_video(Frame* f, int front, int64_t pts, int mode)
     if (!g_quiet) fprintf(g_log, "F %d %lld %016llx\n", g_frames, (long long)pts, (unsigned long long)h);
     g_frames++;
 }
-void push_audio(const uint8_t*, int, int64_t, bool) {}
+// audio up-call (src/video.h:50): when EFX_REF_AUDIO_OUT names a file, every byte the reference's
+// demux hands to push_audio() is appended to it (pins the restatement's efxo_ts_audio_es)
+static FILE* g_audio_out = 0;
+void push_audio(const uint8_t* data, int len, int64_t, bool)
+{
+    if (g_audio_out && len > 0)
+        fwrite(data, 1, (size_t)len, g_audio_out);
+}
 void video_reset() {}
 
 static Frame g_fb[2];           // adjacent, as ESPFlix::_frame_buffers (src/espflix.cpp:641)
@@ -179,6 +186,8 @@ int main(int argc, char** argv)
         return 0;
     }
     if (cmd == "decode" && argc >= 4) {
+        if (getenv("EFX_REF_AUDIO_OUT"))
+            g_audio_out = fopen(getenv("EFX_REF_AUDIO_OUT"), "wb");
         std::vector<uint8_t> v = slurp(argv[2]);
         if (strcmp(argv[3], "-")) g_out = fopen(argv[3], "wb");
         bool flush = argc > 4 && !strcmp(argv[4], "flush");
@@ -186,6 +195,7 @@ int main(int argc, char** argv)
         int n = decode_rom(&v[0], (int)v.size(), flush);
         fprintf(g_log, "CHAIN %d %016llx\n", n, (unsigned long long)g_chain);
         if (g_out) fclose(g_out);
+        if (g_audio_out) fclose(g_audio_out);
         fflush(g_log);
         _exit(0);       // decoder thread is parked in pause(); do not run static destructors under it
     }

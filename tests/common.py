@@ -219,3 +219,42 @@ def index_queries(hdr_first: int, hdr_last: int):
                     hdr_last - 1, hdr_last, hdr_last + 90000, 0, 1 << 33]:
             q.append((int(pts), speed))
     return q
+
+
+def hostile_audio_packets(seed: int):
+    """Audio PES packets (PID 0x101 / 0x102) with and without PTS -- the gate of player.cpp:421-433
+    opens and closes -- split over transport packets of random payload size."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(60):
+        pid = 0x102 if k % 3 else 0x101
+        kind = int(rng.integers(0, 4))   # 0: PES without PTS (closes the gate)
+        body = bytes(rng.integers(0, 256, int(rng.integers(20, 500)), dtype=np.uint8))
+        head = pes_header(None if kind == 0 else int(rng.integers(0, 1 << 33)), dts=kind == 2, stuffing=3 if kind == 3 else 0)
+        pos, first = 0, True
+        while first or pos < len(body):
+            h = head if first else b""
+            n = min(len(body) - pos, int(rng.integers(1, 184 - len(h) + 1)))
+            out.append(ts_packet(pid, h + body[pos:pos + n], pusi=first))
+            pos += n
+            first = False
+    return out
+
+
+def interleave_audio(video_ts: bytes, seed: int) -> bytes:
+    """A valid video transport stream with hostile audio packets (and a few null packets) mixed in."""
+    rng = np.random.default_rng(seed + 1000)
+    v = [video_ts[i:i + 188] for i in range(0, len(video_ts) - 187, 188)]
+    a = hostile_audio_packets(seed)
+    out = bytearray()
+    ia = 0
+    for pkt in v:
+        out += pkt
+        while ia < len(a) and rng.integers(0, 3) == 0:
+            out += a[ia]
+            ia += 1
+        if rng.integers(0, 9) == 0:
+            out += ts_packet(0x1FFF, bytes(184))
+    for pkt in a[ia:]:
+        out += pkt
+    return bytes(out)

@@ -167,6 +167,17 @@ def ref_decode(ts: np.ndarray | str, flush_last: bool = True, want_frames: bool 
         return hashes, pts, frames
 
 
+def ref_audio_es(ts: np.ndarray) -> np.ndarray:
+    """Every byte the reference's demux hands to push_audio() while it plays the transport stream."""
+    with tempfile.TemporaryDirectory() as td:
+        src, out = os.path.join(td, "in.ts"), os.path.join(td, "audio.bin")
+        np.ascontiguousarray(ts, dtype=np.uint8).tofile(src)
+        env = dict(os.environ, EFX_REF_AUDIO_OUT=out)
+        subprocess.run([os.path.join(REF_DIR, "efx_ref_decode"), "decode", src, "-", "flush"], stderr=subprocess.DEVNULL,
+                       stdout=subprocess.DEVNULL, timeout=120, env=env)
+        return np.fromfile(out, dtype=np.uint8)
+
+
 def ref_video_field(frames2: np.ndarray, ntsc: bool, nfields: int) -> np.ndarray:
     with tempfile.TemporaryDirectory() as td:
         src, out = os.path.join(td, "f.bin"), os.path.join(td, "o.bin")

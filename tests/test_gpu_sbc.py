@@ -133,3 +133,41 @@ def test_batch_of_streams_and_pdm_chain(efx):
         st = np.zeros(3, dtype=np.int32)
         assert np.array_equal(words[i], oracle.pdm(st, pcm[i])), i
     dec.close()
+
+
+def hostile_audio_ts(seed: int) -> bytes:
+    """Hostile audio (common.hostile_audio_packets) inside a valid video stream: > 128 packets, so the
+    gate crosses k_demux's chunk boundary."""
+    from espflix_amd import gen
+    return common.interleave_audio(gen.Batch(400 + seed, 1, 8).ts(0).tobytes(), seed)
+
+
+def test_audio_demux_on_device_and_full_chain(efx, golden, clips):
+    """efx_demux_audio: the bytes push_audio() receives, for the clips and for hostile muxing, equal
+    the oracle's; then TS -> audio ES -> SBC -> PCM entirely on the device equals the golden PCM."""
+    streams = [clips["splash"].tobytes(), clips["vmedia"].tobytes()] + [hostile_audio_ts(s) for s in (1, 2, 3)] + [b""]
+    stride = (max(len(s) for s in streams) + 255) & ~255
+    dec = efx.Decoder(len(streams), 1, 2, max_stream_bytes=sum(len(s) for s in streams) + 4096)
+    d_audio, d_len = dec.alloc(len(streams) * stride), dec.alloc(len(streams) * 4)
+    dec.demux_audio(streams, d_audio, stride, d_len)
+    lens = d_len.download(np.uint32, len(streams))
+    audio = d_audio.download(np.uint8, len(streams) * stride).reshape(len(streams), stride)
+    for i, ts in enumerate(streams):
+        want = oracle.ts_audio_es(np.frombuffer(ts, dtype=np.uint8))
+        assert lens[i] == want.size, (i, lens[i], want.size)
+        assert np.array_equal(audio[i, :lens[i]], want), i
+    assert lens[2] > 0 and lens[5] == 0
+    # the clips' audio straight from the device buffer into k_sbc
+    for i, clip in enumerate(("splash", "vmedia")):
+        fb = common.CLIP_SBC_FRAME_BYTES[clip]
+        frames = int(lens[i]) // fb
+        d_st, d_pcm, d_cnt = dec.alloc(efx.sbc_state_bytes()), dec.alloc(frames * 256 * 2), dec.alloc(4)
+        d_st.upload(np.zeros(efx.sbc_state_bytes(), dtype=np.uint8))
+        dec.sbc_decode(1, d_audio.ptr + i * stride, stride, fb, frames, d_st, d_pcm, frames * 256, None, d_cnt, probe_first=True)
+        dec.sync()
+        cnt = int(d_cnt.download(np.uint32, 1)[0])
+        pcm = d_pcm.download(np.int16, cnt)
+        want, _ = oracle.sbc_decode(audio[i, :frames * fb], fb, True)
+        assert np.array_equal(pcm, want[128:])
+        assert f"{common.fnv_bytes(want):016x}" == golden["sbc"]["clip:" + clip]["pcm_fnv"]
+    dec.close()

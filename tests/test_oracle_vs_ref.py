@@ -148,3 +148,18 @@ def test_trick_play_index_file(clips):
         q = common.index_queries(int(first), int(last))
         want = oracle.ref_idx_query(ref, q)
         assert [oracle.idx_query(ref, p, s) for p, s in q] == want, name
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_audio_bytes_pushed(seed, clips):
+    """What push_audio() receives (MpegDecoder::demux, player.cpp:421-433): for the clips and for a
+    video stream with hostile audio muxed in (PES with / without PTS: the _audio_pts gate)."""
+    b = gen.Batch(400 + seed, 1, 8)
+    cases = [common.interleave_audio(b.ts(0).tobytes(), seed)]
+    if seed == 1:
+        cases += [clips["splash"].tobytes(), clips["vmedia"].tobytes()]
+    for ts in cases:
+        a = np.frombuffer(ts, dtype=np.uint8)
+        ref = oracle.ref_audio_es(a)
+        got = oracle.ts_audio_es(a)
+        assert ref.size > 0 and np.array_equal(ref, got)
