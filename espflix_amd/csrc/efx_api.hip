@@ -24,9 +24,9 @@ __global__ void k_ts_sequences(const uint8_t*, const uint64_t*, const uint32_t*,
 __global__ void k_idx_bins(const PesEntry*, const uint32_t*, const IdxInfo*, uint32_t, uint32_t*, size_t);
 __global__ void k_index(const uint8_t*, const uint64_t*, int, PicInfo*, SliceTmp*, uint32_t*, uint32_t*, uint32_t*,
                         const uint32_t*, const PesEntry*, const uint32_t*, const uint32_t*, int64_t*);
-__global__ void k_slice_scan(const PicInfo*, const uint32_t*, int, int, uint32_t*, DecodeCounters*);
+__global__ void k_slice_scan(const PicInfo*, const uint32_t*, int, int, const uint32_t*, uint32_t*, DecodeCounters*);
 __global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, const uint64_t*, const uint32_t*, int, int,
-                             SliceDesc*);
+                             const uint32_t*, SliceDesc*);
 __global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const ParseTables*, MbRec*, uint32_t*, uint32_t*,
                         int, int);
 __global__ void k_recon(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, int, int, int);
@@ -61,6 +61,7 @@ struct efx_ctx {
     // device buffers
     uint8_t* d_es = nullptr;
     uint64_t* d_stream_off = nullptr;
+    uint32_t* d_stream_perm = nullptr;  // streams by descending length: the order of slices inside a picture index
     ParseTables* d_tables = nullptr;
     uint8_t* d_frames = nullptr;
     // transport-stream input (allocated on the first EFX_FORMAT_TS upload)
@@ -215,6 +216,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     };
     A(dalloc(&ctx->d_es, ctx->es_cap));
     A(dalloc(&ctx->d_stream_off, n + 1));
+    A(dalloc(&ctx->d_stream_perm, n));
     A(dalloc(&ctx->d_tables, 1));
     for (auto& sl : ctx->slot) {
         A(dalloc(&sl.d_pic_count, n));
@@ -288,7 +290,7 @@ void efx_destroy(efx_ctx* ctx)
             (void)hipStreamSynchronize(ps);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
-    void* bufs[] = {ctx->d_es,   ctx->d_stream_off, ctx->d_tables,
+    void* bufs[] = {ctx->d_es,   ctx->d_stream_off, ctx->d_stream_perm, ctx->d_tables,
                     ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0], ctx->d_video_lines[1], ctx->d_hash,
                     ctx->d_ts, ctx->d_ts_len, ctx->d_pkt_base, ctx->d_es_len, ctx->d_pes_count, ctx->d_pes, ctx->d_sbc_tables, ctx->d_idx_info, ctx->d_ts_off, ctx->d_idx_len, ctx->d_idx_base, ctx->d_idx_seq};
     for (auto& ev : ctx->ev_demux)
@@ -402,6 +404,12 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
     }
     memset(ctx->h_es + pos, 0, kEsGuardBytes);
     ctx->h_stream_off[n_streams] = pos;
+    // slices of one picture index are dealt to the parse waves stream by stream: longest streams
+    // first, so that a wave's 64 slices have similar bit rates (and the long waves start early)
+    std::vector<uint32_t> perm((size_t)n_streams);
+    for (int i = 0; i < n_streams; i++)
+        perm[i] = (uint32_t)i;
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return len[a] > len[b]; });
     ctx->es_used = pos;
     ctx->n_streams = n_streams;
     ctx->ts_input = is_ts;
@@ -410,6 +418,7 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
     hipStream_t st = ctx->stream;
     EFX_HIP(hipMemcpyAsync(ctx->d_stream_off, ctx->h_stream_off.data(), ((size_t)n_streams + 1) * sizeof(uint64_t),
                            hipMemcpyHostToDevice, st));
+    EFX_HIP(hipMemcpyAsync(ctx->d_stream_perm, perm.data(), (size_t)n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     if (is_ts) {
         if (packets > ctx->pes_cap)
             return fail(ctx, EFX_ERR_CAPACITY, "efx_upload_streams: PES list capacity");
@@ -502,10 +511,10 @@ int efx_decode(efx_ctx* ctx)
     hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, sp, ctx->d_es, ctx->d_stream_off, P, sl.d_pics, sl.d_slices_tmp,
                        sl.d_pic_count, sl.d_status, sl.d_qtab, ctx->d_tables->scan, ctx->d_pes, ctx->d_pkt_base,
                        ctx->d_pes_count, ctx->ts_input ? sl.d_pts : nullptr);
-    hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, sl.d_pics, sl.d_pic_count, n, P, sl.d_slice_base,
+    hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, sl.d_pics, sl.d_pic_count, n, P, ctx->d_stream_perm, sl.d_slice_base,
                        sl.d_counters);
     hipLaunchKernelGGL(k_slice_emit, dim3((n * P * kMaxSlicesPerPicture + 255) / 256), dim3(256), 0, sp, sl.d_pics,
-                       sl.d_slices_tmp, sl.d_pic_count, ctx->d_stream_off, sl.d_slice_base, n, P, sl.d_descs);
+                       sl.d_slices_tmp, sl.d_pic_count, ctx->d_stream_off, sl.d_slice_base, n, P, ctx->d_stream_perm, sl.d_descs);
     if (te)
         EFX_HIP(hipEventRecord(te->ev[1], sp));
     const int max_slices = n * P * kMaxSlicesPerPicture;

@@ -248,12 +248,16 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
     }
 }
 
+// stream_perm: the order in which the streams contribute to a picture index -- by descending
+// bitstream length (host side), so that the 64 slices of a parse wave come from streams of similar
+// bit rate and finish at similar times.
 // Exclusive prefix sum of slice counts over (picture, stream) pairs in picture-major order, so
 // that the slices of one picture index are contiguous: a parse wave then holds 64 slices of the
 // same picture type.  Single workgroup.
 __global__ __launch_bounds__(1024) void k_slice_scan(const PicInfo* __restrict__ pics,
                                                      const uint32_t* __restrict__ pic_count, int n_streams,
-                                                     int max_pictures, uint32_t* __restrict__ slice_base,
+                                                     int max_pictures, const uint32_t* __restrict__ stream_perm,
+                                                     uint32_t* __restrict__ slice_base,
                                                      DecodeCounters* __restrict__ counters)
 {
     __shared__ uint32_t wave_tot[16];
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(1024) void k_slice_scan(const PicInfo* __restrict__
         int i = base + tid;
         uint32_t v = 0;
         if (i < n) {
-            int p = i / n_streams, s = i - p * n_streams;
+            int p = i / n_streams, s = (int)stream_perm[i - p * n_streams];
             if ((uint32_t)p < pic_count[s])
                 v = pics[(size_t)s * max_pictures + p].n_slices;
         }
@@ -300,13 +304,14 @@ __global__ __launch_bounds__(256) void k_slice_emit(const PicInfo* __restrict__ 
                                                     const uint32_t* __restrict__ pic_count,
                                                     const uint64_t* __restrict__ stream_off,
                                                     const uint32_t* __restrict__ slice_base, int n_streams,
-                                                    int max_pictures, SliceDesc* __restrict__ descs)
+                                                    int max_pictures, const uint32_t* __restrict__ stream_perm,
+                                                    SliceDesc* __restrict__ descs)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     int k = t % kMaxSlicesPerPicture, i = t / kMaxSlicesPerPicture;
     if (i >= n_streams * max_pictures)
         return;
-    int p = i / n_streams, s = i - p * n_streams;
+    int p = i / n_streams, s = (int)stream_perm[i - p * n_streams];
     if ((uint32_t)p >= pic_count[s])
         return;
     PicInfo pi = pics[(size_t)s * max_pictures + p];
