@@ -1,4 +1,5 @@
-/* efx_oracle.c -- CPU restatement of the espflix MPEG-1 / composite / PDM hot path.
+/* efx_oracle.c -- CPU restatement of the espflix hot path: MPEG-1 decode, TS demux (video + audio),
+ * composite video incl. overlay / slide, PDM, SBC audio decode, trick-play index.
  *
  * TEST INFRASTRUCTURE ONLY (see efx_oracle.h).  Plain C99, serial, written for clarity.
  * Every function cites the reference file:line (under /root/reference) it restates.

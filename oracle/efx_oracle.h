@@ -3,8 +3,10 @@
  * This library is the parity checker for the HIP implementation in espflix_amd/csrc.  It is a
  * plain-C restatement of the reference algorithms, each function citing the reference
  * file:line it follows.  It is pinned against the real reference (compiled unmodified into
- * oracle/_ref/ by oracle/Makefile) on the two embedded clips, on synthetic streams, on
- * composite fields and on PDM words -- see tests/test_oracle_vs_ref.py and tests/golden/.
+ * oracle/_ref/ by oracle/Makefile) on the two embedded clips (video and audio), on synthetic
+ * streams and hostile muxing, on composite fields incl. overlay / slide, on PDM words, on SBC
+ * frames and tables, and on the indexer's video.idx -- see tests/test_oracle_vs_ref.py and
+ * tests/golden/.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The
  * product (espflix_amd/) never links, imports or executes anything in oracle/.
