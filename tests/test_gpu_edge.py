@@ -125,3 +125,22 @@ def test_decode_continues_across_uploads_with_double_buffer(efx):
     assert int(hh[0, dec.picture_slot(5)]) == int(h[11])
     assert int(hh[0, dec.picture_slot(4)]) == int(h[10])
     dec.close()
+
+
+def test_epoch_tags_wrap_under_back_to_back_decodes(efx):
+    """Macroblock records carry an 8-bit epoch per hand-over slot; 800 pipelined efx_decode calls
+    (3 slots, 2 parse streams) take every slot through the wrap-and-clear path."""
+    from espflix_amd import gen
+    b = gen.Batch(0, 3, 4, 12, 0)
+    streams = b.all_es()
+    dec = efx.Decoder(3, 4, 2)
+    dec.upload(streams, efx.FORMAT_ES)
+    dec.decode()
+    want = dec.frame_hashes().copy()
+    for i in range(800):
+        dec.decode(sync=False)
+        if i in (254, 255, 256, 511, 765, 766, 799):
+            dec.sync()
+            assert np.array_equal(dec.frame_hashes(), want), i
+            assert all(dec.stream_status(k) == 0 and dec.picture_count(k) == 4 for k in range(3))
+    dec.close()
