@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <thread>
 
 #include <cstdio>
 #include <cstring>
@@ -388,22 +389,62 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
             return fail(ctx, EFX_ERR_CAPACITY, "efx_upload_streams: more bytes than max_stream_bytes");
         ctx->h_stream_off[i] = pos;
         ctx->h_es_len[i] = (uint32_t)n;
-        if (n)
-            memcpy(ctx->h_es + pos, src, n);
         if (is_ts) {
-            // raw packets; k_demux writes the ES, the end-of-data tail and the zero fill
-            memset(ctx->h_es + pos + n, 0, padded - n);
             ts_len[i] = (uint32_t)n;
             pkt_base[i] = (uint32_t)packets;
             packets += n / 188;
-        } else {
-            memcpy(ctx->h_es + pos + n, tail, kEsTailBytes);
-            memset(ctx->h_es + pos + n + kEsTailBytes, 0, padded - n - kEsTailBytes);
         }
         pos += padded;
     }
-    memset(ctx->h_es + pos, 0, kEsGuardBytes);
     ctx->h_stream_off[n_streams] = pos;
+    // Stage into the pinned buffer and ship it: the streams are cut into groups, one host thread
+    // copies each group, and a group's H2D transfer is queued as soon as its copy is done, so the
+    // transfer of the first groups runs under the copies of the last.
+    hipStream_t st = ctx->stream;
+    uint8_t* d_dst = is_ts ? ctx->d_ts : ctx->d_es;
+    auto stage = [&](int i0, int i1) {
+        for (int i = i0; i < i1; i++) {
+            uint8_t* at = ctx->h_es + ctx->h_stream_off[i];
+            const size_t n = len[i], padded = (size_t)(ctx->h_stream_off[i + 1] - ctx->h_stream_off[i]);
+            if (n)
+                memcpy(at, data[i], n);
+            if (is_ts)  // raw packets; k_demux writes the ES, the end-of-data tail and the zero fill
+                memset(at + n, 0, padded - n);
+            else {
+                memcpy(at + n, tail, kEsTailBytes);
+                memset(at + n + kEsTailBytes, 0, padded - n - kEsTailBytes);
+            }
+        }
+    };
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        int groups = pos > ((size_t)4 << 20) ? (int)std::min<unsigned>(8u, std::max(1u, hw / 2)) : 1;
+        groups = std::min(groups, n_streams);
+        std::vector<std::thread> workers;
+        std::vector<int> first((size_t)groups + 1);
+        for (int g = 0; g <= groups; g++)
+            first[g] = (int)((int64_t)n_streams * g / groups);
+        int started = 0;  // groups 1 .. started have a worker; the rest are copied inline (no exception leaves the C-ABI)
+        try {
+            for (int g = 1; g < groups; g++) {
+                workers.emplace_back(stage, first[g], first[g + 1]);
+                started = g;
+            }
+        } catch (...) {
+        }
+        hipError_t e = hipSuccess;
+        for (int g = 0; g < groups; g++) {
+            if (g >= 1 && g <= started)
+                workers[g - 1].join();
+            else
+                stage(first[g], first[g + 1]);
+            const size_t a = ctx->h_stream_off[first[g]], b = ctx->h_stream_off[first[g + 1]];
+            if (e == hipSuccess && b > a)
+                e = hipMemcpyAsync(d_dst + a, ctx->h_es + a, b - a, hipMemcpyHostToDevice, st);
+        }
+        if (e != hipSuccess)
+            return fail(ctx, EFX_ERR_DEVICE, "efx_upload_streams: H2D", e);
+    }
     // slices of one picture index are dealt to the parse waves stream by stream: longest streams
     // first, so that a wave's 64 slices have similar bit rates (and the long waves start early)
     std::vector<uint32_t> perm((size_t)n_streams);
@@ -415,14 +456,13 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
     ctx->ts_input = is_ts;
     ctx->demux_ms = 0.f;
     ctx->ts_bytes = 0;
-    hipStream_t st = ctx->stream;
     EFX_HIP(hipMemcpyAsync(ctx->d_stream_off, ctx->h_stream_off.data(), ((size_t)n_streams + 1) * sizeof(uint64_t),
                            hipMemcpyHostToDevice, st));
     EFX_HIP(hipMemcpyAsync(ctx->d_stream_perm, perm.data(), (size_t)n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     if (is_ts) {
         if (packets > ctx->pes_cap)
             return fail(ctx, EFX_ERR_CAPACITY, "efx_upload_streams: PES list capacity");
-        EFX_HIP(hipMemcpyAsync(ctx->d_ts, ctx->h_es, pos + kEsGuardBytes, hipMemcpyHostToDevice, st));
+        EFX_HIP(hipMemsetAsync(ctx->d_ts + pos, 0, kEsGuardBytes, st));
         EFX_HIP(hipMemcpyAsync(ctx->d_ts_len, ts_len.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         EFX_HIP(hipMemcpyAsync(ctx->d_pkt_base, pkt_base.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         EFX_HIP(hipMemsetAsync(ctx->d_es + pos, 0, kEsGuardBytes, st));
@@ -437,7 +477,7 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
         for (int i = 0; i < n_streams; i++)
             ctx->ts_bytes += ts_len[i];
     } else
-        EFX_HIP(hipMemcpyAsync(ctx->d_es, ctx->h_es, pos + kEsGuardBytes, hipMemcpyHostToDevice, st));
+        EFX_HIP(hipMemsetAsync(ctx->d_es + pos, 0, kEsGuardBytes, st));
     EFX_HIP(hipStreamSynchronize(st));
     if (is_ts && ctx->timing)
         EFX_HIP(hipEventElapsedTime(&ctx->demux_ms, ctx->ev_demux[0], ctx->ev_demux[1]));
