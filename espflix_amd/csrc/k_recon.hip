@@ -107,7 +107,7 @@ constexpr int kBlocksPerPicture = kMbCount * 6;
 constexpr int kLaneHalfwords = 66;  // per-lane LDS block: 64 int16 + 2 pad = 33 dwords (odd: lanes fan out over the banks)
 
 // grid = (streams, 25): blockIdx.x = stream, blockIdx.y = group of 64 consecutive 8x8 blocks of the
-// picture (block b = macroblock b / 6, block b % 6); ONE LANE PER BLOCK.  With a stream count that
+// picture in plane-row order (see below); ONE LANE PER BLOCK.  With a stream count that
 // is a multiple of 8 all blocks of a stream are dispatched to XCD (stream % 8).
 //
 // The previous mapping (one wave per macroblock, 48 of 64 lanes in the butterflies, transposition
@@ -138,7 +138,21 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     const int b_raw = blockIdx.y * 64 + lane;
     const bool have = b_raw < kBlocksPerPicture;
     const int b = have ? b_raw : kBlocksPerPicture - 1;
-    const int mb = b / 6, blk = b - mb * 6;
+    // Block order inside a picture: by macroblock row, and inside it by plane row -- the 44 upper luma
+    // blocks, the 44 lower ones, the 22 "cr" and the 22 "cb" blocks -- so that the lanes of a wave
+    // write (and mostly read) long contiguous runs of every frame row they touch.
+    const int mbrow = b / 132, rr = b - mbrow * 132;
+    int blk, mbx;
+    if (rr < 88) {
+        const int h = rr >= 44, r2 = rr - 44 * h;
+        blk = 2 * h + (r2 & 1);
+        mbx = r2 >> 1;
+    } else {
+        const int h = rr >= 110;
+        blk = 4 + h;
+        mbx = rr - 88 - 22 * h;
+    }
+    const int mb = mbrow * kMbW + mbx;
     uint8_t* cur = frames + ((size_t)s * ring_depth + cur_slot) * kFrameBytes;
     const uint8_t* ref = frames + ((size_t)s * ring_depth + ref_slot) * kFrameBytes;
 
