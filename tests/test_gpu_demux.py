@@ -131,3 +131,23 @@ def test_demux_timing_reported(efx):
     dec.decode()
     t = dec.timing()
     assert t.ts_bytes == sum(len(x) for x in blobs) and t.demux_ms > 0
+
+
+def test_pts_survive_pipelined_decodes(efx, golden):
+    """Per-picture PTS live in the hand-over slots: back-to-back efx_decode calls (three slots, two
+    parse streams) report the same PTS and frames every time."""
+    from espflix_amd import gen
+    b = gen.Batch(0, 8, 12, 12, 0)
+    blobs = [b.ts(k) for k in range(8)]
+    dec = upload(efx, blobs, efx.FORMAT_TS, max_pictures=12, ring_depth=13)
+    want = None
+    for rounds in (1, 2, 3, 4, 7):
+        for _ in range(rounds):
+            dec.decode(sync=False)
+        dec.sync()
+        got = [[dec.picture_pts(i, p) for p in range(dec.picture_count(i))] for i in range(8)]
+        h = dec.frame_hashes().copy()
+        if want is None:
+            want = (got, h)
+            assert got[0] == golden["synthetic"]["0:0"]["pts"]
+        assert got == want[0] and np.array_equal(h, want[1])
