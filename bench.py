@@ -3,22 +3,38 @@
 
 One "step" = one efx_decode() pass over the whole resident batch: start-code index, VLC parse,
 dequantisation, IDCT, half-pel motion compensation and strip-layout store of every picture of
-every stream.  Workload at N = 1 (BASELINE.json configs[2], the per-GPU shard of configs[4]):
-1024 synthetic 352x192 streams x one GOP(12) = I + 11 P pictures,
-bitstreams already resident in HBM when the timed region starts.  At N > 1 every rank decodes its
-own 1024 streams (ids rank*1024 ...): weak scaling, no collective on the data path; RCCL is only
-used for the barrier, the max-over-ranks time and the checksum-of-checksums report.
+every stream.  Workload (BASELINE.json configs[2], the per-GPU shard of configs[4]): 1024 synthetic
+352x192 streams per GPU x one GOP(12) = I + 11 P pictures, bitstreams
+already resident in HBM when the timed region starts.  Rank r of N decodes stream ids
+[r*1024, (r+1)*1024): weak scaling, no collective on the data path -- at N = 8 this IS configs[4]
+(8192 streams, stream k on rank floor(k*8/8192)).  RCCL is used for the barriers, the
+max-over-ranks time, the all-gather of per-stream frame-chain hashes and the counter sums.
+
+    python bench.py --gpus N --steps K --warmup W       N > 1 without a torchrun environment re-launches
+                                                         itself under torch.distributed.run (one rank per GPU)
+
+Parity gate: BEFORE the timed region every stream of the shard is decoded
+with all pictures kept and every picture's frame hash is compared with tests/golden/bench_*.u64 --
+the output of the unmodified reference decoder on the same streams (tests/golden/make_bench_golden.py).
+After the timed region the two frames left in the double buffer are compared again, the per-stream
+chain hashes are all-gathered and rank 0 checks the whole job against the golden table.  A mismatch
+aborts the run: no number is printed for a decoder that differs from the reference.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel's algorithmic GB/s vs the 8 TB/s HBM peak (HIP-event stage times
-                measured inside the timed region on the decode stream)
-  cpu_baseline  the unmodified reference decoder (oracle/_ref, kind "reference") -- or the C
-                restatement (kind "port") when the reference build is absent -- timed on this
-                box's host cores over the same TS-wrapped streams (N = 1, rank 0 only)
+  roofline          dominant kernel's algorithmic GB/s vs the 8 TB/s HBM peak (HIP-event stage times
+                    measured inside the timed region on the kernels' own streams)
+  cpu_baseline      the unmodified reference decoder (oracle/_ref, kind "reference") -- or the C
+                    restatement (kind "port") when the reference build is absent -- timed on this
+                    box's host cores over the same TS-wrapped streams (rank 0, every N)
+  fixed_batch_8192  SURVEY.md 8d config 5 as written: the fixed 8192-stream batch, stream k on rank
+                    floor(k*N/8192) (strong scaling), timed after the primary region
+  other_workloads   the service's real stream shape (5 slices per picture, ~6.25 kB per picture) and the
+                    reference's embedded clip replicated x1024, with stage times (N = 1 only)
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -31,18 +47,41 @@ sys.path.insert(0, ROOT)
 
 FRAME_BYTES = 101376
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+FIXED_BATCH = 8192
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+FNV_BASIS, FNV_PRIME, M64 = 0xCBF29CE484222325, 0x100000001B3, (1 << 64) - 1
+
+# name -> (generator flags, golden table, rows in the table, pictures per row)
+WORKLOADS = {
+    "gop12": (0, "bench_gop12.u64", 8192, 12),
+    "wide1500k": (4 | 32, "bench_wide1500k.u64", 1024, 12),
+}
+
+
+def log(msg):
+    sys.stderr.write(f"[bench rank {os.environ.get('RANK', '0')}] {msg}\n")
+    sys.stderr.flush()
 
 
 def pmc_traffic(kernel, S, P):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE, separate runs, gfx950 correction applied by tools/summarize_profiles.py).  PMC
-    counters cannot be collected from inside this process, so the figure is the one measured
-    on this exact workload (1024 streams x GOP 12) and None for any other."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_summary.json")
-    if (S, P) != (1024, 12) or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f)["kernels"].get(kernel, {}).get("hbm_traffic_bytes")
+    """(HBM bytes per launch of `kernel`, provenance) from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE, separate runs, gfx950 correction applied by
+    tools/summarize_profiles.py).  PMC counters cannot be collected from inside this process, so
+    the figure is the one measured on this exact workload (1024 streams x GOP 12), None otherwise."""
+    for name in ("r2_pmc_summary.json", "r1_pmc_summary.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if (S, P) != (1024, 12) or not os.path.exists(path):
+            continue
+        with open(path) as f:
+            v = json.load(f)["kernels"].get(kernel, {}).get("hbm_traffic_bytes")
+        sha = None
+        try:
+            sha = subprocess.run(["git", "log", "-1", "--format=%h", "--", path], cwd=ROOT, capture_output=True, text=True,
+                                 timeout=10).stdout.strip() or None
+        except (OSError, subprocess.SubprocessError):
+            pass
+        return v, {"file": "profiles/" + name, "commit": sha, "note": "separate rocprofv3 --pmc passes of this command, not this run"}
+    return None, None
 
 
 def algorithmic_bytes(es_bytes: int, n_i: int, n_p: int) -> int:
@@ -66,7 +105,27 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(batch, n_streams: int, n_pictures: int, budget_streams: int):
+def chain_hashes(table: np.ndarray) -> np.ndarray:
+    """Per-stream frame-chain hash: FNV-1a-64 over the 8 little-endian bytes of each
+    successive frame hash.  table: [streams][pictures] uint64."""
+    out = np.empty(table.shape[0], dtype=np.uint64)
+    for i, row in enumerate(np.ascontiguousarray(table, dtype="<u8")):
+        h = FNV_BASIS
+        for b in row.tobytes():
+            h = ((h ^ b) * FNV_PRIME) & M64
+        out[i] = h
+    return out
+
+
+def load_golden(workload: str):
+    flags, fname, rows, pics = WORKLOADS[workload]
+    path = os.path.join(GOLDEN_DIR, fname)
+    if not os.path.exists(path):
+        raise SystemExit(f"{path} is missing: the bench refuses to time a decoder it cannot check against the reference")
+    return np.fromfile(path, dtype="<u8").reshape(rows, pics)
+
+
+def cpu_baseline(batch, n_streams: int, n_pictures: int, budget_streams: int, seconds: float = 5.0):
     """Time the reference decoder on this host over the first `budget_streams` streams."""
     cores = usable_cores()
     n = min(n_streams, budget_streams)
@@ -81,8 +140,8 @@ def cpu_baseline(batch, n_streams: int, n_pictures: int, budget_streams: int):
                     path = os.path.join(td, f"{i}.ts")
                     batch.ts(i).tofile(path)
                     f.write(path + "\n")
-            # aim at ~5 s of wall time on all cores (the reference does ~2-4 k frames/s/core)
-            repeat = max(1, int(5.0 * cores * 3000 / (n * n_pictures)))
+            # aim at ~`seconds` of wall time on all cores (the reference does ~2-4 k frames/s/core)
+            repeat = max(1, int(seconds * cores * 3000 / (n * n_pictures)))
             try:
                 p = subprocess.run([ref, "bench", str(cores), lst, str(repeat)], stderr=subprocess.PIPE,
                                    stdout=subprocess.DEVNULL, text=True, timeout=150)
@@ -112,27 +171,327 @@ def _port_decode(ts):
     return n
 
 
-def main():
+# ---------------------------------------------------------------------------------------------------
+class Job:
+    """Rank-local state of one bench run: torch.distributed handle + the decoder factory.
+    `make_decoder(max_streams, max_pictures, ring_depth, max_stream_bytes)` returns an object with
+    the espflix_amd.Decoder interface; the gloo tests substitute a CPU stand-in to run this exact
+    control flow (partition, gate, gather, report) without a GPU."""
+
+    def __init__(self, rank, world, dist, device, make_decoder, local_world=None):
+        self.rank, self.world, self.dist, self.device, self.make_decoder = rank, world, dist, device, make_decoder
+        self.local_world = local_world or world
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.device == "cuda":
+            import torch
+            torch.cuda.synchronize()
+
+
+def gate_against_golden(dec_factory, streams, ids, golden, P, what):
+    """Decode `streams` once with every picture kept and compare every frame hash with the golden
+    table (rows = stream ids).  Returns the [n][P] table actually decoded."""
+    S = len(streams)
+    es_bytes = int(sum(s.size for s in streams))
+    dec = dec_factory(S, P, P + 1, es_bytes + 64 * S)
+    dec.upload(streams, 0)
+    dec.decode()
+    hashes = dec.frame_hashes()
+    got = np.empty((S, P), dtype=np.uint64)
+    for p in range(P):
+        got[:, p] = hashes[:, dec.picture_slot(p)]
+    counts = np.array([dec.picture_count(i) for i in range(S)])
+    status = np.array([dec.stream_status(i) for i in range(S)])
+    dec.close()
+    if not (counts == P).all() or status.any():
+        bad = np.nonzero((counts != P) | (status != 0))[0][:8]
+        raise SystemExit(f"parity gate ({what}): streams {[int(ids[b]) for b in bad]} decoded {counts[bad]} pictures, status {status[bad]}")
+    want = golden[np.asarray(ids) % golden.shape[0]]
+    if not np.array_equal(got, want):
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        raise SystemExit(f"parity gate ({what}): {bad.size} of {S} streams differ from the reference decoder, first ids "
+                         f"{[int(ids[b]) for b in bad[:8]]}")
+    return got
+
+
+def timed_region(job, dec, steps, warmup, overlap=True):
+    """W untimed + K timed efx_decode passes, barrier + synchronize on both sides, max over ranks."""
+    from espflix_amd import dist as edist
+    for _ in range(warmup):  # same enqueue pattern as the timed steps
+        dec.decode(sync=not overlap)
+    dec.sync()
+    job.barrier()
+    dec.set_timing(True)  # new averaging window: the stage times cover exactly the timed steps
+    t0 = time.perf_counter()
+    # Steps are enqueued back to back: libefx runs the parse half of step k+1 (parse stream)
+    # while the reconstruction half of step k is still on the GPU (double-buffered hand-over),
+    # exactly what a service decoding batch after batch does.  Every step still performs the
+    # complete decode of the whole batch; all K steps finish inside the timed region.
+    for _ in range(steps):
+        dec.decode(sync=not overlap)
+    dec.sync()
+    job.barrier()
+    elapsed = time.perf_counter() - t0
+    return edist.max_over_ranks(elapsed, job.dist, job.device)
+
+
+def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_serial=True):
+    """Generate, gate, time one workload on this rank.  Returns a dict of rank-local + job results."""
+    from espflix_amd import dist as edist
+    from espflix_amd import gen
+    flags, _, _, P = WORKLOADS[workload]
+    golden = load_golden(workload)
+    t_gen = time.perf_counter()
+    # ids are contiguous per rank (or wrapped for the small tables): generate in runs of consecutive ids
+    batches, streams = [], []
+    start = 0
+    while start < S:
+        end = start + 1
+        while end < S and ids[end] == ids[end - 1] + 1:
+            end += 1
+        b = gen.Batch(int(ids[start]), end - start, P, 12, flags, gen_threads)
+        batches.append((start, b))
+        streams.extend(b.all_es())
+        start = end
+    t_gen = time.perf_counter() - t_gen
+    es_bytes = int(sum(s.size for s in streams))
+    n_i = S * ((P + 11) // 12)
+    n_p = S * P - n_i
+
+    got = gate_against_golden(job.make_decoder, streams, ids, golden, P, f"{workload}, before timing")
+
+    dec = job.make_decoder(S, P, 2, es_bytes + 64 * S)
+    dec.upload(streams, 0)  # bitstreams resident in HBM from here on
+    dec.set_timing(True)
+    elapsed = timed_region(job, dec, steps, warmup, overlap=not args.no_overlap)
+    t = dec.timing()
+    stage_ms = np.array([t.index_ms, t.parse_ms, t.recon_ms])
+    timed_calls = t.timed_calls
+
+    # the double buffer now holds pictures P-2 and P-1 of every stream: compare them with the reference again
+    assert t.pictures == S * P, (t.pictures, S * P)
+    bad = [i for i in range(S) if dec.stream_status(i) != 0]
+    assert not bad, f"streams with non-zero status: {bad[:8]}"
+    hashes = dec.frame_hashes()
+    for p in (P - 2, P - 1):
+        if p >= 0 and not np.array_equal(hashes[:, dec.picture_slot(p)], got[:, p]):
+            raise SystemExit(f"parity gate ({workload}, after timing): picture {p} differs from the reference decoder")
+    n_coefs = t.coefficients
+
+    # whole-job check: all-gather the per-stream chain hashes, rank 0 compares with the golden table
+    chains = edist.gather_u64(chain_hashes(got), job.dist, job.device, job.world)
+    all_ids = edist.gather_u64(np.asarray(ids, dtype=np.uint64), job.dist, job.device, job.world)
+    totals = edist.sum_over_ranks([S * P, es_bytes, int(n_coefs)], job.dist, job.device)
+    if job.rank == 0:
+        want = chain_hashes(golden[all_ids.astype(np.int64) % golden.shape[0]])
+        if not np.array_equal(chains, want):
+            raise SystemExit(f"parity gate ({workload}): gathered chain hashes differ from the reference on {int((chains != want).sum())} streams")
+
+    serial_ms = None
+    if want_serial:
+        # outside the timed region: the same stages one call at a time (no overlap between calls), for
+        # the uncontended per-kernel figures quoted next to the timed-region ones
+        dec.set_timing(True)
+        for _ in range(3):
+            dec.decode(sync=True)
+        ts = dec.timing()
+        serial_ms = [ts.index_ms, ts.parse_ms, ts.recon_ms]
+    dec.close()
+    with np.errstate(over="ignore"):
+        csum = int(np.bitwise_xor.reduce(chains * edist.GOLDEN)) if chains.size else 0
+    return {"workload": workload, "S": S, "P": P, "es_bytes": es_bytes, "n_i": n_i, "n_p": n_p, "elapsed": elapsed,
+            "stage_ms": stage_ms, "serial_ms": serial_ms, "timed_calls": timed_calls, "n_coefs": int(n_coefs),
+            "gen_seconds": t_gen, "batch0": batches[0][1], "job_pictures": totals[0], "job_es_bytes": totals[1],
+            "checksum": csum, "streams_checked": int(chains.size), "first_id": int(ids[0]), "last_id": int(ids[-1])}
+
+
+def run_clip(job, args, clip, S, steps):
+    """The reference's own embedded clip (src/vmedia.h / src/splash.h, dumped to tests/golden/*.ts),
+    replicated S times as transport-stream input: real ffmpeg output, 5 slices per picture.  Gated
+    against the reference's per-picture hashes (tests/golden/golden.json), then timed."""
+    with open(os.path.join(GOLDEN_DIR, "golden.json")) as f:
+        g = json.load(f)["clips"][clip]
+    want = np.array([int(h, 16) for h in g["hashes"]], dtype=np.uint64)
+    P = want.size
+    ts = np.fromfile(os.path.join(GOLDEN_DIR, clip + ".ts"), dtype=np.uint8)
+    streams = [ts] * S
+    dec = job.make_decoder(S, P, P + 1, (ts.size + 64) * S)
+    dec.upload(streams, 1)
+    dec.decode()
+    hashes = dec.frame_hashes()
+    for p in range(P):
+        if not (hashes[:, dec.picture_slot(p)] == want[p]).all():
+            raise SystemExit(f"parity gate (clip {clip}): picture {p} differs from the reference decoder")
+    if any(dec.picture_count(i) != P or dec.stream_status(i) for i in range(S)):
+        raise SystemExit(f"parity gate (clip {clip}): picture count / status")
+    dec.close()
+    dec = job.make_decoder(S, P, 2, (ts.size + 64) * S)
+    dec.upload(streams, 1)
+    dec.set_timing(True)
+    elapsed = timed_region(job, dec, steps, 1, overlap=not args.no_overlap)
+    t = dec.timing()
+    h2 = dec.frame_hashes()
+    if not (h2[:, dec.picture_slot(P - 1)] == want[P - 1]).all():
+        raise SystemExit(f"parity gate (clip {clip}, after timing): last picture differs")
+    dec.close()
+    return {"what": f"tests/golden/{clip}.ts (the reference's embedded clip: ffmpeg output, {P} pictures, 5 slices per picture) x {S} as "
+                    "transport-stream input (k_demux on upload, not timed), every picture gated against the reference decoder",
+            "frames_per_s": S * P * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "pictures_per_stream": int(P),
+            "mean_ts_bytes_per_picture": ts.size / P,
+            "stage_ms": {"k_index(+scan,emit)": t.index_ms, "k_parse": t.parse_ms, f"k_recon x{P}": t.recon_ms}}
+
+
+def stage_report(r, steps):
+    names = ["k_index(+scan,emit)", "k_parse", "k_recon x%d" % r["P"]]
+    out = {"frames_per_s": r["job_pictures"] * steps / r["elapsed"], "ms_per_step": r["elapsed"] / steps * 1e3,
+           "mean_bytes_per_picture": r["es_bytes"] / (r["S"] * r["P"]),
+           "stage_ms": dict(zip(names, [float(x) for x in r["stage_ms"]]))}
+    if r["serial_ms"] is not None:
+        out["serial_stage_ms"] = dict(zip(names, [float(x) for x in r["serial_ms"]]))
+    return out
+
+
+def run(job, args):
+    from espflix_amd import dist as edist
+    rank, world = job.rank, job.world
+    S = args.streams
+    threads = max(1, usable_cores() // max(1, job.local_world))
+    first, _ = edist.shard(rank, world, S)
+    ids = np.arange(first, first + S)
+    if world > 1 and rank == 0:
+        log(f"{'RCCL' if job.device == 'cuda' else 'gloo'} saw {world} ranks")
+
+    r = run_workload(job, args, "gop12", S, ids, threads, args.steps, args.warmup)
+    P = r["P"]
+
+    # SURVEY 8d config 5 as written: the FIXED 8192-stream batch, stream k on rank floor(k*N/8192)
+    fixed = None
+    if not args.no_fixed_batch:
+        if S * world == args.fixed_batch:
+            fixed = {"same_as_primary": True}
+        else:
+            lo, hi = edist.shard_fixed(rank, world, args.fixed_batch)
+            fsteps = max(2, min(args.steps, 10))
+            fr = run_workload(job, args, "gop12", hi - lo, np.arange(lo, hi), threads, fsteps, 2, want_serial=False)
+            fixed = {"steps": fsteps}
+            fixed.update(stage_report(fr, fsteps))
+            fixed["streams_per_gpu"] = hi - lo
+        fixed["streams_total"] = args.fixed_batch
+        fixed["partition"] = f"stream k -> rank floor(k*{world}/{args.fixed_batch})"
+        fixed["scaling"] = "strong"
+
+    others = None
+    if world == 1 and not args.no_other_workloads:
+        others = {}
+        ow = run_workload(job, args, "wide1500k", S, np.arange(S) % WORKLOADS["wide1500k"][2], threads, min(args.steps, 10), 2)
+        others["wide_slices_1500k"] = {"what": f"{S} streams x GOP(12), 5 slices per picture spanning 2-3 macroblock rows, quantiser "
+                                               "chosen per stream for ~6.25 kB per picture (the service's 1.5 Mbit/s profile, reference "
+                                               "indexer/indexer.cpp:306-309), every picture gated against the reference decoder",
+                                       **stage_report(ow, min(args.steps, 10))}
+        others["vmedia_x%d" % S] = run_clip(job, args, "vmedia", S, max(2, min(args.steps, 5)))
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(r["batch0"], S, P, 1024, args.cpu_baseline_seconds)
+    job.barrier()
+
+    if rank != 0:
+        return None
+    steps = args.steps
+    value = r["job_pictures"] * steps / r["elapsed"]
+    stage_ms = r["stage_ms"]
+    names = ["k_index(+scan,emit)", "k_parse", "k_recon x%d" % P]
+    alg = algorithmic_bytes(r["es_bytes"], r["n_i"], r["n_p"])
+    # The roofline object is k_recon's: it is the kernel that moves SURVEY 8d's algorithmic bytes (the
+    # frames); k_parse, which only reads the bitstream and writes 4 B per coefficient + 16 B per
+    # macroblock, is reported next to it.
+    alg_launch = alg / P
+    dur_s = stage_ms[2] / 1e3 / P
+    achieved = alg_launch / dur_s / 1e9
+    parse_bytes = r["es_bytes"] + 4 * r["n_coefs"] + 16 * S * P * 264
+    traffic, traffic_src = pmc_traffic("efx::k_recon", S, P)
+    ptraffic, _ = pmc_traffic("efx::k_parse", S, P)
+    serial_ms = r["serial_ms"]
+    out = {
+        "metric": "MPEG-1 352x192 frames/s", "value": value, "unit": "frames/s", "n_gpus": world,
+        "steps": steps, "warmup": args.warmup, "ms_per_step": r["elapsed"] / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
+        "config": {"workload": f"{S} streams/GPU x GOP(12) I+11P, 352x192 MPEG-1 ES resident in HBM, ids rank*{S}.. per rank "
+                               f"(BASELINE configs[2]; at 8 GPUs = configs[4], stream k on rank floor(k*8/8192))",
+                   "streams_per_gpu": S, "streams_total": S * world, "pictures_per_stream": P, "es_bytes_per_gpu": r["es_bytes"],
+                   "mean_bytes_per_picture": r["es_bytes"] / (S * P), "parallelism": f"stream-partition x{world}",
+                   "coefficients_per_gpu": r["n_coefs"], "ring_depth": 2},
+        "roofline": {"bound": "hbm", "limiter": "VALU issue (see DESIGN.md section 6)", "kernel": names[2], "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": alg_launch, "avg_launch_ms": dur_s * 1e3,
+                     "whole_step_achieved_GBs": alg / (r["elapsed"] / steps) / 1e9,
+                     "whole_step_frac": alg / (r["elapsed"] / steps) / 1e9 / HBM_PEAK_GBS,
+                     "stage_ms": dict(zip(names, [float(x) for x in stage_ms])),
+                     "timed_calls_averaged": r["timed_calls"],
+                     "note": "stage_ms / avg_launch_ms are means over the timed steps, where the parse half of "
+                             "later steps shares the GPU with k_recon; serial_* = the same stages one call at a "
+                             "time, measured after the timed region",
+                     "serial_stage_ms": dict(zip(names, [float(x) for x in serial_ms])),
+                     "serial_frac": alg / P / (serial_ms[2] / P / 1e3) / 1e9 / HBM_PEAK_GBS,
+                     "k_parse": {"algorithmic_bytes_per_launch": parse_bytes, "avg_launch_ms": float(stage_ms[1]),
+                                 "achieved": parse_bytes / (stage_ms[1] / 1e3) / 1e9,
+                                 "serial_launch_ms": float(serial_ms[1]), "traffic": ptraffic,
+                                 "bound": "serial symbol chains (VALU issue), not bandwidth"}},
+        "parity_gate": {"reference": "tests/golden/bench_gop12.u64 (unmodified reference decoder, tests/golden/make_bench_golden.py)",
+                        "streams_checked": r["streams_checked"], "pictures_checked_per_stream": P,
+                        "when": "every picture before the timed region; pictures P-2, P-1 again after it; chain hashes of all "
+                                "ranks gathered and compared on rank 0", "passed": True},
+        "checksum_of_checksums": f"{r['checksum']:016x}",
+        "gen_seconds": r["gen_seconds"],
+        "fixed_batch_8192": fixed,
+        "other_workloads": others,
+        "cpu_baseline": cpu,
+    }
+    return out
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: run the same command line under
+    torch.distributed.run, one rank per GPU, and pass its output through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
-    ap.add_argument("--pictures", type=int, default=12)
+    ap.add_argument("--fixed-batch", type=int, default=FIXED_BATCH, help="streams of the fixed (strong-scaling) batch")
+    ap.add_argument("--no-fixed-batch", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=5.0, help="wall-time target of the CPU baseline leg")
     ap.add_argument("--no-overlap", action="store_true", help="synchronise after every step (no cross-step pipelining)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import torch
     import espflix_amd as efx
-    from espflix_amd import gen
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: espflix_amd has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -141,117 +500,15 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from espflix_amd import dist as edist
-    first, S = edist.shard(rank, world, args.streams)
-    P = args.pictures
-    threads = max(1, usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
-    t_gen = time.perf_counter()
-    batch = gen.Batch(first, S, P, 12, 0, threads)
-    streams = batch.all_es()
-    t_gen = time.perf_counter() - t_gen
-    es_bytes = int(sum(s.size for s in streams))
-    n_i = S * ((P + 11) // 12)
-    n_p = S * P - n_i
+    def make_decoder(max_streams, max_pictures, ring_depth, max_stream_bytes):
+        return efx.Decoder(max_streams=max_streams, max_pictures=max_pictures, ring_depth=ring_depth, device=local_rank,
+                           max_stream_bytes=max_stream_bytes)
 
-    dec = efx.Decoder(max_streams=S, max_pictures=P, ring_depth=2, device=local_rank, max_stream_bytes=es_bytes + 64 * S)
-    dec.upload(streams, efx.FORMAT_ES)  # bitstreams resident in HBM from here on
-    dec.set_timing(True)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):  # same enqueue pattern as the timed steps
-        dec.decode(sync=args.no_overlap)
-    dec.sync()
-    barrier()
-    dec.set_timing(True)  # new averaging window: the stage times below cover exactly the timed steps
-    t0 = time.perf_counter()
-    # Steps are enqueued back to back: libefx runs the parse half of step k+1 (parse stream)
-    # while the reconstruction half of step k is still on the GPU (double-buffered hand-over),
-    # exactly what a service decoding batch after batch does.  Every step still performs the
-    # complete decode of the whole batch; all K steps finish inside the timed region.
-    for _ in range(args.steps):
-        dec.decode(sync=args.no_overlap)
-    dec.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # stage times: HIP events on the kernels' own streams, mean over the timed steps (the last 64)
-    t = dec.timing()
-    stage = np.array([t.index_ms, t.parse_ms, t.recon_ms]) * args.steps
-    elapsed = edist.max_over_ranks(elapsed, dist, "cuda")
-
-    # verification riding along: every stream decoded all its pictures with a clean status, and
-    # a checksum of the per-stream frame checksums (deterministic for a given shard)
-    t = dec.timing()
-    assert t.pictures == S * P, (t.pictures, S * P)
-    bad = [i for i in range(S) if dec.stream_status(i) != 0]
-    assert not bad, f"streams with non-zero status: {bad[:8]}"
-    hashes = dec.frame_hashes()
-    csum = edist.xor_over_ranks(edist.frame_checksum(hashes), dist, "cuda", world)
-    n_coefs = t.coefficients
-
-    # outside the timed region: the same stages one call at a time (no overlap between calls), for
-    # the uncontended per-kernel figures quoted next to the timed-region ones
-    dec.set_timing(True)
-    for _ in range(3):
-        dec.decode(sync=True)
-    ts = dec.timing()
-    serial_ms = [ts.index_ms, ts.parse_ms, ts.recon_ms]
-
+    job = Job(rank, world, dist, "cuda", make_decoder, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    out = run(job, args)
     if rank == 0:
-        frames = world * S * P * args.steps
-        value = frames / elapsed
-        stage_ms = stage / args.steps
-        names = ["k_index(+scan,emit)", "k_parse", "k_recon x%d" % P]
-        alg = algorithmic_bytes(es_bytes, n_i, n_p)
-        # The two halves take about the same GPU time (k_parse 1 launch, k_recon P launches).  The
-        # roofline object is k_recon's: it is the kernel that moves SURVEY 8d's algorithmic bytes (the
-        # frames); k_parse, which only reads the bitstream and writes 4 B per coefficient + 16 B per
-        # macroblock, is reported next to it.
-        k = 2
-        launches = [1, 1, P]
-        alg_launch = alg / P
-        dur_s = stage_ms[k] / 1e3 / launches[k]
-        achieved = alg_launch / dur_s / 1e9
-        parse_bytes = es_bytes + 4 * n_coefs + 16 * S * P * 264
-        traffic = pmc_traffic("efx::k_recon", S, P)
-        out = {
-            "metric": "MPEG-1 352x192 frames/s", "value": value, "unit": "frames/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
-            "config": {"workload": f"{S} streams/GPU x GOP(12) I+11P, 352x192 MPEG-1 ES resident in HBM, "
-                                   f"ids {first}..{first + S - 1} per rank (BASELINE configs[2]; shard of configs[4])",
-                       "streams_per_gpu": S, "pictures_per_stream": P, "es_bytes_per_gpu": es_bytes,
-                       "mean_bytes_per_picture": es_bytes / (S * P), "parallelism": f"stream-partition x{world}",
-                       "coefficients_per_gpu": int(n_coefs),
-                       "ring_depth": 2},
-            "roofline": {"bound": "hbm", "kernel": names[k], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_launch, "avg_launch_ms": dur_s * 1e3,
-                         "whole_step_achieved_GBs": alg / (elapsed / args.steps) / 1e9,
-                         "stage_ms": dict(zip(names, [float(x) for x in stage_ms])),
-                         "timed_calls_averaged": t.timed_calls,
-                         "note": "stage_ms / avg_launch_ms are means over the timed steps, where the parse half of "
-                                 "later steps shares the GPU with k_recon; serial_* = the same stages one call at a "
-                                 "time, measured after the timed region",
-                         "serial_stage_ms": dict(zip(names, [float(x) for x in serial_ms])),
-                         "serial_frac": alg / P / (serial_ms[2] / P / 1e3) / 1e9 / HBM_PEAK_GBS,
-                         "k_parse": {"algorithmic_bytes_per_launch": parse_bytes, "avg_launch_ms": float(stage_ms[1]),
-                                     "achieved": parse_bytes / (stage_ms[1] / 1e3) / 1e9,
-                                     "serial_launch_ms": float(serial_ms[1]),
-                                     "traffic": pmc_traffic("efx::k_parse", S, P),
-                                     "bound": "serial symbol chains (VALU issue), not bandwidth"}},
-            "checksum_of_checksums": f"{csum:016x}",
-            "gen_seconds": t_gen,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(batch, S, P, 1024)
-        else:
-            out["cpu_baseline"] = None
         print(json.dumps(out))
-    dec.close()
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -3,7 +3,8 @@
 Streams are fully independent, so scaling is a pure partition: rank r owns stream ids
 [r * per_gpu, (r + 1) * per_gpu) and no collective touches the data path.  torch.distributed
 (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests) is used only for the
-bracketing barrier, the max-over-ranks wall time and the checksum-of-checksums report.
+bracketing barrier, the max-over-ranks wall time, the all-gather of per-stream frame-chain hashes
+(8 bytes per stream) and the counter sums.
 """
 from __future__ import annotations
 
@@ -17,6 +18,16 @@ def shard(rank: int, world: int, per_gpu: int):
     if not (0 <= rank < world) or per_gpu <= 0:
         raise ValueError("bad shard arguments")
     return rank * per_gpu, per_gpu
+
+
+def shard_fixed(rank: int, world: int, total: int):
+    """[lo, hi) of a FIXED batch of `total` streams owned by `rank`: stream k lives on rank
+    floor(k * world / total), i.e. lo = ceil(rank * total / world)."""
+    if not (0 <= rank < world) or total <= 0:
+        raise ValueError("bad shard arguments")
+    lo = -(-rank * total // world)
+    hi = -(-(rank + 1) * total // world)
+    return lo, hi
 
 
 def frame_checksum(hashes: np.ndarray) -> int:
@@ -48,3 +59,33 @@ def xor_over_ranks(csum: int, dist, device, world: int) -> int:
         a, b, c = (int(x) for x in o.tolist())
         total ^= a | (b << 31) | (c << 62)
     return total
+
+
+def gather_u64(values: np.ndarray, dist, device, world: int) -> np.ndarray:
+    """all_gather of one uint64 array per rank (per-stream chain hashes: 8 bytes per stream, 64 KiB for
+    the 8192-stream job), concatenated in rank order.  Ranks may hold different counts."""
+    import torch
+    v = np.ascontiguousarray(values, dtype=np.uint64)
+    if dist is None:
+        return v.copy()
+    n = torch.tensor([v.size], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    cap = max(counts)
+    buf = np.zeros(cap, dtype=np.int64)
+    buf[: v.size] = v.view(np.int64)
+    mine = torch.from_numpy(buf).to(device)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return np.concatenate([o.cpu().numpy()[:c] for o, c in zip(out, counts)]).view(np.uint64)
+
+
+def sum_over_ranks(values, dist, device):
+    """all_reduce(sum) of a few integer counters (pictures, bytes, coefficients)."""
+    import torch
+    if dist is None:
+        return [int(x) for x in values]
+    t = torch.tensor([int(x) for x in values], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(x) for x in t.tolist()]

@@ -15,6 +15,7 @@ FLAG_CUSTOM_MATRICES = 2
 FLAG_WIDE_SLICES = 4
 FLAG_LONG_SKIPS = 8
 FLAG_FLAT_BRIGHT = 16
+FLAG_RATE_1500K = 32   # mean picture ~6.25 kB (1.5 Mbit/s at 30 Hz, the service's profile)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libefx_gen.so")

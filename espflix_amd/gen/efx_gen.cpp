@@ -35,6 +35,8 @@ enum : uint32_t {
     FLAG_WIDE_SLICES = 4,    // slices span 2-3 macroblock rows (5 slices, like ffmpeg's output)
     FLAG_LONG_SKIPS = 8,     // P pictures contain skip runs > 33 (macroblock_escape) and stuffing
     FLAG_FLAT_BRIGHT = 16,   // source has flat 255 areas (unclamped DC-only intra blocks)
+    FLAG_RATE_1500K = 32,    // quantiser chosen per stream so that the mean picture is ~6.25 kB: the service's
+                             // 1.5 Mbit/s at 30 Hz (reference indexer/indexer.cpp:306-309)
 };
 
 struct Lcg {
@@ -246,10 +248,10 @@ struct Encoder {
     int ox = 0, oy = 0;  // cumulative source offset
     std::vector<uint32_t> pic_offsets;
 
-    explicit Encoder(uint32_t stream, uint32_t fl) : k(stream), flags(fl)
+    explicit Encoder(uint32_t stream, uint32_t fl, int q_override = 0) : k(stream), flags(fl)
     {
         rng.s = 0xE5F10000u + stream;
-        qscale_base = 3 + (stream & 7);
+        qscale_base = q_override ? q_override : 4 + (int)(stream & 7);
         f_code = (stream & 1) ? 2 : 1;
         full_pel = (stream & 7) == 7;
         memcpy(intra_q, efx::kDefaultIntraQ, 64);
@@ -757,6 +759,34 @@ void* efxgen_batch_create(uint32_t first_id, int n_streams, int n_pictures, int 
             int i = next.fetch_add(1);
             if (i >= n_streams)
                 break;
+            if (flags & FLAG_RATE_1500K) {
+                // quantiser_scale whose stream size is closest to the target: bisection for the largest
+                // scale still at or above it (size falls with the scale), then the neighbour is tried
+                const size_t target = (size_t)6250 * n_pictures;
+                auto size_at = [&](int q) {
+                    Encoder t(first_id + (uint32_t)i, flags, q);
+                    t.run(n_pictures, gop);
+                    return t.bw.buf.size();
+                };
+                int lo = 1, hi = 31;
+                while (lo < hi) {
+                    int mid = (lo + hi + 1) / 2;
+                    if (size_at(mid) >= target)
+                        lo = mid;
+                    else
+                        hi = mid - 1;
+                }
+                if (lo < 31) {
+                    const size_t a = size_at(lo), b2 = size_at(lo + 1);
+                    if (a > target && b2 < target && target - b2 < a - target)
+                        lo++;
+                }
+                Encoder e(first_id + (uint32_t)i, flags, lo);
+                e.run(n_pictures, gop);
+                b->es[i].swap(e.bw.buf);
+                b->offs[i].swap(e.pic_offsets);
+                continue;
+            }
             Encoder e(first_id + (uint32_t)i, flags);
             e.run(n_pictures, gop);
             b->es[i].swap(e.bw.buf);
