@@ -36,9 +36,6 @@ __global__ void k_fill(uint32_t*, uint32_t, size_t);
 __global__ void k_composite(const uint8_t*, const VideoTables*, const VideoLineTemplates*, FieldArgs, uint16_t*);
 __global__ void k_pdm(const int16_t*, int, int, int32_t*, uint16_t*);
 __global__ void k_sbc(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int);
-#ifdef EFX_PARSE_PROFILE
-__global__ void k_parse_set_prof(uint32_t*);
-#endif
 }  // namespace efx
 
 using namespace efx;
@@ -1052,17 +1049,6 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out)
     return EFX_OK;
 }
 
-#ifdef EFX_PARSE_PROFILE
-// development aid (libefx_prof.so only): per-slice {cycles, loop iterations, coefficients, bytes}
-int efx_debug_parse_profile(efx_ctx* ctx, uint32_t* dptr)
-{
-    for (auto ps : ctx->parse_streams) {
-        hipLaunchKernelGGL(k_parse_set_prof, dim3(1), dim3(1), 0, ps, dptr);
-        EFX_HIP(hipStreamSynchronize(ps));
-    }
-    return EFX_OK;
-}
-#endif
 
 int efx_device_alloc(efx_ctx* ctx, size_t bytes, void** dptr)
 {

@@ -29,10 +29,6 @@
 
 namespace efx {
 
-#ifdef EFX_PARSE_PROFILE
-__device__ uint32_t* g_parse_prof = nullptr;  // development aid: per-slice timing records
-__global__ void k_parse_set_prof(uint32_t* p) { g_parse_prof = p; }
-#endif
 
 namespace {
 
@@ -248,10 +244,6 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
 
     BitReader br;
     br.init(es, d.es_off, &sh.ring[threadIdx.x >> 6][0][threadIdx.x & 63]);
-#ifdef EFX_PARSE_PROFILE
-    const unsigned long long prof_t0 = __builtin_readcyclecounter();
-    uint32_t prof_iters = 0, prof_mbs = 0;
-#endif
 
     uint32_t st = 0;
     uint32_t n_coefs = 0, n_mbs = 0;
@@ -434,10 +426,6 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
             bool dropped = false;
             uint32_t cont;
             do {
-#ifdef EFX_PARSE_PROFILE
-                if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1)
-                    prof_iters++;
-#endif
                 br.topup();
                 win = br.window();
                 const uint32_t pk = win >> 16;
@@ -483,21 +471,6 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
             break;
         }
     }
-#ifdef EFX_PARSE_PROFILE
-    {
-        // per-lane record: [gid] = {cycles, coef-loop iterations this lane led, own symbols, bytes}
-        unsigned long long t1 = __builtin_readcyclecounter();
-        uint32_t* prof = coefs + (size_t)counters->total_slices * 0;  // placeholder, see below
-        (void)prof;
-        if (g_parse_prof) {
-            g_parse_prof[gid * 4 + 0] = (uint32_t)(t1 - prof_t0);
-            g_parse_prof[gid * 4 + 1] = prof_iters;
-            g_parse_prof[gid * 4 + 2] = n_coefs;
-            g_parse_prof[gid * 4 + 3] = d.es_len | (i_picture ? 0x80000000u : 0);
-        }
-        (void)prof_mbs;
-    }
-#endif
     if (st)
         atomicOr(&status[d.stream], st);
     atomicAdd(&counters->coefficients, (unsigned long long)n_coefs);

@@ -279,6 +279,7 @@ typedef struct {
     frame_t* ref;
     frame_t* curf;
     int bad_size;
+    int custom_q; /* the sequence header in force loaded a quantiser matrix (trace only) */
     int ended;
 
     /* results */
@@ -289,6 +290,21 @@ typedef struct {
     uint64_t* hash_out;
     long max_frames;
 } dec_t;
+
+/* optional parse trace (tests/parse_harness.cpp): every slice, macroblock, coefficient and block
+ * result in decode order, see efx_oracle.h */
+static efxo_trace_fn trace_fn;
+static void* trace_user;
+void efxo_set_trace(efxo_trace_fn fn, void* user)
+{
+    trace_fn = fn;
+    trace_user = user;
+}
+#define TRACE(kind, a, b, c, e) \
+    do { \
+        if (trace_fn) \
+            trace_fn(trace_user, kind, a, b, c, e); \
+    } while (0)
 
 static const uint8_t eos_pad[8] = {0, 0, 1, 0xB7, 0, 0, 1, 0xB7}; /* player.cpp:456 */
 
@@ -449,15 +465,18 @@ static void sequence_header(dec_t* d) /* player.cpp:658-678 */
     get_bits(d, 4);  /* picture rate */
     get_bits(d, 18); /* bit rate */
     get_bits(d, 12); /* marker, vbv buffer size, constrained flag */
+    d->custom_q = 0;
     if (get_bits(d, 1)) {
         /* stored in arrival (zig-zag) order and later indexed by raster position: kept as is */
         for (int i = 0; i < 64; i++)
             d->intra_q[i] = (uint8_t)get_bits(d, 8);
+        d->custom_q = 1;
     } else
         memcpy(d->intra_q, intra_default, 64);
     if (get_bits(d, 1)) {
         for (int i = 0; i < 64; i++)
             d->non_intra_q[i] = (uint8_t)get_bits(d, 8);
+        d->custom_q = 1;
     } else
         memset(d->non_intra_q, 16, 64);
     d->mb_width = (w + 15) >> 4;
@@ -702,10 +721,12 @@ static int decode_block(dec_t* d, int blk, int intra)
             else
                 d->dc_y = b[0];
         }
+        TRACE(EFXO_T_COEF, blk, 0, b[0], 0);
         b[0] = (int)((unsigned)b[0] << 8);
         q = d->intra_q;
         n = 1;
     }
+    int count = n;
 
     for (;;) { /* run/level pairs, player.cpp:1070-1122 */
         int p = peek_bits(d, 2);
@@ -721,8 +742,10 @@ static int decode_block(dec_t* d, int blk, int intra)
         } else {
             int ok = 1;
             int rl = get_vlc(d, &T_dct, &ok);
-            if (!ok)
+            if (!ok) {
+                TRACE(EFXO_T_BLOCK, blk, -2, count, 0);
                 return -2;
+            }
             if (rl == -1) { /* escape: 6 bit run, 8 or 16 bit level (player.cpp:1092-1099) */
                 run = get_bits(d, 6);
                 v = get_bits(d, 8);
@@ -740,8 +763,12 @@ static int decode_block(dec_t* d, int blk, int intra)
             }
         }
         n += run;
-        if (n >= 64)
+        if (n >= 64) {
+            TRACE(EFXO_T_BLOCK, blk, -1, count, 0);
             return -1;
+        }
+        TRACE(EFXO_T_COEF, blk, n, v, 0);
+        count++;
         int zz = zigzag[n++];
 
         /* reconstruction, player.cpp:1110-1121 */
@@ -758,6 +785,7 @@ static int decode_block(dec_t* d, int blk, int intra)
         b[zz] = v * premul[zz];
     }
 
+    TRACE(EFXO_T_BLOCK, blk, 0, count, 0);
     /* destination, player.cpp:1124-1131 */
     int plane = blk < 4 ? 0 : blk - 3;
     int px, py;
@@ -826,6 +854,11 @@ static void decode_slice(dec_t* d, int code)
 {
     d->mb_y = code - 2;
     d->mb_x = d->mb_width - 1; /* first advance wraps to column 0 of row code-1 */
+    {
+        int rejected = d->mb_y >= d->mb_height || d->bad_size || d->mb_width == 0;
+        TRACE(EFXO_T_SLICE, (int)d->pictures - 1, code,
+              d->pic_type | (d->full_pel << 4) | (d->r_size << 8) | (rejected ? 0 : 1 << 16), d->custom_q);
+    }
     if (d->mb_y >= d->mb_height || d->bad_size || d->mb_width == 0)
         return;
     reset_predictors(d);
@@ -861,6 +894,7 @@ static void decode_slice(dec_t* d, int code)
                 if (!advance_mb(d))
                     return;
                 predict_zero(d); /* skipped macroblocks copy the reference */
+                TRACE(EFXO_T_MB, d->mb_y * d->mb_width + d->mb_x, 2, 0, 0);
                 inc--;
             }
             if (!advance_mb(d))
@@ -889,6 +923,8 @@ static void decode_slice(dec_t* d, int code)
         int cbp = (type & 2) ? get_vlc(d, &T_cbp, &ok) : (intra ? 63 : 0);
         if (!ok)
             return;
+        TRACE(EFXO_T_MB, d->mb_y * d->mb_width + d->mb_x, intra | (d->qscale << 2), d->full_pel ? d->mv_h << 1 : d->mv_h,
+              d->full_pel ? d->mv_v << 1 : d->mv_v);
         for (int blk = 0; blk < 6; blk++)
             if (cbp & (0x20 >> blk))
                 if (decode_block(d, blk, intra) == -2)

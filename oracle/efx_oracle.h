@@ -39,6 +39,16 @@ enum { EFXO_FMT_ES = 0, EFXO_FMT_TS = 1 };
 long efxo_decode(const uint8_t* data, size_t len, int format, int flush_last,
                  uint8_t* frames_out, int64_t* pts_out, uint64_t* hash_out, long max_frames);
 
+/* Parse trace for tests/parse_harness.cpp: when a callback is set, efxo_decode reports, in decode order,
+ *   EFXO_T_SLICE  a = picture index, b = slice start code, c = picture_coding_type | full_pel << 4 | r_size << 8 |
+ *                 (slice decoded ? 1 << 16 : 0), e = loaded quantiser matrices in force
+ *   EFXO_T_MB     a = macroblock address, b = intra | skipped << 1 | quantiser_scale << 2, c / e = half-pel luma vector
+ *   EFXO_T_COEF   a = block, b = scan position, c = signed level before dequantisation (intra DC: the DC value)
+ *   EFXO_T_BLOCK  a = block, b = 0 decoded / -1 abandoned (ran past 64) / -2 invalid code, c = entries so far */
+enum { EFXO_T_SLICE = 0, EFXO_T_MB = 1, EFXO_T_COEF = 2, EFXO_T_BLOCK = 3 };
+typedef void (*efxo_trace_fn)(void* user, int kind, int a, int b, int c, int e);
+void efxo_set_trace(efxo_trace_fn fn, void* user);
+
 /* TS -> video ES (PID 0x100 payloads, PES headers stripped; player.cpp:381-493).  Writes at
  * most es_cap bytes, returns the ES length.  pic_pts_out/max_pics (optional) receive the PES
  * pts latched by flush_picture for each picture start code in order of appearance. */
