@@ -9,13 +9,13 @@ CSRC     = espflix_amd/csrc
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 OBJS     = $(CSRC)/efx_api.o $(CSRC)/k_demux.o $(CSRC)/k_index.o $(CSRC)/k_parse.o $(CSRC)/k_recon.o $(CSRC)/k_video.o $(CSRC)/k_sbc.o $(CSRC)/k_tsindex.o $(CSRC)/efx_tables.o
 
-.PHONY: all lib gen oracle ref clean harness
+.PHONY: all lib gen oracle ref clean
 all: lib gen oracle
 
 lib: espflix_amd/libefx.so
 gen: espflix_amd/gen/libefx_gen.so
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/efx_internal.h $(CSRC)/parse_core.h include/efx.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/efx_internal.h include/efx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/efx_tables.o: $(CSRC)/efx_tables.cpp $(CSRC)/efx_internal.h $(CSRC)/mpeg1_codebook.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
@@ -25,13 +25,6 @@ espflix_amd/libefx.so: $(OBJS)
 
 espflix_amd/gen/libefx_gen.so: espflix_amd/gen/efx_gen.cpp $(CSRC)/mpeg1_codebook.h
 	g++ -std=c++17 -O2 -Wall -Wextra -fPIC -shared -pthread $< -o $@
-
-# TEST TOOL: the slice parser of k_parse (parse_core.h) compiled for the host, checked against the oracle's parse trace
-harness: tests/_build/parse_harness
-tests/_build/parse_harness: tests/parse_harness.cpp $(CSRC)/parse_core.h $(CSRC)/efx_internal.h $(CSRC)/efx_tables.cpp oracle/efx_oracle.c oracle/efx_oracle.h
-	mkdir -p tests/_build
-	gcc -std=c99 -O2 -c oracle/efx_oracle.c -o tests/_build/efx_oracle.o
-	g++ -std=c++17 -O2 -Wall -Iinclude -I$(CSRC) -Ioracle tests/parse_harness.cpp $(CSRC)/efx_tables.cpp tests/_build/efx_oracle.o -o $@ -lm
 
 oracle:
 	$(MAKE) -C oracle port
