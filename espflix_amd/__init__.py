@@ -89,6 +89,8 @@ _SYMBOLS = {
     "efx_reset": (C.c_int, [_P]),
     "efx_erase_frames": (C.c_int, [_P]),
     "efx_decode": (C.c_int, [_P]),
+    "efx_decode_from": (C.c_int, [_P, C.c_int]),
+    "efx_stream_picture_slot": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "efx_sync": (C.c_int, [_P]),
     "efx_picture_count": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
     "efx_stream_status": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32)]),
@@ -268,8 +270,9 @@ class Decoder:
         _check(self._ctx, self._lib.efx_erase_frames(self._ctx))
 
     # -- decode ---------------------------------------------------------------------------
-    def decode(self, sync: bool = True):
-        _check(self._ctx, self._lib.efx_decode(self._ctx))
+    def decode(self, sync: bool = True, first_picture: int = 0):
+        """efx_decode (first_picture = 0) / efx_decode_from: the decoder keeps going from call to call."""
+        _check(self._ctx, self._lib.efx_decode_from(self._ctx, first_picture))
         if sync:
             self.sync()
 
@@ -299,8 +302,11 @@ class Decoder:
         _check(self._ctx, self._lib.efx_picture_pts(self._ctx, stream, picture, C.byref(p)))
         return p.value
 
-    def picture_slot(self, picture: int) -> int:
-        return self._lib.efx_picture_slot(self._ctx, picture)
+    def picture_slot(self, picture: int, stream: int = 0) -> int:
+        """Ring slot of a picture of the last decode (synchronises)."""
+        slot = C.c_int()
+        _check(self._ctx, self._lib.efx_stream_picture_slot(self._ctx, stream, picture, C.byref(slot)))
+        return slot.value
 
     # -- frames out -----------------------------------------------------------------------
     def frame_ptr(self, stream: int, slot: int) -> int:

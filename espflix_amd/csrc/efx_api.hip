@@ -24,13 +24,14 @@ __global__ void k_demux_audio(const uint8_t*, const uint64_t*, const uint32_t*, 
 __global__ void k_ts_sequences(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, PesEntry*, IdxInfo*);
 __global__ void k_idx_bins(const PesEntry*, const uint32_t*, const IdxInfo*, uint32_t, uint32_t*, size_t);
 __global__ void k_index(const uint8_t*, const uint64_t*, int, PicInfo*, SliceTmp*, uint32_t*, uint32_t*, uint32_t*,
-                        const uint32_t*, const PesEntry*, const uint32_t*, const uint32_t*, int64_t*);
+                        const uint32_t*, const PesEntry*, const uint32_t*, const uint32_t*, int64_t*, int);
+__global__ void k_advance(StreamState*, const uint32_t*, int64_t*, const PesEntry*, const uint32_t*, const uint32_t*, int, int, int32_t*);
 __global__ void k_slice_scan(const PicInfo*, const uint32_t*, int, int, const uint32_t*, uint32_t*, DecodeCounters*);
 __global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, const uint64_t*, const uint32_t*, int, int,
                              const uint32_t*, SliceDesc*);
 __global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const ParseTables*, MbRec*, uint32_t*, uint32_t*,
                         int, int);
-__global__ void k_recon(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, int, int, int);
+__global__ void k_recon(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, const int32_t*, int);
 __global__ void k_frame_hash(const uint8_t*, int, uint64_t*);
 __global__ void k_fill(uint32_t*, uint32_t, size_t);
 __global__ void k_composite(const uint8_t*, const VideoTables*, const VideoLineTemplates*, FieldArgs, uint16_t*);
@@ -43,6 +44,7 @@ using namespace efx;
 constexpr int kParseStreams = 2;  // parse halves in flight at once (latency-bound kernels: two overlap well)
 constexpr int kTimingRing = 64;   // efx_decode calls whose stage times efx_get_timing can average
 constexpr int kSlots = 3;         // parse -> recon hand-over buffer sets (one being reconstructed + two being parsed)
+constexpr int kUploads = 2;       // bitstream buffers: one being decoded, one being filled
 
 struct efx_ctx {
     efx_config cfg{};
@@ -50,37 +52,50 @@ struct efx_ctx {
     bool own_stream = false;
     std::string err;
 
-    // capacities
-    size_t es_cap = 0;  // bytes of ES buffer (including tails and guard)
-    int n_streams = 0;  // streams in the current upload
-    size_t es_used = 0;
-    bool uploaded = false, decoded = false, results_valid = false;
+    size_t es_cap = 0;  // bytes of one ES buffer (including tails and guard)
+    bool decoded = false, results_valid = false;
 
-    // device buffers
-    uint8_t* d_es = nullptr;
-    uint64_t* d_stream_off = nullptr;
-    uint32_t* d_stream_perm = nullptr;  // streams by descending length: the order of slices inside a picture index
     ParseTables* d_tables = nullptr;
     uint8_t* d_frames = nullptr;
-    // transport-stream input (allocated on the first EFX_FORMAT_TS upload)
+    StreamState* d_state = nullptr;  // per stream: ring position, "a PTS has been seen", newest PES PTS (k_advance)
+
+    // One resident batch of bitstreams.  efx_upload_streams fills the buffer the last decode does NOT read
+    // (staging copy on the host, H2D and k_demux on the copy stream) while the GPU still decodes the other
+    // one: ingest and decode of consecutive batches overlap.
+    struct Upload {
+        uint8_t* d_es = nullptr;
+        uint64_t* d_stream_off = nullptr;
+        uint32_t* d_stream_perm = nullptr;  // streams by descending length: the order of slices inside a picture index
+        // transport-stream input (allocated on the first EFX_FORMAT_TS upload)
+        uint32_t* d_ts_len = nullptr;    // per stream: TS bytes
+        uint32_t* d_pkt_base = nullptr;  // per stream: first entry of its PES list (= packets before it)
+        uint32_t* d_es_len = nullptr;    // per stream: demuxed ES bytes (without tail)
+        uint32_t* d_pes_count = nullptr;
+        PesEntry* d_pes = nullptr;
+        uint8_t* h_es = nullptr;         // pinned staging: the bitstreams, then the small per-stream arrays
+        uint8_t* h_meta = nullptr;       // pinned: stream_off (n + 1 x u64) | perm | ts_len | pkt_base (n x u32 each)
+        std::vector<uint64_t> stream_off;
+        std::vector<uint32_t> es_len;    // per stream, ES input only
+        int n_streams = 0;
+        size_t es_used = 0, ts_bytes = 0;
+        bool ts_input = false, valid = false;
+        hipEvent_t uploaded = nullptr;                                  // H2D (+ k_demux) done, copy stream
+        hipEvent_t last_read[kParseStreams] = {nullptr, nullptr};       // newest parse half that reads this buffer
+        hipEvent_t ev_demux[2] = {nullptr, nullptr};
+        bool demux_timed = false;
+    } up[kUploads];
+    int cur_up = -1;  // batch the next efx_decode reads
+    hipStream_t copy_stream = nullptr;
+    // transient TS staging on the device + the lists of efx_index_streams / efx_demux_audio
     uint8_t* d_ts = nullptr;
-    uint32_t* d_ts_len = nullptr;    // per stream: TS bytes
-    uint32_t* d_pkt_base = nullptr;  // per stream: first entry of its PES list (= packets before it)
-    uint32_t* d_es_len = nullptr;    // per stream: demuxed ES bytes (without tail)
-    uint32_t* d_pes_count = nullptr;
-    PesEntry* d_pes = nullptr;
     size_t pes_cap = 0;
-    // efx_index_streams keeps its own lists: the ones above belong to the uploaded batch (k_index
-    // reads them at every efx_decode); only the transient TS staging buffer d_ts is shared
     IdxInfo* d_idx_info = nullptr;
     uint64_t* d_ts_off = nullptr;
     uint32_t* d_idx_len = nullptr;
     uint32_t* d_idx_base = nullptr;
     PesEntry* d_idx_seq = nullptr;
-    bool ts_input = false;
-    hipEvent_t ev_demux[2] = {nullptr, nullptr};
-    float demux_ms = 0.f;
-    size_t ts_bytes = 0;
+    bool ts_ready = false;  // every transport-stream buffer and event exists
+
     // kSlots sets of parse -> recon hand-over buffers: efx_decode() number n parses into slot
     // n % kSlots on parse stream n % kParseStreams while the recon stream is still reconstructing
     // earlier calls from the other slots.  The parse half is bound by the latency of its longest
@@ -99,9 +114,11 @@ struct efx_ctx {
         uint32_t* d_qtab = nullptr;  // per (stream, picture) custom quantiser tables, read by k_recon
         uint32_t* d_slice_base = nullptr;
         SliceDesc* d_descs = nullptr;
-        int64_t* d_pts = nullptr;  // per (stream, picture): PTS latched at the picture header (TS input)
+        int64_t* d_pts = nullptr;    // per (stream, picture): PTS latched at the picture header (TS input)
+        int32_t* d_call_pos = nullptr;  // per stream: ring position of this call's first picture, first picture with a PTS
         hipEvent_t parse_done = nullptr, recon_done = nullptr;
         int epoch = 0;
+        int upload = 0;  // batch this call decoded
     } slot[kSlots];
     // stage timing: one event set per efx_decode call since efx_set_timing(1), so that a run of
     // back-to-back (overlapping) calls can be averaged afterwards without a host sync in between
@@ -118,12 +135,11 @@ struct efx_ctx {
     SbcTables* d_sbc_tables = nullptr;
     uint64_t* d_hash = nullptr;
 
-    // host staging / results
-    uint8_t* h_es = nullptr;  // pinned
-    std::vector<uint64_t> h_stream_off;
+    // results of the last decode (fetch_results)
+    int n_streams = 0;  // streams of the batch the last decode read
     std::vector<int64_t> h_pts;  // per (stream, picture), TS input only
-    std::vector<uint32_t> h_es_len;  // per stream, ES input only
     std::vector<uint32_t> h_pic_count, h_status;
+    std::vector<int32_t> h_call_pos;
     DecodeCounters h_counters{};
 
     bool timing = false;
@@ -155,6 +171,17 @@ hipError_t dalloc(T** p, size_t n)
 {
     return hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
 }
+
+int sync_all(efx_ctx* ctx)
+{
+    EFX_HIP(hipStreamSynchronize(ctx->copy_stream));
+    for (auto ps : ctx->parse_streams)
+        EFX_HIP(hipStreamSynchronize(ps));
+    EFX_HIP(hipStreamSynchronize(ctx->stream));
+    return EFX_OK;
+}
+
+size_t meta_bytes(size_t n) { return (n + 1) * sizeof(uint64_t) + 3 * n * sizeof(uint32_t); }
 
 }  // namespace
 
@@ -212,10 +239,21 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         if (e == hipSuccess)
             e = r;
     };
-    A(dalloc(&ctx->d_es, ctx->es_cap));
-    A(dalloc(&ctx->d_stream_off, n + 1));
-    A(dalloc(&ctx->d_stream_perm, n));
     A(dalloc(&ctx->d_tables, 1));
+    A(dalloc(&ctx->d_state, n));
+    A(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (auto& u : ctx->up) {
+        A(dalloc(&u.d_es, ctx->es_cap));
+        A(dalloc(&u.d_stream_off, n + 1));
+        A(dalloc(&u.d_stream_perm, n));
+        A(hipHostMalloc(reinterpret_cast<void**>(&u.h_es), ctx->es_cap, hipHostMallocDefault));
+        A(hipHostMalloc(reinterpret_cast<void**>(&u.h_meta), meta_bytes(n), hipHostMallocDefault));
+        A(hipEventCreateWithFlags(&u.uploaded, hipEventDisableTiming));
+        for (auto& ev : u.last_read)
+            A(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        if (e == hipSuccess)
+            A(hipMemset(u.d_es, 0, ctx->es_cap));
+    }
     for (auto& sl : ctx->slot) {
         A(dalloc(&sl.d_pic_count, n));
         A(dalloc(&sl.d_status, n));
@@ -227,6 +265,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         A(dalloc(&sl.d_qtab, n * P * 64));
         A(dalloc(&sl.d_slice_base, n * P + 1));
         A(dalloc(&sl.d_descs, n * P * kMaxSlicesPerPicture));
+        A(dalloc(&sl.d_call_pos, 2 * n));
     }
     {
         // the parse kernel is a few thousand long-running waves: give it the higher priority so its
@@ -243,7 +282,6 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     A(dalloc(&ctx->d_video_lines[1], 1));
     A(dalloc(&ctx->d_hash, n * D));
     A(dalloc(&ctx->d_sbc_tables, 1));
-    A(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_es), ctx->es_cap, hipHostMallocDefault));
     if (e != hipSuccess) {
         fprintf(stderr, "efx_create: %s\n", hipGetErrorString(e));
         return bail(EFX_ERR_DEVICE);
@@ -267,7 +305,6 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         A(hipMemcpy(ctx->d_sbc_tables, &st, sizeof(st), hipMemcpyHostToDevice));
     }
     A(hipMemset(ctx->d_frames, 0, n * D * kFrameBytes));
-    A(hipMemset(ctx->d_es, 0, ctx->es_cap));
     for (auto& sl : ctx->slot) {
         A(hipMemset(sl.d_mbrecs, 0, n * P * kMbCount * sizeof(MbRec)));
         A(hipEventCreateWithFlags(&sl.parse_done, hipEventDisableTiming));
@@ -276,6 +313,10 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     if (e != hipSuccess)
         return bail(EFX_ERR_DEVICE);
     *out = ctx;
+    if (efx_reset(ctx) != EFX_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        *out = nullptr;
+        return bail(EFX_ERR_DEVICE);
+    }
     return EFX_OK;
 }
 
@@ -283,17 +324,16 @@ void efx_destroy(efx_ctx* ctx)
 {
     if (!ctx)
         return;
+    if (ctx->copy_stream)
+        (void)hipStreamSynchronize(ctx->copy_stream);
     for (auto ps : ctx->parse_streams)
         if (ps)
             (void)hipStreamSynchronize(ps);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
-    void* bufs[] = {ctx->d_es,   ctx->d_stream_off, ctx->d_stream_perm, ctx->d_tables,
-                    ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0], ctx->d_video_lines[1], ctx->d_hash,
-                    ctx->d_ts, ctx->d_ts_len, ctx->d_pkt_base, ctx->d_es_len, ctx->d_pes_count, ctx->d_pes, ctx->d_sbc_tables, ctx->d_idx_info, ctx->d_ts_off, ctx->d_idx_len, ctx->d_idx_base, ctx->d_idx_seq};
-    for (auto& ev : ctx->ev_demux)
-        if (ev)
-            (void)hipEventDestroy(ev);
+    void* bufs[] = {ctx->d_tables, ctx->d_state, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0],
+                    ctx->d_video_lines[1], ctx->d_hash, ctx->d_ts, ctx->d_sbc_tables, ctx->d_idx_info, ctx->d_ts_off, ctx->d_idx_len,
+                    ctx->d_idx_base, ctx->d_idx_seq};
     for (auto& te : ctx->timing_ring)
         for (auto& ev : te.ev)
             if (ev)
@@ -301,8 +341,22 @@ void efx_destroy(efx_ctx* ctx)
     for (void* b : bufs)
         if (b)
             (void)hipFree(b);
+    for (auto& u : ctx->up) {
+        void* ub[] = {u.d_es, u.d_stream_off, u.d_stream_perm, u.d_ts_len, u.d_pkt_base, u.d_es_len, u.d_pes_count, u.d_pes};
+        for (void* b : ub)
+            if (b)
+                (void)hipFree(b);
+        if (u.h_es)
+            (void)hipHostFree(u.h_es);
+        if (u.h_meta)
+            (void)hipHostFree(u.h_meta);
+        hipEvent_t evs[] = {u.uploaded, u.last_read[0], u.last_read[1], u.ev_demux[0], u.ev_demux[1]};
+        for (auto ev : evs)
+            if (ev)
+                (void)hipEventDestroy(ev);
+    }
     for (auto& sl : ctx->slot) {
-        void* sb[] = {sl.d_pic_count, sl.d_status, sl.d_counters, sl.d_mbrecs, sl.d_coefs, sl.d_pts,
+        void* sb[] = {sl.d_pic_count, sl.d_status, sl.d_counters, sl.d_mbrecs, sl.d_coefs, sl.d_pts, sl.d_call_pos,
                       sl.d_pics,      sl.d_slices_tmp, sl.d_qtab, sl.d_slice_base, sl.d_descs};
         for (void* b : sb)
             if (b)
@@ -312,32 +366,38 @@ void efx_destroy(efx_ctx* ctx)
         if (sl.recon_done)
             (void)hipEventDestroy(sl.recon_done);
     }
-    if (ctx->h_es)
-        (void)hipHostFree(ctx->h_es);
     for (auto ps : ctx->parse_streams)
         if (ps)
             (void)hipStreamDestroy(ps);
+    if (ctx->copy_stream)
+        (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream && ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 
-// transport-stream staging (first EFX_FORMAT_TS upload or first index call): the TS of stream i
+// transport-stream buffers (first EFX_FORMAT_TS upload or first index call): the TS of stream i
 // occupies the same region of d_ts that its elementary stream will occupy in d_es (an ES is never
 // longer than its TS)
 static int ensure_ts_buffers(efx_ctx* ctx)
 {
-    if (ctx->d_ts)
+    if (ctx->ts_ready)
         return EFX_OK;
+    if (ctx->d_ts)
+        return fail(ctx, EFX_ERR_DEVICE, "transport-stream buffers: an earlier allocation failed");
     const size_t n_max = (size_t)ctx->cfg.max_streams;
     ctx->pes_cap = ctx->es_cap / 188 + n_max;
     hipError_t e = dalloc(&ctx->d_ts, ctx->es_cap);
-    if (e == hipSuccess) e = dalloc(&ctx->d_ts_len, n_max);
-    if (e == hipSuccess) e = dalloc(&ctx->d_pkt_base, n_max);
-    if (e == hipSuccess) e = dalloc(&ctx->d_es_len, n_max);
-    if (e == hipSuccess) e = dalloc(&ctx->d_pes_count, n_max);
-    if (e == hipSuccess) e = dalloc(&ctx->d_pes, ctx->pes_cap);
+    for (auto& u : ctx->up) {
+        if (e == hipSuccess) e = dalloc(&u.d_ts_len, n_max);
+        if (e == hipSuccess) e = dalloc(&u.d_pkt_base, n_max);
+        if (e == hipSuccess) e = dalloc(&u.d_es_len, n_max);
+        if (e == hipSuccess) e = dalloc(&u.d_pes_count, n_max);
+        if (e == hipSuccess) e = dalloc(&u.d_pes, ctx->pes_cap);
+        for (auto& ev : u.ev_demux)
+            if (e == hipSuccess) e = hipEventCreate(&ev);
+    }
     if (e == hipSuccess) e = dalloc(&ctx->d_idx_info, n_max);
     if (e == hipSuccess) e = dalloc(&ctx->d_ts_off, n_max + 1);
     if (e == hipSuccess) e = dalloc(&ctx->d_idx_len, n_max);
@@ -345,10 +405,9 @@ static int ensure_ts_buffers(efx_ctx* ctx)
     if (e == hipSuccess) e = dalloc(&ctx->d_idx_seq, ctx->pes_cap);
     for (auto& sl : ctx->slot)
         if (e == hipSuccess) e = dalloc(&sl.d_pts, n_max * (size_t)ctx->cfg.max_pictures);
-    for (auto& ev : ctx->ev_demux)
-        if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e != hipSuccess)
         return fail(ctx, EFX_ERR_DEVICE, "transport-stream buffers", e);
+    ctx->ts_ready = true;
     return EFX_OK;
 }
 
@@ -358,9 +417,6 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
         return fail(ctx, EFX_ERR_ARG, "efx_upload_streams: bad argument");
     if (n_streams > ctx->cfg.max_streams)
         return fail(ctx, EFX_ERR_CAPACITY, "efx_upload_streams: more streams than max_streams");
-    for (auto ps : ctx->parse_streams)
-        EFX_HIP(hipStreamSynchronize(ps));  // the bitstream buffer may still be in use
-    EFX_HIP(hipStreamSynchronize(ctx->stream));
     const bool is_ts = format == EFX_FORMAT_TS;
     if (is_ts) {
         int r = ensure_ts_buffers(ctx);
@@ -368,41 +424,59 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
             return r;
     }
     static const uint8_t tail[kEsTailBytes] = {0, 0, 0, 1, 0xB7, 0, 0, 1, 0xB7};
-    ctx->h_stream_off.assign((size_t)n_streams + 1, 0);
-    ctx->h_es_len.assign((size_t)n_streams, 0);
-    std::vector<uint32_t> ts_len, pkt_base;
-    if (is_ts) {
-        ts_len.resize(n_streams);
-        pkt_base.resize(n_streams);
-    }
+    // offsets and lengths are built in locals and moved into the batch only when the call can no longer be
+    // rejected: a refused upload leaves the resident batch (and what efx_download_es reads) untouched
+    std::vector<uint64_t> stream_off((size_t)n_streams + 1, 0);
+    std::vector<uint32_t> es_len((size_t)n_streams, 0);
     size_t pos = 0, packets = 0;
     for (int i = 0; i < n_streams; i++) {
-        const uint8_t* src = data[i];
         const size_t n = len[i];
-        if (!src && n)
+        if (!data[i] && n)
             return fail(ctx, EFX_ERR_ARG, "efx_upload_streams: null stream");
         const size_t padded = (n + kEsTailBytes + 15) & ~(size_t)15;
         if (pos + padded + kEsGuardBytes > ctx->es_cap)
             return fail(ctx, EFX_ERR_CAPACITY, "efx_upload_streams: more bytes than max_stream_bytes");
-        ctx->h_stream_off[i] = pos;
-        ctx->h_es_len[i] = (uint32_t)n;
-        if (is_ts) {
-            ts_len[i] = (uint32_t)n;
-            pkt_base[i] = (uint32_t)packets;
-            packets += n / 188;
-        }
+        stream_off[i] = pos;
+        es_len[i] = (uint32_t)n;
+        packets += n / 188;
         pos += padded;
     }
-    ctx->h_stream_off[n_streams] = pos;
+    stream_off[n_streams] = pos;
+    if (is_ts && packets > ctx->pes_cap)
+        return fail(ctx, EFX_ERR_CAPACITY, "efx_upload_streams: PES list capacity");
+
+    // the buffer the last decode does not read; its previous content may still be in use by an older parse
+    // half (two calls back) and its staging memory by its own H2D transfer
+    const int ui = (ctx->cur_up + 1) % kUploads;
+    efx_ctx::Upload& u = ctx->up[ui];
+    if (u.valid) {
+        EFX_HIP(hipEventSynchronize(u.uploaded));
+        for (auto ev : u.last_read)
+            EFX_HIP(hipEventSynchronize(ev));
+    }
+    u.valid = false;
+    hipStream_t st = ctx->copy_stream;
+    uint8_t* d_dst = is_ts ? ctx->d_ts : u.d_es;
+    // small per-stream arrays, pinned: stream_off | perm | ts_len | pkt_base
+    uint64_t* m_off = reinterpret_cast<uint64_t*>(u.h_meta);
+    uint32_t* m_perm = reinterpret_cast<uint32_t*>(m_off + n_streams + 1);
+    uint32_t *m_ts_len = m_perm + n_streams, *m_pkt_base = m_ts_len + n_streams;
+    memcpy(m_off, stream_off.data(), ((size_t)n_streams + 1) * sizeof(uint64_t));
+    {
+        size_t pk = 0;
+        for (int i = 0; i < n_streams; i++) {
+            m_ts_len[i] = (uint32_t)len[i];
+            m_pkt_base[i] = (uint32_t)pk;
+            pk += len[i] / 188;
+        }
+    }
     // Stage into the pinned buffer and ship it: the streams are cut into groups, one host thread
     // copies each group, and a group's H2D transfer is queued as soon as its copy is done, so the
     // transfer of the first groups runs under the copies of the last.
-    hipStream_t st = ctx->stream;
-    uint8_t* d_dst = is_ts ? ctx->d_ts : ctx->d_es;
     auto stage = [&](int i0, int i1) {
         for (int i = i0; i < i1; i++) {
-            uint8_t* at = ctx->h_es + ctx->h_stream_off[i];
-            const size_t n = len[i], padded = (size_t)(ctx->h_stream_off[i + 1] - ctx->h_stream_off[i]);
+            uint8_t* at = u.h_es + stream_off[i];
+            const size_t n = len[i], padded = (size_t)(stream_off[i + 1] - stream_off[i]);
             if (n)
                 memcpy(at, data[i], n);
             if (is_ts)  // raw packets; k_demux writes the ES, the end-of-data tail and the zero fill
@@ -435,72 +509,70 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
                 workers[g - 1].join();
             else
                 stage(first[g], first[g + 1]);
-            const size_t a = ctx->h_stream_off[first[g]], b = ctx->h_stream_off[first[g + 1]];
+            const size_t a = stream_off[first[g]], b = stream_off[first[g + 1]];
             if (e == hipSuccess && b > a)
-                e = hipMemcpyAsync(d_dst + a, ctx->h_es + a, b - a, hipMemcpyHostToDevice, st);
+                e = hipMemcpyAsync(d_dst + a, u.h_es + a, b - a, hipMemcpyHostToDevice, st);
         }
         if (e != hipSuccess)
             return fail(ctx, EFX_ERR_DEVICE, "efx_upload_streams: H2D", e);
     }
     // slices of one picture index are dealt to the parse waves stream by stream: longest streams
     // first, so that a wave's 64 slices have similar bit rates (and the long waves start early)
-    std::vector<uint32_t> perm((size_t)n_streams);
     for (int i = 0; i < n_streams; i++)
-        perm[i] = (uint32_t)i;
-    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return len[a] > len[b]; });
-    ctx->es_used = pos;
-    ctx->n_streams = n_streams;
-    ctx->ts_input = is_ts;
-    ctx->demux_ms = 0.f;
-    ctx->ts_bytes = 0;
-    EFX_HIP(hipMemcpyAsync(ctx->d_stream_off, ctx->h_stream_off.data(), ((size_t)n_streams + 1) * sizeof(uint64_t),
-                           hipMemcpyHostToDevice, st));
-    EFX_HIP(hipMemcpyAsync(ctx->d_stream_perm, perm.data(), (size_t)n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        m_perm[i] = (uint32_t)i;
+    std::stable_sort(m_perm, m_perm + n_streams, [&](uint32_t a, uint32_t b) { return len[a] > len[b]; });
+    EFX_HIP(hipMemcpyAsync(u.d_stream_off, m_off, ((size_t)n_streams + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    EFX_HIP(hipMemcpyAsync(u.d_stream_perm, m_perm, (size_t)n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    u.ts_bytes = 0;
+    u.demux_timed = false;
     if (is_ts) {
-        if (packets > ctx->pes_cap)
-            return fail(ctx, EFX_ERR_CAPACITY, "efx_upload_streams: PES list capacity");
         EFX_HIP(hipMemsetAsync(ctx->d_ts + pos, 0, kEsGuardBytes, st));
-        EFX_HIP(hipMemcpyAsync(ctx->d_ts_len, ts_len.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        EFX_HIP(hipMemcpyAsync(ctx->d_pkt_base, pkt_base.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        EFX_HIP(hipMemsetAsync(ctx->d_es + pos, 0, kEsGuardBytes, st));
+        EFX_HIP(hipMemcpyAsync(u.d_ts_len, m_ts_len, n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        EFX_HIP(hipMemcpyAsync(u.d_pkt_base, m_pkt_base, n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        EFX_HIP(hipMemsetAsync(u.d_es + pos, 0, kEsGuardBytes, st));
         // MpegDecoder::more()/demux() for the whole batch (player.cpp:381-493)
         if (ctx->timing)
-            EFX_HIP(hipEventRecord(ctx->ev_demux[0], st));
-        hipLaunchKernelGGL(k_demux, dim3(n_streams), dim3(256), 0, st, ctx->d_ts, ctx->d_stream_off, ctx->d_ts_len,
-                           ctx->d_pkt_base, ctx->d_es, ctx->d_es_len, ctx->d_pes, ctx->d_pes_count);
-        if (ctx->timing)
-            EFX_HIP(hipEventRecord(ctx->ev_demux[1], st));
+            EFX_HIP(hipEventRecord(u.ev_demux[0], st));
+        hipLaunchKernelGGL(k_demux, dim3(n_streams), dim3(256), 0, st, ctx->d_ts, u.d_stream_off, u.d_ts_len, u.d_pkt_base, u.d_es,
+                           u.d_es_len, u.d_pes, u.d_pes_count);
+        if (ctx->timing) {
+            EFX_HIP(hipEventRecord(u.ev_demux[1], st));
+            u.demux_timed = true;
+        }
         EFX_HIP(hipGetLastError());
         for (int i = 0; i < n_streams; i++)
-            ctx->ts_bytes += ts_len[i];
+            u.ts_bytes += len[i];
     } else
-        EFX_HIP(hipMemsetAsync(ctx->d_es + pos, 0, kEsGuardBytes, st));
-    EFX_HIP(hipStreamSynchronize(st));
-    if (is_ts && ctx->timing)
-        EFX_HIP(hipEventElapsedTime(&ctx->demux_ms, ctx->ev_demux[0], ctx->ev_demux[1]));
-    ctx->uploaded = true;
-    ctx->decoded = false;
-    ctx->results_valid = false;
+        EFX_HIP(hipMemsetAsync(u.d_es + pos, 0, kEsGuardBytes, st));
+    EFX_HIP(hipEventRecord(u.uploaded, st));
+    // the batch is resident (as far as every later call on this context is concerned: they wait for the event)
+    u.stream_off.swap(stream_off);
+    u.es_len.swap(es_len);
+    u.n_streams = n_streams;
+    u.es_used = pos;
+    u.ts_input = is_ts;
+    u.valid = true;
+    ctx->cur_up = ui;
     return EFX_OK;
 }
 
 int efx_download_es(efx_ctx* ctx, int stream, uint8_t* dst, size_t cap, size_t* es_len)
 {
-    if (!ctx || !es_len || stream < 0 || stream >= ctx->n_streams || (!dst && cap))
-        return EFX_ERR_ARG;
-    if (!ctx->uploaded)
-        return fail(ctx, EFX_ERR_STATE, "efx_download_es: no streams uploaded");
+    if (!ctx || !es_len || ctx->cur_up < 0 || stream < 0 || stream >= ctx->up[ctx->cur_up].n_streams || (!dst && cap))
+        return ctx && ctx->cur_up < 0 ? fail(ctx, EFX_ERR_STATE, "efx_download_es: no streams uploaded") : EFX_ERR_ARG;
+    efx_ctx::Upload& u = ctx->up[ctx->cur_up];
+    EFX_HIP(hipEventSynchronize(u.uploaded));
     size_t n;
-    if (ctx->ts_input) {
+    if (u.ts_input) {
         uint32_t v = 0;
-        EFX_HIP(hipMemcpy(&v, ctx->d_es_len + stream, sizeof(v), hipMemcpyDeviceToHost));
+        EFX_HIP(hipMemcpy(&v, u.d_es_len + stream, sizeof(v), hipMemcpyDeviceToHost));
         n = v;
     } else
-        n = ctx->h_es_len[stream];
+        n = u.es_len[stream];
     *es_len = n;
     size_t c = n < cap ? n : cap;
     if (c)
-        EFX_HIP(hipMemcpy(dst, ctx->d_es + ctx->h_stream_off[stream], c, hipMemcpyDeviceToHost));
+        EFX_HIP(hipMemcpy(dst, u.d_es + u.stream_off[stream], c, hipMemcpyDeviceToHost));
     return EFX_OK;
 }
 
@@ -508,8 +580,17 @@ int efx_reset(efx_ctx* ctx)
 {
     if (!ctx)
         return EFX_ERR_ARG;
-    size_t bytes = (size_t)ctx->cfg.max_streams * ctx->cfg.ring_depth * kFrameBytes;
-    EFX_HIP(hipMemsetAsync(ctx->d_frames, 0, bytes, ctx->stream));
+    const size_t n = (size_t)ctx->cfg.max_streams;
+    EFX_HIP(hipMemsetAsync(ctx->d_frames, 0, n * ctx->cfg.ring_depth * kFrameBytes, ctx->stream));
+    // the constructor's state (player.cpp:354-361): frame index 1 (_reference = _fb[0], _current = _fb[1]), no PTS seen
+    std::vector<StreamState> init(n);
+    for (auto& st : init) {
+        st.fb_index = 1;
+        st.pts_seen = 0;
+        st.pts_carry = -1;
+    }
+    EFX_HIP(hipMemcpyAsync(ctx->d_state, init.data(), n * sizeof(StreamState), hipMemcpyHostToDevice, ctx->stream));
+    EFX_HIP(hipStreamSynchronize(ctx->stream));  // (pageable source)
     return EFX_OK;
 }
 
@@ -522,18 +603,22 @@ int efx_erase_frames(efx_ctx* ctx)
     return EFX_OK;
 }
 
-int efx_decode(efx_ctx* ctx)
+int efx_decode_from(efx_ctx* ctx, int first_picture)
 {
-    if (!ctx)
+    if (!ctx || first_picture < 0)
         return EFX_ERR_ARG;
-    if (!ctx->uploaded)
+    if (ctx->cur_up < 0)
         return fail(ctx, EFX_ERR_STATE, "efx_decode: no streams uploaded");
-    const int n = ctx->n_streams, P = ctx->cfg.max_pictures, D = ctx->cfg.ring_depth;
-    hipStream_t sp = ctx->parse_streams[ctx->calls % kParseStreams], sr = ctx->stream;
+    efx_ctx::Upload& u = ctx->up[ctx->cur_up];
+    const int n = u.n_streams, P = ctx->cfg.max_pictures, D = ctx->cfg.ring_depth;
+    const int pi = (int)(ctx->calls % kParseStreams);
+    hipStream_t sp = ctx->parse_streams[pi], sr = ctx->stream;
     ctx->cur = (int)(ctx->calls++ % kSlots);
     efx_ctx::Slot& sl = ctx->slot[ctx->cur];
+    sl.upload = ctx->cur_up;
 
-    // ---- parse half (parse stream): index -> slice list -> VLC parse + dequantisation ---------------
+    // ---- parse half (parse stream): index -> slice list -> VLC parse ---------------------------------------
+    EFX_HIP(hipStreamWaitEvent(sp, u.uploaded, 0));     // the batch is in HBM (H2D and k_demux on the copy stream)
     EFX_HIP(hipStreamWaitEvent(sp, sl.recon_done, 0));  // the call kSlots back has released this slot
     // macroblock records carry the epoch that wrote them; recycle the tag space by clearing
     if (++sl.epoch > 255) {
@@ -545,29 +630,33 @@ int efx_decode(efx_ctx* ctx)
         te = &ctx->timing_ring[ctx->timed_calls++ % kTimingRing];
     if (te)
         EFX_HIP(hipEventRecord(te->ev[0], sp));
-    hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, sp, ctx->d_es, ctx->d_stream_off, P, sl.d_pics, sl.d_slices_tmp,
-                       sl.d_pic_count, sl.d_status, sl.d_qtab, ctx->d_tables->scan, ctx->d_pes, ctx->d_pkt_base,
-                       ctx->d_pes_count, ctx->ts_input ? sl.d_pts : nullptr);
-    hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, sl.d_pics, sl.d_pic_count, n, P, ctx->d_stream_perm, sl.d_slice_base,
+    hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, sp, u.d_es, u.d_stream_off, P, sl.d_pics, sl.d_slices_tmp, sl.d_pic_count,
+                       sl.d_status, sl.d_qtab, ctx->d_tables->scan, u.d_pes, u.d_pkt_base, u.d_pes_count,
+                       u.ts_input ? sl.d_pts : nullptr, first_picture);
+    hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, sl.d_pics, sl.d_pic_count, n, P, u.d_stream_perm, sl.d_slice_base,
                        sl.d_counters);
     hipLaunchKernelGGL(k_slice_emit, dim3((n * P * kMaxSlicesPerPicture + 255) / 256), dim3(256), 0, sp, sl.d_pics,
-                       sl.d_slices_tmp, sl.d_pic_count, ctx->d_stream_off, sl.d_slice_base, n, P, ctx->d_stream_perm, sl.d_descs);
+                       sl.d_slices_tmp, sl.d_pic_count, u.d_stream_off, sl.d_slice_base, n, P, u.d_stream_perm, sl.d_descs);
     if (te)
         EFX_HIP(hipEventRecord(te->ev[1], sp));
     const int max_slices = n * P * kMaxSlicesPerPicture;
-    hipLaunchKernelGGL(k_parse, dim3((max_slices + 255) / 256), dim3(256), 0, sp, ctx->d_es, sl.d_descs, sl.d_counters,
+    hipLaunchKernelGGL(k_parse, dim3((max_slices + 255) / 256), dim3(256), 0, sp, u.d_es, sl.d_descs, sl.d_counters,
                        ctx->d_tables, sl.d_mbrecs, sl.d_coefs, sl.d_status, P, sl.epoch);
     if (te)
         EFX_HIP(hipEventRecord(te->ev[2], sp));
     EFX_HIP(hipEventRecord(sl.parse_done, sp));
+    EFX_HIP(hipEventRecord(u.last_read[pi], sp));  // the bitstream buffer is free for the upload after next
 
     // ---- reconstruction half (context stream): one launch per picture index ------------------------------
     EFX_HIP(hipStreamWaitEvent(sr, sl.parse_done, 0));
     if (te)
         EFX_HIP(hipEventRecord(te->ev[4], sr));
+    // ring positions of this call's pictures; the reconstruction stream orders the calls
+    hipLaunchKernelGGL(k_advance, dim3((n + 255) / 256), dim3(256), 0, sr, ctx->d_state, sl.d_pic_count, u.ts_input ? sl.d_pts : nullptr,
+                       u.d_pes, u.d_pkt_base, u.d_pes_count, n, P, sl.d_call_pos);
     for (int p = 0; p < P; p++)
         hipLaunchKernelGGL(k_recon, dim3(n, (kMbCount * 6 + 63) / 64), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs, ctx->d_tables->scan,
-                           sl.d_qtab, ctx->d_frames, P, D, p, (p + 1) % D, p % D, sl.epoch);
+                           sl.d_qtab, ctx->d_frames, P, D, p, sl.d_call_pos, sl.epoch);
     if (te)
         EFX_HIP(hipEventRecord(te->ev[3], sr));
     EFX_HIP(hipEventRecord(sl.recon_done, sr));
@@ -577,14 +666,13 @@ int efx_decode(efx_ctx* ctx)
     return EFX_OK;
 }
 
+int efx_decode(efx_ctx* ctx) { return efx_decode_from(ctx, 0); }
+
 int efx_sync(efx_ctx* ctx)
 {
     if (!ctx)
         return EFX_ERR_ARG;
-    for (auto ps : ctx->parse_streams)
-        EFX_HIP(hipStreamSynchronize(ps));
-    EFX_HIP(hipStreamSynchronize(ctx->stream));
-    return EFX_OK;
+    return sync_all(ctx);
 }
 
 static int fetch_results(efx_ctx* ctx)
@@ -593,65 +681,91 @@ static int fetch_results(efx_ctx* ctx)
         return fail(ctx, EFX_ERR_STATE, "no decode has run");
     if (ctx->results_valid)
         return EFX_OK;
-    for (auto ps : ctx->parse_streams)
-        EFX_HIP(hipStreamSynchronize(ps));
-    EFX_HIP(hipStreamSynchronize(ctx->stream));
+    int r = sync_all(ctx);
+    if (r)
+        return r;
     const efx_ctx::Slot& sl = ctx->slot[ctx->cur];
+    const efx_ctx::Upload& u = ctx->up[sl.upload];
+    ctx->n_streams = u.n_streams;
     ctx->h_pic_count.resize(ctx->n_streams);
     ctx->h_status.resize(ctx->n_streams);
+    ctx->h_call_pos.resize(2 * (size_t)ctx->n_streams);
     EFX_HIP(hipMemcpy(ctx->h_pic_count.data(), sl.d_pic_count, ctx->n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost));
     EFX_HIP(hipMemcpy(ctx->h_status.data(), sl.d_status, ctx->n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    EFX_HIP(hipMemcpy(ctx->h_call_pos.data(), sl.d_call_pos, 2 * (size_t)ctx->n_streams * sizeof(int32_t), hipMemcpyDeviceToHost));
     EFX_HIP(hipMemcpy(&ctx->h_counters, sl.d_counters, sizeof(DecodeCounters), hipMemcpyDeviceToHost));
-    if (ctx->ts_input) {
+    if (u.ts_input) {
         ctx->h_pts.resize((size_t)ctx->n_streams * ctx->cfg.max_pictures);
         EFX_HIP(hipMemcpy(ctx->h_pts.data(), sl.d_pts, ctx->h_pts.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-    }
+    } else
+        ctx->h_pts.clear();
     ctx->results_valid = true;
     return EFX_OK;
 }
 
 int efx_picture_count(efx_ctx* ctx, int stream, int* n_pictures)
 {
-    if (!ctx || !n_pictures || stream < 0 || stream >= ctx->n_streams)
+    if (!ctx || !n_pictures || stream < 0)
         return EFX_ERR_ARG;
     int r = fetch_results(ctx);
     if (r)
         return r;
+    if (stream >= ctx->n_streams)
+        return EFX_ERR_ARG;
     *n_pictures = (int)ctx->h_pic_count[stream];
     return EFX_OK;
 }
 
 int efx_stream_status(efx_ctx* ctx, int stream, uint32_t* bits)
 {
-    if (!ctx || !bits || stream < 0 || stream >= ctx->n_streams)
+    if (!ctx || !bits || stream < 0)
         return EFX_ERR_ARG;
     int r = fetch_results(ctx);
     if (r)
         return r;
+    if (stream >= ctx->n_streams)
+        return EFX_ERR_ARG;
     *bits = ctx->h_status[stream];
     return EFX_OK;
 }
 
 int efx_picture_pts(efx_ctx* ctx, int stream, int picture, int64_t* pts)
 {
-    if (!ctx || !pts || stream < 0 || stream >= ctx->n_streams || picture < 0)
+    if (!ctx || !pts || stream < 0 || picture < 0)
         return EFX_ERR_ARG;
-    if (!ctx->ts_input) {
-        *pts = picture;  // elementary-stream input carries no PTS: pictures are numbered
-        return EFX_OK;
-    }
     int r = fetch_results(ctx);
     if (r)
         return r;
+    if (stream >= ctx->n_streams)
+        return EFX_ERR_ARG;
+    if (ctx->h_pts.empty()) {
+        *pts = picture;  // elementary-stream input carries no PTS: pictures are numbered
+        return EFX_OK;
+    }
     *pts = picture < (int)ctx->h_pic_count[stream] ? ctx->h_pts[(size_t)stream * ctx->cfg.max_pictures + picture] : -1;
     return EFX_OK;
 }
 
-int efx_picture_slot(const efx_ctx* ctx, int picture)
+int efx_stream_picture_slot(efx_ctx* ctx, int stream, int picture, int* slot)
 {
-    if (!ctx || picture < 0)
+    if (!ctx || !slot || stream < 0 || picture < 0)
         return EFX_ERR_ARG;
-    return (picture + 1) % ctx->cfg.ring_depth;
+    int r = fetch_results(ctx);
+    if (r)
+        return r;
+    if (stream >= ctx->n_streams)
+        return EFX_ERR_ARG;
+    const int pos0 = ctx->h_call_pos[2 * (size_t)stream], f = ctx->h_call_pos[2 * (size_t)stream + 1];
+    const uint32_t q = (uint32_t)pos0 + (uint32_t)(f < 0 ? picture + 1 : std::max(0, picture - f));
+    *slot = (int)(q % (uint32_t)ctx->cfg.ring_depth);
+    return EFX_OK;
+}
+
+int efx_picture_slot(efx_ctx* ctx, int picture)
+{
+    int slot = 0;
+    int r = efx_stream_picture_slot(ctx, 0, picture, &slot);
+    return r ? r : slot;
 }
 
 int efx_frame_device_ptr(efx_ctx* ctx, int stream, int slot, void** dptr)
@@ -786,10 +900,11 @@ int efx_demux_audio(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, const
     int r = ensure_ts_buffers(ctx);
     if (r)
         return r;
-    // the TS staging buffers are shared with efx_upload_streams, which only uses them during the call
-    for (auto ps : ctx->parse_streams)
-        EFX_HIP(hipStreamSynchronize(ps));
-    EFX_HIP(hipStreamSynchronize(ctx->stream));
+    // the TS staging buffers are shared with efx_upload_streams: nothing may be in flight
+    r = sync_all(ctx);
+    if (r)
+        return r;
+    uint8_t* const h_stage = ctx->up[0].h_es;
     std::vector<uint64_t> off((size_t)n_streams + 1), out_off((size_t)n_streams + 1);
     std::vector<uint32_t> tlen(n_streams);
     size_t pos = 0;
@@ -804,8 +919,8 @@ int efx_demux_audio(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, const
         off[i] = pos;
         out_off[i] = (uint64_t)i * stride;
         if (len[i])
-            memcpy(ctx->h_es + pos, ts[i], len[i]);
-        memset(ctx->h_es + pos + len[i], 0, padded - len[i]);
+            memcpy(h_stage + pos, ts[i], len[i]);
+        memset(h_stage + pos + len[i], 0, padded - len[i]);
         tlen[i] = (uint32_t)len[i];
         pos += padded;
     }
@@ -814,7 +929,7 @@ int efx_demux_audio(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, const
     hipStream_t st = ctx->stream;
     uint64_t* d_out_off = nullptr;
     EFX_HIP(dalloc(&d_out_off, (size_t)n_streams + 1));
-    hipError_t e = hipMemcpyAsync(ctx->d_ts, ctx->h_es, pos, hipMemcpyHostToDevice, st);
+    hipError_t e = hipMemcpyAsync(ctx->d_ts, h_stage, pos, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_ts_off, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_out_off, out_off.data(), out_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_idx_len, tlen.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st);
@@ -842,10 +957,11 @@ int efx_index_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, con
     int r = ensure_ts_buffers(ctx);
     if (r)
         return r;
-    // the TS staging buffers are shared with efx_upload_streams, which only uses them during the call
-    for (auto ps : ctx->parse_streams)
-        EFX_HIP(hipStreamSynchronize(ps));
-    EFX_HIP(hipStreamSynchronize(ctx->stream));
+    // the TS staging buffers are shared with efx_upload_streams: nothing may be in flight
+    r = sync_all(ctx);
+    if (r)
+        return r;
+    uint8_t* const h_stage = ctx->up[0].h_es;
     std::vector<uint64_t> off((size_t)n_streams + 1);
     std::vector<uint32_t> tlen(n_streams), base(n_streams);
     size_t pos = 0, packets = 0;
@@ -857,8 +973,8 @@ int efx_index_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, con
             return fail(ctx, EFX_ERR_CAPACITY, "efx_index_streams: more bytes than max_stream_bytes");
         off[i] = pos;
         if (len[i])
-            memcpy(ctx->h_es + pos, ts[i], len[i]);
-        memset(ctx->h_es + pos + len[i], 0, padded - len[i]);
+            memcpy(h_stage + pos, ts[i], len[i]);
+        memset(h_stage + pos + len[i], 0, padded - len[i]);
         tlen[i] = (uint32_t)len[i];
         base[i] = (uint32_t)packets;
         packets += len[i] / 188;
@@ -872,7 +988,7 @@ int efx_index_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, con
         (void)hipFree(d_samples);
         return code;
     };
-    hipError_t e = hipMemcpyAsync(ctx->d_ts, ctx->h_es, pos, hipMemcpyHostToDevice, st);
+    hipError_t e = hipMemcpyAsync(ctx->d_ts, h_stage, pos, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_ts_off, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_idx_len, tlen.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_idx_base, base.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st);
@@ -1042,9 +1158,13 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out)
         t.pictures += ctx->h_pic_count[i];
     t.slices = ctx->h_counters.total_slices;
     t.coefficients = ctx->h_counters.coefficients;
-    t.es_bytes = ctx->es_used;
-    t.demux_ms = ctx->demux_ms;
-    t.ts_bytes = ctx->ts_bytes;
+    {
+        efx_ctx::Upload& u = ctx->up[ctx->slot[ctx->cur].upload];
+        t.es_bytes = u.es_used;
+        t.ts_bytes = u.ts_bytes;
+        if (u.ts_input && u.demux_timed)
+            EFX_HIP(hipEventElapsedTime(&t.demux_ms, u.ev_demux[0], u.ev_demux[1]));
+    }
     *out = t;
     return EFX_OK;
 }

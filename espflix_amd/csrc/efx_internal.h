@@ -43,6 +43,14 @@ struct PesEntry {
     int64_t pts;
 };
 
+// decoder state that survives from one efx_decode call to the next (MpegDecoder::_fb_index, _last_pts != -1,
+// _pts; reference src/player.h:37-47); efx_reset puts back the constructor's values
+struct StreamState {
+    uint32_t fb_index;  // frame index of the next picture's predecessor: pictures so far that swapped buffers, + 1
+    uint32_t pts_seen;  // a picture header has latched a PES PTS
+    int64_t pts_carry;  // newest PES PTS of the uploads so far (-1: none)
+};
+
 struct SliceTmp {
     uint32_t off;       // stream-relative offset of the first byte after the slice start code
     uint32_t len_code;  // (bytes up to the next start code) << 8 | slice start code value

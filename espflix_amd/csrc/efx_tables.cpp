@@ -6,7 +6,8 @@
 //  * VideoTables: composite-video geometry, sync/burst levels and the chroma-phase LUT, derived
 //    with the same float/double arithmetic the reference uses at init time
 //    (video_init/pal_init/usec, video.cpp:554-630; LUT derivation gen_palettes,
-//    espflix.cpp:1091-1161).  tests/test_tables_vs_reference.py pins every value.
+//    espflix.cpp:1091-1161).  tests/test_abi.py and tests/test_oracle_golden.py pin the values
+//    against the reference-derived goldens (geometry, colour LUT, zig-zag, pre-multipliers).
 #include <cmath>
 #include <cstring>
 

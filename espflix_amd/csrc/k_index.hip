@@ -48,7 +48,8 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
                                               uint32_t* __restrict__ status, uint32_t* __restrict__ qtab,
                                               const uint32_t* __restrict__ scan_tab, const PesEntry* __restrict__ pes,
                                               const uint32_t* __restrict__ pkt_base,
-                                              const uint32_t* __restrict__ pes_count, int64_t* __restrict__ pts_out)
+                                              const uint32_t* __restrict__ pes_count, int64_t* __restrict__ pts_out,
+                                              int first_picture)
 {
     __shared__ uint32_t u_off[kMaxUnitsPerStream];
     __shared__ uint32_t u_info[kMaxUnitsPerStream];
@@ -141,7 +142,9 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
     PicInfo* mypics = pics + (size_t)s * max_pictures;
     SliceTmp* myslices = slices_tmp + (size_t)s * max_pictures * kMaxSlicesPerPicture;
     if (lane == 0) {
-        int pic = -1;
+        // pictures before `first_picture` (efx_decode_from: a stream longer than max_pictures is decoded in
+        // several passes) are walked for their state -- sequence matrices, the P pictures' f_code -- and dropped
+        int pic = -1 - first_picture;
         uint32_t slice_total = 0;
         uint32_t p_full = 0, p_r = 0;  // forward_r_size / full_pel_forward persist across pictures
         uint32_t seq_flags = 0, seq_off = 0;
@@ -173,6 +176,8 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
                     uint32_t fc = (info >> 12) & 7;
                     p_r = fc ? fc - 1 : 0;  // f_code 0 is forbidden; the reference would shift by -1
                 }
+                if (pic < 0)
+                    continue;
                 PicInfo pi;
                 pi.first_slice = slice_total;
                 pi.n_slices = 0;
@@ -201,9 +206,9 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
         }
         if (pic >= 0)
             mypics[pic].n_slices = nsl;
-        pic_count[s] = (uint32_t)(pic + 1);
+        pic_count[s] = (uint32_t)(pic >= 0 ? pic + 1 : 0);
         status[s] = st;
-        sh_misc[0] = (uint32_t)(pic + 1);
+        sh_misc[0] = (uint32_t)(pic >= 0 ? pic + 1 : 0);
     }
     __syncthreads();
 
@@ -246,6 +251,49 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
         uint32_t qn = (flags & 2) ? load_bits(sp, non_intra_bit + 8 * zz, 8) : 16;
         qtab[((size_t)s * max_pictures + p) * 64 + lane] = (t & 0xFFFF) | (qi << 16) | (qn << 24);
     }
+}
+
+// flush_picture() as a per-stream recurrence (reference src/player.cpp:692-702, constructor 354-361): the
+// decoder alternates _current / _reference at a picture header only once a picture carried a PES PTS
+// (_last_pts != -1), and its frame index, "a PTS has been seen" and the newest PTS survive from one Buffer
+// to the next.  One thread per stream turns the pictures of this efx_decode call into ring positions:
+//   picture i is reconstructed into slot (pos0 + swaps(i)) % D from slot (pos0 + swaps(i) - 1) % D,
+//   swaps(i) = i + 1 if a PTS was seen before this call, else max(0, i - f), f = first picture with a PTS,
+// (call_pos[2 s] = pos0, call_pos[2 s + 1] = f or -1), patches the PTS of pictures that precede this
+// upload's first PES with the carried one, and advances the state.  Elementary-stream input has no PES
+// layer: every picture counts as carrying a PTS (its index).  Runs on the reconstruction stream, which
+// orders the calls.
+__global__ void k_advance(StreamState* __restrict__ state, const uint32_t* __restrict__ pic_count, int64_t* __restrict__ pts,
+                          const PesEntry* __restrict__ pes, const uint32_t* __restrict__ pkt_base,
+                          const uint32_t* __restrict__ pes_count, int n_streams, int max_pictures, int32_t* __restrict__ call_pos)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams)
+        return;
+    StreamState st = state[s];
+    const int n = (int)pic_count[s];
+    int f = st.pts_seen ? -1 : n;  // first picture of this call whose header latched a PTS
+    if (pts) {
+        int64_t* my = pts + (size_t)s * max_pictures;
+        for (int i = 0; i < n; i++) {
+            if (my[i] == -1 && st.pts_carry != -1)
+                my[i] = st.pts_carry;  // the PES that carries this picture's PTS arrived with an earlier upload
+            if (f == n && my[i] != -1)
+                f = i;
+        }
+        const uint32_t np = pes_count[s];
+        if (np)
+            st.pts_carry = pes[pkt_base[s] + np - 1].pts;
+    } else if (!st.pts_seen)
+        f = 0;
+    call_pos[2 * s] = (int32_t)st.fb_index;
+    call_pos[2 * s + 1] = f;
+    if (n > 0) {
+        st.fb_index += f < 0 ? (uint32_t)n : (uint32_t)(n - 1 > f ? n - 1 - f : 0);
+        if (f < n)
+            st.pts_seen = 1;
+    }
+    state[s] = st;
 }
 
 // stream_perm: the order in which the streams contribute to a picture index -- by descending

@@ -117,11 +117,10 @@ constexpr int kLaneHalfwords = 66;  // per-lane LDS block: 64 int16 + 2 pad = 33
 // 2-D IDCT in registers, forms the prediction of its 8 x 8 pixels from nine 12-byte row fetches and
 // stores eight 8-byte rows.  No lane ever waits for another: no barrier, no shuffle, no scalar
 // bookkeeping, every lane busy.
-// cur_slot / ref_slot are the ring slots of this picture index.
 __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, const uint32_t* __restrict__ coefs,
                                               const uint32_t* __restrict__ scan_tab,
                                               const uint32_t* __restrict__ qtab_custom, uint8_t* __restrict__ frames,
-                                              int max_pictures, int ring_depth, int pic, int cur_slot, int ref_slot,
+                                              int max_pictures, int ring_depth, int pic, const int32_t* __restrict__ call_pos,
                                               int epoch)
 {
     __shared__ int16_t cfh[64 * kLaneHalfwords];
@@ -153,6 +152,10 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         mbx = rr - 88 - 22 * h;
     }
     const int mb = mbrow * kMbW + mbx;
+    // ring position of this picture (k_advance): the reference's _current / _reference alternation, player.cpp:692-702
+    const int pos0 = call_pos[2 * s], first_pts = call_pos[2 * s + 1];
+    const uint32_t q = (uint32_t)pos0 + (uint32_t)(first_pts < 0 ? pic + 1 : max(0, pic - first_pts));
+    const uint32_t cur_slot = q % (uint32_t)ring_depth, ref_slot = (q - 1) % (uint32_t)ring_depth;
     uint8_t* cur = frames + ((size_t)s * ring_depth + cur_slot) * kFrameBytes;
     const uint8_t* ref = frames + ((size_t)s * ring_depth + ref_slot) * kFrameBytes;
 

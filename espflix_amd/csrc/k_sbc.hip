@@ -135,6 +135,11 @@ __global__ __launch_bounds__(64) void k_sbc(const uint8_t* __restrict__ frames, 
     }
     int frequency = st->frequency, blocks = st->blocks, channels = st->channels, mode = st->mode, allocation = st->allocation,
         subbands = st->subbands, bitpool = st->bitpool;
+    // A rejected frame is synthesised "from whatever the state holds" (sbc_decoder.cpp:346-373): a state buffer
+    // that was not zero-initialised must not index the LDS rows or the PCM buffer out of range.
+    blocks = min(blocks, 16);
+    channels = min(channels, 2);
+    subbands = subbands == 4 ? 4 : 8;
     __syncthreads();
 
     const uint8_t* base = frames + (size_t)s * stream_stride;

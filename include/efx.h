@@ -50,7 +50,7 @@ typedef enum efx_status {
 typedef enum efx_format {
     EFX_FORMAT_ES = 0, /* raw ISO 11172-2 video elementary stream */
     EFX_FORMAT_TS = 1  /* 188-byte transport packets, video on PID 0x100 (src/player.cpp:381-493);
-                          demultiplexed on the host at upload, PES PTS kept per picture */
+                          demultiplexed on the device at upload (k_demux), PES PTS kept per picture */
 } efx_format;
 
 typedef struct efx_config {
@@ -81,26 +81,41 @@ const char* efx_status_string(int status);
  * 381-436,459-493) for the whole batch -- adaptation fields and PES headers skipped at the
  * reference's fixed offsets, one zero byte per packet that lost sync, PES PTS values kept for
  * efx_picture_pts.  Like MpegDecoder::more() at end of data (src/player.cpp:456,469-473) each
- * stream is terminated with 00 | 00 00 01 B7 | 00 00 01 B7.  Does NOT reset the frame rings. */
+ * stream is terminated with 00 | 00 00 01 B7 | 00 00 01 B7.  Does NOT reset the frame rings.
+ * Two bitstream buffers alternate: the call copies into pinned staging memory and queues the
+ * transfer (and k_demux) on a copy stream, then returns; the GPU may still be decoding the previous
+ * batch, so ingest and decode of consecutive batches overlap.  efx_decode decodes the batch uploaded
+ * last. */
 int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, const size_t* len, int format);
 /* The elementary stream the decoder sees for `stream` (what MpegDecoder::more() feeds the bit
  * reader, src/player.cpp:459-493), without the end-of-data tail: *es_len receives its length,
  * up to `cap` bytes are copied to dst (dst may be NULL when cap is 0). */
 int efx_download_es(efx_ctx* ctx, int stream, uint8_t* dst, size_t cap, size_t* es_len);
 
-/* MpegDecoder::reset + Frame::init (src/player.cpp:439-453): zero the frame rings and restart
- * picture numbering. */
+/* A freshly constructed decoder: Frame::init (src/player.cpp:25-31) zeroes the frame rings, and the
+ * per-stream state that otherwise survives from one efx_decode to the next -- the frame index
+ * (_fb_index), "a picture has latched a PTS" (_last_pts != -1) and the newest PES PTS (_pts) -- goes
+ * back to the constructor's values (src/player.cpp:354-361).  (MpegDecoder::reset(), 439-453, keeps
+ * _fb_index and _pts across plays; call efx_reset only where a new MpegDecoder would be made.) */
 int efx_reset(efx_ctx* ctx);
 /* Frame::erase (src/player.cpp:48-52): fill every ring frame with 0x30. */
 int efx_erase_frames(efx_ctx* ctx);
 
 /* -- decode ------------------------------------------------------------------------------ */
 /* MpegDecoder::run() over the uploaded batch (src/player.cpp:1355-1367 and everything below
- * it: marker/sequence/gop/picture/slice/block/idct/mocomp).  Asynchronous on the context's
- * stream.  Picture i of a stream (counting every picture start code) is reconstructed into
- * ring slot (i+1) % ring_depth from slot i % ring_depth, exactly as the reference alternates
- * _current/_reference (src/player.cpp:692-702). */
+ * it: marker/sequence/gop/picture/slice/block/idct/mocomp).  Asynchronous.  The decoder keeps
+ * going from call to call like the reference fed Buffer after Buffer: every stream carries its
+ * frame index and its "a PTS has been latched" state (flush_picture, src/player.cpp:692-702).
+ * With p the frame index before the call (1 after efx_reset) picture i of the call is
+ * reconstructed into ring slot (p + s(i)) % ring_depth from slot (p + s(i) - 1) % ring_depth,
+ * s(i) = i + 1 once a picture has latched a PES PTS, else max(0, i - f) with f the first picture of
+ * the call that does: the reference does not swap its two buffers before the first PTS.  Elementary-
+ * stream input counts every picture as carrying one.  ring_depth 2 is the reference's pair. */
 int efx_decode(efx_ctx* ctx);
+/* The same, starting at picture `first_picture` of every uploaded stream (earlier pictures are walked
+ * for their header state only): a stream with more than max_pictures pictures (EFX_STREAM_TRUNCATED)
+ * is decoded by efx_decode_from(ctx, 0), (ctx, max_pictures), (ctx, 2 * max_pictures) ... */
+int efx_decode_from(efx_ctx* ctx, int first_picture);
 int efx_sync(efx_ctx* ctx);
 
 /* number of pictures found in a stream by the last efx_decode (valid after efx_sync) */
@@ -112,8 +127,12 @@ int efx_stream_status(efx_ctx* ctx, int stream, uint32_t* bits);
 int efx_picture_pts(efx_ctx* ctx, int stream, int picture, int64_t* pts);
 
 /* -- frames out (the push_video up-call surface, src/video.h:49) ------------------------- */
-/* Ring slot that holds picture `picture` of the last decode. */
-int efx_picture_slot(const efx_ctx* ctx, int picture);
+/* Ring slot that holds picture `picture` of stream `stream` after the last efx_decode (valid after
+ * efx_sync; see efx_decode for the arithmetic). */
+int efx_stream_picture_slot(efx_ctx* ctx, int stream, int picture, int* slot);
+/* The same for stream 0 as a return value (negative = efx_status): every stream of a batch shares it as
+ * long as all of them decoded the same number of pictures in every call since efx_reset. */
+int efx_picture_slot(efx_ctx* ctx, int picture);
 /* Device pointer to a ring frame in the reference strip layout (12 x 8448 bytes). */
 int efx_frame_device_ptr(efx_ctx* ctx, int stream, int slot, void** dptr);
 /* Copy one ring frame to host memory (EFX_FRAME_BYTES). Synchronous. */

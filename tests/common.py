@@ -129,6 +129,16 @@ def hostile_ts(es: bytes, seed: int, noise: bool = True) -> bytes:
     return packetize(es, starts, rng, noise=noise)
 
 
+def late_pts_ts(es: bytes, first_with_pts: int) -> bytes:
+    """One PES per picture, the first `first_with_pts` of them WITHOUT a PTS: the reference neither pushes nor
+    swaps its buffers until a picture header has latched one (flush_picture, player.cpp:692-702)."""
+    offs = picture_offsets(es)
+    # a PES starts at the first header of each picture's group (sequence / GOP headers travel with their picture)
+    starts = [0] + offs[1:]
+    pes = [(o, None if i < first_with_pts else 129003 + 3003 * i, False, 0) for i, o in enumerate(starts)]
+    return packetize(es, pes, np.random.default_rng(7), noise=False, min_payload=100)
+
+
 # ---- display-state cases shared by the oracle-vs-reference, golden and GPU tests ---------------
 EASE = [0, 8, 16, 24, 48, 72, 104, 136, 176, 216, 248, 280, 304, 328, 336, 344]   # _easd, video.cpp:1076
 

@@ -111,48 +111,143 @@ def test_double_buffer_ring_matches_full_ring(efx):
     dec.close()
 
 
+def bench_golden(name, rows, pictures):
+    """Per-picture frame hashes the unmodified reference decoder produced (tests/golden/make_bench_golden.py)."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+    return np.fromfile(path, dtype="<u8").reshape(rows, pictures)
+
+
+def picture_table(dec, n_streams, n_pictures):
+    """[stream][picture] frame hashes of the last decode of a context that keeps every picture."""
+    h = dec.frame_hashes()
+    return np.stack([h[:, dec.picture_slot(p)] for p in range(n_pictures)], axis=1)[:n_streams]
+
+
 def test_config2_batch256_i_frames(efx):
-    """BASELINE configs[1]: 256 I-frame-only streams; a sample against the oracle, all of them
-    through size-independent properties."""
+    """BASELINE configs[1]: 256 I-frame-only streams, EVERY stream and picture against the reference decoder's
+    output (bench_ionly.u64)."""
     from espflix_amd import gen
+    want = bench_golden("bench_ionly.u64", 256, 8)
     b = gen.Batch(0, 256, 8, 12, gen.FLAG_I_ONLY)
     es = b.all_es()
-    res = gpu_hashes(efx, es, efx.FORMAT_ES, 8)
-    assert all(r["n"] == 8 and r["status"] == 0 for r in res)
-    for k in range(0, 256, 17):
-        _, h, _, _ = oracle.decode(es[k], 0)
-        assert res[k]["hashes"] == [int(x) for x in h]
-    # I pictures do not depend on history: decoding the same batch into a dirty ring is identical
     dec = efx.Decoder(256, 8, 9)
-    dec.erase_frames()
     dec.upload(es, efx.FORMAT_ES)
     dec.decode()
-    h2 = dec.frame_hashes()
-    for k in range(256):
-        assert [int(h2[k, dec.picture_slot(p)]) for p in range(8)] == res[k]["hashes"]
+    assert all(dec.picture_count(i) == 8 and dec.stream_status(i) == 0 for i in range(256))
+    assert np.array_equal(picture_table(dec, 256, 8), want)
+    # I pictures do not depend on history: decoding the same batch again into a dirty ring is identical
+    dec.erase_frames()
+    dec.decode()
+    assert np.array_equal(picture_table(dec, 256, 8), want)
     dec.close()
 
 
-def test_config3_batch1024_gop12_properties(efx):
-    """BASELINE configs[2] at full size: 1024 streams x GOP(12).  Oracle on a spread sample;
-    determinism (two decodes, and a decode after a permuted upload) on all of them."""
+def test_config3_batch1024_gop12_every_stream(efx):
+    """BASELINE configs[2] at full size: 1024 streams x GOP(12), EVERY stream and picture against the reference
+    decoder's output (bench_gop12.u64); the decoder keeps going across calls (the ring rotates), and streams are
+    independent (a permuted batch gives permuted results)."""
     from espflix_amd import gen
+    want = bench_golden("bench_gop12.u64", 8192, 12)[:1024]
     b = gen.Batch(0, 1024, 12, 12, 0)
     es = b.all_es()
     dec = efx.Decoder(1024, 12, 13, max_stream_bytes=sum(e.size for e in es) + 65536)
     dec.upload(es, efx.FORMAT_ES)
     dec.decode()
-    h1 = dec.frame_hashes().copy()
     assert all(dec.picture_count(i) == 12 and dec.stream_status(i) == 0 for i in range(1024))
-    dec.decode()                                   # P pictures start from the I picture: idempotent
-    assert np.array_equal(h1, dec.frame_hashes())
-    for k in range(5, 1024, 97):
-        _, h, _, _ = oracle.decode(es[k], 0)
-        assert [int(h1[k, dec.picture_slot(p)]) for p in range(12)] == [int(x) for x in h]
-    # streams are independent: a permuted batch gives permuted results
+    slots1 = [dec.picture_slot(p) for p in range(12)]
+    assert np.array_equal(picture_table(dec, 1024, 12), want)
+    dec.decode()  # the same GOP again: P pictures start from the I picture, the ring position moves on
+    assert [dec.picture_slot(p) for p in range(12)] == [(s + 12) % 13 for s in slots1]
+    assert np.array_equal(picture_table(dec, 1024, 12), want)
     perm = np.random.default_rng(0).permutation(1024)
     dec.upload([es[j] for j in perm], efx.FORMAT_ES)
     dec.decode()
-    h3 = dec.frame_hashes()
-    assert np.array_equal(h3, h1[perm])
+    assert np.array_equal(picture_table(dec, 1024, 12), want[perm])
     dec.close()
+
+
+def test_real_stream_shape_every_stream(efx):
+    """The service's stream shape (5 slices per picture over 2-3 macroblock rows, ~6.25 kB per picture): 256 streams
+    against the reference decoder's output (bench_wide1500k.u64)."""
+    from espflix_amd import gen
+    want = bench_golden("bench_wide1500k.u64", 1024, 12)[:256]
+    b = gen.Batch(0, 256, 12, 12, gen.FLAG_WIDE_SLICES | gen.FLAG_RATE_1500K)
+    es = b.all_es()
+    dec = efx.Decoder(256, 12, 13, max_stream_bytes=sum(e.size for e in es) + 65536)
+    dec.upload(es, efx.FORMAT_ES)
+    dec.decode()
+    assert all(dec.picture_count(i) == 12 and dec.stream_status(i) == 0 for i in range(256))
+    assert np.array_equal(picture_table(dec, 256, 12), want)
+    dec.close()
+
+
+def test_decoder_keeps_going_across_odd_chunks(efx):
+    """ring_depth = 2 and uploads that end after an odd number of pictures, different for every stream: the frame
+    index is per-stream state (MpegDecoder::_fb_index), not a property of the call."""
+    from espflix_amd import gen
+    b = gen.Batch(20, 3, 12, 12, 0)
+    es = [b.es(k) for k in range(3)]
+    offs = [b.picture_offsets(k) for k in range(3)]
+    cuts = [(5, 8), (4, 9), (7, 10)]  # pictures per stream after the first and second upload
+    want = [oracle.decode(e, 0)[1] for e in es]
+    dec = efx.Decoder(3, 8, 2)
+    bounds = [(0, c[0], c[1], 12) for c in cuts]
+    last = [None] * 3
+    for step in range(3):
+        chunk = [es[k][offs[k][bounds[k][step]]:offs[k][bounds[k][step + 1]]] for k in range(3)]
+        dec.upload(chunk, efx.FORMAT_ES)
+        dec.decode()
+        h = dec.frame_hashes()
+        for k in range(3):
+            n = dec.picture_count(k)
+            assert n == bounds[k][step + 1] - bounds[k][step] and dec.stream_status(k) == 0
+            first = bounds[k][step]
+            for i in (n - 1, n - 2):  # the two pictures the double buffer holds
+                if i >= 0:
+                    assert int(h[k, dec.picture_slot(i, k)]) == int(want[k][first + i]), (step, k, i)
+    dec.close()
+
+
+def test_decode_from_walks_a_long_stream(efx):
+    """A stream with more pictures than max_pictures: efx_decode_from(0), (5), (10) decode it in passes; the
+    truncation is reported, the ring carries over."""
+    from espflix_amd import gen
+    b = gen.Batch(30, 2, 12, 12, 0)
+    es = b.all_es()
+    want = [oracle.decode(e, 0)[1] for e in es]
+    dec = efx.Decoder(2, 5, 2)
+    dec.upload(es, efx.FORMAT_ES)
+    for first, n, trunc in ((0, 5, True), (5, 5, True), (10, 2, False)):
+        dec.decode(first_picture=first)
+        h = dec.frame_hashes()
+        for k in range(2):
+            assert dec.picture_count(k) == n
+            assert bool(dec.stream_status(k) & efx.STREAM_TRUNCATED) == trunc
+            assert int(h[k, dec.picture_slot(n - 1, k)]) == int(want[k][first + n - 1])
+            assert int(h[k, dec.picture_slot(n - 2, k)]) == int(want[k][first + n - 2])
+    dec.close()
+
+
+def test_no_buffer_swap_before_the_first_pts(efx):
+    """flush_picture() neither pushes nor swaps while no PES PTS has been latched (player.cpp:692-702): pictures
+    ahead of the first PTS are decoded over each other; the oracle (pinned against the reference on the same
+    streams, tests/test_oracle_vs_ref.py) and the HIP path agree on every pushed frame, and on the slots."""
+    from espflix_amd import gen
+    b = gen.Batch(50, 2, 8, 12, 0)
+    for k in range(2):
+        es = b.es(k).tobytes()
+        ts = np.frombuffer(common.late_pts_ts(es, first_with_pts=2 + k), dtype=np.uint8)
+        n, hashes, pts, _ = oracle.decode(ts, 1, flush_last=True)
+        assert n == 8 - (2 + k)  # the pictures ahead of the first PTS are never pushed
+        dec = efx.Decoder(1, 8, 9)
+        dec.upload([ts], efx.FORMAT_TS)
+        dec.decode()
+        assert dec.picture_count(0) == 8
+        got_pts = [dec.picture_pts(0, p) for p in range(8)]
+        assert got_pts[:2 + k] == [-1] * (2 + k) and got_pts[2 + k:] == [int(x) for x in pts]
+        slots = [dec.picture_slot(p) for p in range(8)]
+        assert slots[:3 + k] == [1] * (3 + k) and slots[3 + k:] == list(range(2, 7 - k))
+        h = dec.frame_hashes()
+        assert [int(h[0, slots[p]]) for p in range(2 + k, 8)] == [int(x) for x in hashes]
+        dec.close()

@@ -63,6 +63,8 @@ def test_hostile_muxing_es_pts_and_frames(efx, clips):
         n, hashes, pts, _ = oracle.decode(np.frombuffer(ts, dtype=np.uint8), efx.FORMAT_TS, flush_last=True)
         assert dec.picture_count(i) == n
         assert [dec.picture_pts(i, p) for p in range(n)] == [int(x) for x in pts], i
+        h = dec.frame_hashes()  # (double buffer: the last two pictures are resident)
+        assert [int(h[i, dec.picture_slot(p, i)]) for p in (n - 2, n - 1)] == [int(x) for x in hashes[-2:]], i
 
 
 def test_malformed_packets(efx):
@@ -146,7 +148,8 @@ def test_pts_survive_pipelined_decodes(efx, golden):
             dec.decode(sync=False)
         dec.sync()
         got = [[dec.picture_pts(i, p) for p in range(dec.picture_count(i))] for i in range(8)]
-        h = dec.frame_hashes().copy()
+        hh = dec.frame_hashes()
+        h = np.stack([hh[:, dec.picture_slot(p)] for p in range(12)], axis=1)  # the ring moves on with every call
         if want is None:
             want = (got, h)
             assert got[0] == golden["synthetic"]["0:0"]["pts"]

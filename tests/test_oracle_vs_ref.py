@@ -74,6 +74,19 @@ def test_hostile_muxing_pts_latch(seed, clips):
         assert (pts == rpts).all(), (seed, i, pts.tolist(), rpts.tolist())
 
 
+@pytest.mark.parametrize("first_with_pts", [1, 2, 3, 5])
+def test_no_push_and_no_swap_before_the_first_pts(first_with_pts):
+    """flush_picture() while _last_pts == -1 (player.cpp:692-702): pictures ahead of the first PES PTS are decoded
+    over each other and never pushed."""
+    from espflix_amd import gen
+    es = gen.Batch(50, 1, 8, 12, 0).es(0).tobytes()
+    ts = np.frombuffer(common.late_pts_ts(es, first_with_pts), dtype=np.uint8)
+    n, h, pts, _ = oracle.decode(ts, 1, flush_last=True)
+    rh, rpts, _ = oracle.ref_decode(ts, flush_last=True)
+    assert n == len(rh) == 8 - first_with_pts
+    assert (h == rh).all() and list(pts) == list(rpts)
+
+
 @pytest.mark.parametrize("ntsc", [True, False])
 @pytest.mark.parametrize("case", common.DISPLAY_CASES, ids=[c[0] for c in common.DISPLAY_CASES])
 def test_display_state_hscroll_and_overlay(case, ntsc):
