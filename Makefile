@@ -9,7 +9,7 @@ CSRC     = espflix_amd/csrc
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 OBJS     = $(CSRC)/efx_api.o $(CSRC)/k_demux.o $(CSRC)/k_index.o $(CSRC)/k_parse.o $(CSRC)/k_recon.o $(CSRC)/k_video.o $(CSRC)/k_sbc.o $(CSRC)/k_tsindex.o $(CSRC)/efx_tables.o
 
-.PHONY: all lib gen oracle ref clean
+.PHONY: all lib gen oracle ref clean dropin
 all: lib gen oracle
 
 lib: espflix_amd/libefx.so
@@ -25,6 +25,29 @@ espflix_amd/libefx.so: $(OBJS)
 
 espflix_amd/gen/libefx_gen.so: espflix_amd/gen/efx_gen.cpp $(CSRC)/mpeg1_codebook.h
 	g++ -std=c++17 -O2 -Wall -Wextra -fPIC -shared -pthread $< -o $@
+
+# TEST: the reference's UNMODIFIED host player (src/espflix.cpp) and platform layer (src/streamer.cpp) built against
+# libefx's drop-in headers instead of src/player.h / src/video.h -- player.cpp and video.cpp are not in the build.
+# Only where the reference tree exists (the build container); the binaries travel to the GPU box like the .so files.
+REF ?= /root/reference
+DROPIN_FLAGS = -std=c++14 -O1 -w -fpermissive -pthread -Iinclude/espflix_dropin -Iinclude -I$(REF)/src
+DROPIN_LIBS  = -Lespflix_amd -lefx -Wl,-rpath,'$$ORIGIN/../../espflix_amd' -Wl,-rpath,/opt/rocm/lib -L/opt/rocm/lib -lamdhip64
+# (a quoted #include looks in the including file's own directory first, so the reference sources are reached through
+# symbolic links in a scratch directory that holds neither player.h nor video.h: those two -- and only those -- come
+# from include/espflix_dropin; a maintainer simply replaces the two files in src/)
+DROPIN_SRC = tests/_build/dropin_src
+dropin: tests/_build/espflix_dropin tests/_build/espflix_dropin_long
+$(DROPIN_SRC)/espflix.cpp:
+	mkdir -p $(DROPIN_SRC)
+	ln -sf $(REF)/src/espflix.cpp $(DROPIN_SRC)/espflix.cpp
+	ln -sf $(REF)/src/streamer.cpp $(DROPIN_SRC)/streamer.cpp
+tests/_build/espflix_dropin: $(DROPIN_SRC)/espflix.cpp tests/dropin_main.cpp include/efx_player.hpp include/espflix_dropin/player.h espflix_amd/libefx.so
+	g++ $(DROPIN_FLAGS) tests/dropin_main.cpp $(DROPIN_SRC)/espflix.cpp $(DROPIN_SRC)/streamer.cpp $(DROPIN_LIBS) -o $@
+# the same unmodified code playing a 1008-picture synthetic stream: src/splash.h is shadowed by a generated header
+tests/_build/dropin_long/splash.h: tests/make_dropin_long.py espflix_amd/gen/libefx_gen.so
+	python3 tests/make_dropin_long.py tests/_build/dropin_long
+tests/_build/espflix_dropin_long: tests/_build/dropin_long/splash.h $(DROPIN_SRC)/espflix.cpp tests/dropin_main.cpp include/efx_player.hpp espflix_amd/libefx.so
+	g++ -Itests/_build/dropin_long $(DROPIN_FLAGS) tests/dropin_main.cpp $(DROPIN_SRC)/espflix.cpp $(DROPIN_SRC)/streamer.cpp $(DROPIN_LIBS) -o $@
 
 oracle:
 	$(MAKE) -C oracle port

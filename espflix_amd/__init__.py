@@ -88,6 +88,8 @@ _SYMBOLS = {
     "efx_download_es": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "efx_reset": (C.c_int, [_P]),
     "efx_erase_frames": (C.c_int, [_P]),
+    "efx_play_reset": (C.c_int, [_P]),
+    "efx_stream_state": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "efx_decode": (C.c_int, [_P]),
     "efx_decode_from": (C.c_int, [_P, C.c_int]),
     "efx_stream_picture_slot": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int)]),
@@ -265,6 +267,16 @@ class Decoder:
 
     def reset(self):
         _check(self._ctx, self._lib.efx_reset(self._ctx))
+
+    def play_reset(self):
+        """MpegDecoder::reset() between plays: the PTS latch is cleared, the ring position survives."""
+        _check(self._ctx, self._lib.efx_play_reset(self._ctx))
+
+    def stream_state(self, stream: int = 0):
+        """(frame index, a PTS has been latched, newest PES PTS) of a stream."""
+        fi, seen, pts = C.c_uint32(), C.c_int(), C.c_int64()
+        _check(self._ctx, self._lib.efx_stream_state(self._ctx, stream, C.byref(fi), C.byref(seen), C.byref(pts)))
+        return fi.value, bool(seen.value), pts.value
 
     def erase_frames(self):
         _check(self._ctx, self._lib.efx_erase_frames(self._ctx))

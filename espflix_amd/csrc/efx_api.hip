@@ -594,6 +594,40 @@ int efx_reset(efx_ctx* ctx)
     return EFX_OK;
 }
 
+int efx_play_reset(efx_ctx* ctx)
+{
+    if (!ctx)
+        return EFX_ERR_ARG;
+    int r = sync_all(ctx);
+    if (r)
+        return r;
+    const size_t n = (size_t)ctx->cfg.max_streams;
+    std::vector<StreamState> st(n);
+    EFX_HIP(hipMemcpy(st.data(), ctx->d_state, n * sizeof(StreamState), hipMemcpyDeviceToHost));
+    for (auto& x : st)
+        x.pts_seen = 0;  // _last_pts = -1; _fb_index and _pts survive (player.cpp:439-453)
+    EFX_HIP(hipMemcpy(ctx->d_state, st.data(), n * sizeof(StreamState), hipMemcpyHostToDevice));
+    return EFX_OK;
+}
+
+int efx_stream_state(efx_ctx* ctx, int stream, uint32_t* frame_index, int* pts_seen, int64_t* newest_pts)
+{
+    if (!ctx || stream < 0 || stream >= ctx->cfg.max_streams)
+        return EFX_ERR_ARG;
+    int r = sync_all(ctx);
+    if (r)
+        return r;
+    StreamState st;
+    EFX_HIP(hipMemcpy(&st, ctx->d_state + stream, sizeof(st), hipMemcpyDeviceToHost));
+    if (frame_index)
+        *frame_index = st.fb_index;
+    if (pts_seen)
+        *pts_seen = (int)st.pts_seen;
+    if (newest_pts)
+        *newest_pts = st.pts_carry;
+    return EFX_OK;
+}
+
 int efx_erase_frames(efx_ctx* ctx)
 {
     if (!ctx)

@@ -98,6 +98,15 @@ int efx_download_es(efx_ctx* ctx, int stream, uint8_t* dst, size_t cap, size_t* 
  * back to the constructor's values (src/player.cpp:354-361).  (MpegDecoder::reset(), 439-453, keeps
  * _fb_index and _pts across plays; call efx_reset only where a new MpegDecoder would be made.) */
 int efx_reset(efx_ctx* ctx);
+/* MpegDecoder::reset() between two plays on the same decoder (src/player.cpp:439-453): _last_pts = -1,
+ * i.e. the next picture headers neither push nor swap until one latches a PES PTS again; the frame index,
+ * the newest PES PTS and the frame contents survive.  Synchronous. */
+int efx_play_reset(efx_ctx* ctx);
+/* The per-stream decoder state (valid for what has been queued so far; synchronises): the frame index
+ * (MpegDecoder::_fb_index: the next picture is reconstructed into slot frame_index % ring_depth if no buffer
+ * swap precedes it, frame_index + 1 otherwise, from the slot before), whether a picture has latched a PTS
+ * since the last (play) reset, and the newest PES PTS seen (-1: none).  Any pointer may be NULL. */
+int efx_stream_state(efx_ctx* ctx, int stream, uint32_t* frame_index, int* pts_seen, int64_t* newest_pts);
 /* Frame::erase (src/player.cpp:48-52): fill every ring frame with 0x30. */
 int efx_erase_frames(efx_ctx* ctx);
 

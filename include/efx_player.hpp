@@ -21,13 +21,29 @@
 //   * MpegDecoder::run() lives on its own thread, blocks in pop of the full queue, and hands each
 //     picture to push_video() on that thread, in order, with the PTS the reference would latch;
 //     like the reference it does NOT push the last picture of a stream until flush_picture(mode)
-//     is called, and it parks in pause() (DECODER_PAUSED) at end of stream.
-//   * The transport stream of one play (reset() .. zero-length Buffer) is decoded in one batch
-//     call; pictures are therefore delivered after the zero-length Buffer arrived, not while the
-//     file is still streaming in.  (A service decoding many streams uses efx.h directly.)
+//     is called, pushes nothing before a picture has latched a PES PTS, and parks in pause()
+//     (DECODER_PAUSED) at end of stream.
+//   * STREAMING: Buffers are decoded while they arrive, in windows cut where a video PES starts with
+//     a sequence, group or picture start code (every picture of the reference's own files and of
+//     ffmpeg's muxer starts a PES): a window is decoded when a sequence header opens the next one,
+//     when it holds kWindowPictures pictures, or at the zero-length Buffer.  Pictures therefore arrive up
+//     to one window (one GOP) after the reference would have pushed them; a play may be of any length.
+//     The decoder state travels from window to window on the device (frame index, PTS latch, reference
+//     frame: efx.h, efx_decode), exactly as the reference's does from Buffer to Buffer.  A stream whose
+//     PES packets never start at a picture is decoded at its end (one window of at most
+//     kWindowBytes; what does not fit is reported on stderr, never dropped silently).
+//   * Audio: transport packets of PID 0x101 / 0x102 are handed to push_audio() as MpegDecoder::demux does
+//     (player.cpp:421-433), from the decoder thread.
 //   * Frame strips are host memory (the UI draws into them, src/espflix.cpp:62-84); decoded
-//     pictures are copied into them before push_video(), and video_isr() re-uploads the front
-//     Frame once per field, so host-side drawing is honoured.
+//     pictures are copied into them before push_video(), the two Frames are uploaded to the device ring
+//     at the start of a play (a play that opens with P pictures predicts from what the Frames hold), and
+//     video_isr() re-uploads the front Frame once per field, so host-side drawing is honoured.
+//
+// Platform layer.  Defined on its own this header also declares the few platform names the player
+// code needs (Q, Buffer, the event word); compiled INTO the reference tree in place of player.h /
+// video.h (include/espflix_dropin/) it takes them from the reference's own streamer.h
+// (EFX_PLAYER_USE_REFERENCE_PLATFORM), so that the unmodified espflix.cpp and streamer.cpp build
+// against it.
 #ifndef EFX_PLAYER_HPP
 #define EFX_PLAYER_HPP
 
@@ -50,6 +66,9 @@
 #define FB_SLICE_HEIGHT 16
 #define FB_SLICES (FB_HEIGHT / FB_SLICE_HEIGHT)
 
+#ifdef EFX_PLAYER_USE_REFERENCE_PLATFORM
+#include "streamer.h"  // the reference's: Q, Buffer, DECODER_* events, start_thread, printf -> printf_nano
+#else
 enum { DECODER_RUN = 2, DECODER_PAUSED = 4, AUDIO_READY = 8, VIDEO_READY = 16, DNS_READY = 256 };
 
 int get_events();
@@ -69,6 +88,13 @@ class Q {
     int waiting();
 };
 
+class Buffer {
+  public:
+    uint32_t len;
+    uint8_t data[8 * 188];
+};
+#endif
+
 class Frame {
   public:
     uint8_t* _slices[FB_SLICES];
@@ -77,12 +103,6 @@ class Frame {
     uint8_t* get_cr(int y);
     uint8_t* get_cb(int y);
     void erase();
-};
-
-class Buffer {
-  public:
-    uint32_t len;
-    uint8_t data[8 * 188];
 };
 
 // up-calls the host provides, exactly as in the reference
@@ -105,14 +125,25 @@ class MpegDecoder {
     int64_t get_pts();
     void flush_picture(int mode = 0);
 
+    enum { kWindowPictures = 30, kMaxPictures = 64, kWindowBytes = 32 << 20 };
+
   protected:
     void pause();
-    void decode_accumulated();
+    void feed(const uint8_t* packets, size_t bytes);  // transport packets of one Buffer
+    void decode_window(size_t bytes);                 // decode the first `bytes` of the window, keep the rest
+    void seed_ring();
     Q _empty_q;
     Q _full_q;
-    std::vector<uint8_t> _ts;
+    std::vector<uint8_t> _win;  // transport packets not yet decoded
+    size_t _cut;                // newest cut candidate inside _win (0 = none)
+    int _win_pictures;          // picture-starting PES packets in _win
+    bool _play_started;         // the ring has been seeded for this play
     efx_ctx* _ctx;
-    bool _have_last;   // a decoded picture is waiting for the next flush_picture()
+    bool _have_last;            // a decoded picture is waiting for the next flush_picture()
+    // audio branch of demux (player.cpp:421-433)
+    int64_t _audio_pts;
+    int _audio_expected, _audio_mark;
+    std::vector<uint8_t> _frame;
 };
 
 void video_init(int ntsc);
@@ -144,6 +175,7 @@ void efx_set_pdm_sink(efx_pdm_sink sink);
 #ifdef EFX_PLAYER_IMPLEMENTATION
 // =================================================================================================
 
+#ifndef EFX_PLAYER_USE_REFERENCE_PLATFORM
 namespace efx_player_detail {
 inline std::mutex& ev_guard()
 {
@@ -214,6 +246,8 @@ int Q::waiting()
     return (int)queue.size();
 }
 
+#endif  // EFX_PLAYER_USE_REFERENCE_PLATFORM
+
 void Frame::init()
 {
     for (int i = 0; i < FB_SLICES; i++) {
@@ -230,7 +264,9 @@ void Frame::erase()
         memset(_slices[i], 0x30, FB_STRIDE * FB_SLICE_HEIGHT + 4);
 }
 
-MpegDecoder::MpegDecoder(Frame* fb0, Frame* fb1) : _ctx(0), _have_last(false)
+MpegDecoder::MpegDecoder(Frame* fb0, Frame* fb1)
+    : _cut(0), _win_pictures(0), _play_started(false), _ctx(0), _have_last(false), _audio_pts(-1), _audio_expected(0), _audio_mark(0),
+      _frame(EFX_FRAME_BYTES)
 {
     _fb[0] = fb0;
     _fb[1] = fb1;
@@ -241,9 +277,9 @@ MpegDecoder::MpegDecoder(Frame* fb0, Frame* fb1) : _ctx(0), _have_last(false)
     efx_config cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.max_streams = 1;
-    cfg.max_pictures = 250;
-    cfg.ring_depth = 2;
-    cfg.max_stream_bytes = 8u << 20;
+    cfg.max_pictures = kMaxPictures;
+    cfg.ring_depth = kMaxPictures + 1;  // every picture of a decode pass stays until it has been handed out
+    cfg.max_stream_bytes = kWindowBytes;
     if (efx_create(&cfg, &_ctx) != EFX_OK) {
         fprintf(stderr, "MpegDecoder: efx_create failed (a gfx950 device is required)\n");
         abort();
@@ -259,10 +295,15 @@ void MpegDecoder::reset()  // player.cpp:439-453: called by the feeder while the
 {
     while (!_full_q.empty())
         _empty_q.push(_full_q.pop());
-    _ts.clear();
+    _win.clear();
+    _cut = 0;
+    _win_pictures = 0;
+    _play_started = false;
     video_reset();
     _last_pts = -1;
+    _audio_pts = -1;
     _have_last = false;
+    efx_play_reset(_ctx);  // _last_pts = -1 on the device too; frame index and newest PTS survive, as in the reference
 }
 
 int64_t MpegDecoder::get_pts() { return _last_pts; }
@@ -288,47 +329,148 @@ void MpegDecoder::pause()  // player.cpp:1342-1352
     clear_events(DECODER_PAUSED);
 }
 
-void MpegDecoder::decode_accumulated()
+// The two host Frames into the device ring, at the slots the next picture and its reference occupy
+// (_current / _reference): the reference decodes INTO the Frames the UI draws on, so a play that opens
+// with P pictures predicts from whatever they hold.
+void MpegDecoder::seed_ring()
 {
-    const uint8_t* ptr = _ts.empty() ? (const uint8_t*)"" : &_ts[0];
-    size_t len = _ts.size();
-    if (efx_upload_streams(_ctx, 1, &ptr, &len, EFX_FORMAT_TS) != EFX_OK || efx_decode(_ctx) != EFX_OK ||
-        efx_sync(_ctx) != EFX_OK) {
-        fprintf(stderr, "MpegDecoder: %s\n", efx_last_error(_ctx));
+    uint32_t fi = 1;
+    if (efx_stream_state(_ctx, 0, &fi, 0, 0) != EFX_OK)
         return;
-    }
-    int n = 0;
-    efx_picture_count(_ctx, 0, &n);
-    if (n <= 0)
-        return;
-    // The context's two-deep ring (the reference's _fb[2]) only keeps the last two pictures, but
-    // the reference contract is one push_video() per picture: decode the play once more into a
-    // ring deep enough to hold every picture and hand them out in order.
-    efx_ctx* all = 0;
-    efx_config cfg;
-    memset(&cfg, 0, sizeof(cfg));
-    cfg.max_streams = 1;
-    cfg.max_pictures = n;
-    cfg.ring_depth = n + 1;
-    cfg.max_stream_bytes = len + 4096;
-    if (efx_create(&cfg, &all) != EFX_OK)
-        return;
-    efx_upload_streams(all, 1, &ptr, &len, EFX_FORMAT_TS);
-    efx_decode(all);
-    efx_sync(all);
-    std::vector<uint8_t> frame(EFX_FRAME_BYTES);
-    for (int i = 0; i < n; i++) {
-        int64_t pts = -1;
-        efx_picture_pts(all, 0, i, &pts);
-        _pts = pts;        // latched by the PES that carries this picture (player.cpp:417-418)
-        flush_picture(0);  // picture start: push the previous picture, swap buffers (player.cpp:704-706)
-        Frame* dst = _fb[_fb_index & 1];
-        efx_download_frame(all, 0, efx_picture_slot(all, i), &frame[0]);
+    const uint32_t depth = kMaxPictures + 1;
+    for (int k = 0; k < 2; k++) {  // k = 0: _current (slot fi), k = 1: _reference (slot fi - 1)
+        const Frame* f = _fb[(_fb_index - k) & 1];
         for (int s = 0; s < FB_SLICES; s++)
-            memcpy(dst->_slices[s], &frame[(size_t)s * EFX_STRIP_BYTES], EFX_STRIP_BYTES);
-        _have_last = true;
+            memcpy(&_frame[(size_t)s * EFX_STRIP_BYTES], f->_slices[s], EFX_STRIP_BYTES);
+        efx_upload_frame(_ctx, 0, (int)((fi - (uint32_t)k) % depth), &_frame[0]);
     }
-    efx_destroy(all);
+}
+
+void MpegDecoder::decode_window(size_t bytes)
+{
+    if (bytes > _win.size())
+        bytes = _win.size();
+    if (!_play_started) {
+        seed_ring();
+        _play_started = true;
+    }
+    const uint8_t* ptr = _win.empty() ? (const uint8_t*)"" : &_win[0];
+    size_t len = bytes;
+    if (len > (size_t)kWindowBytes) {
+        fprintf(stderr, "MpegDecoder: %zu bytes without a picture-aligned PES; only the first %d are decoded\n", len, (int)kWindowBytes);
+        len = kWindowBytes / 188 * 188;
+    }
+    if (efx_upload_streams(_ctx, 1, &ptr, &len, EFX_FORMAT_TS) != EFX_OK) {
+        fprintf(stderr, "MpegDecoder: %s\n", efx_last_error(_ctx));
+        len = 0;
+    }
+    // passes of at most kMaxPictures pictures over the window (efx_decode_from)
+    for (int first = 0; len;) {
+        if (efx_decode_from(_ctx, first) != EFX_OK || efx_sync(_ctx) != EFX_OK) {
+            fprintf(stderr, "MpegDecoder: %s\n", efx_last_error(_ctx));
+            break;
+        }
+        int n = 0;
+        uint32_t status = 0;
+        efx_picture_count(_ctx, 0, &n);
+        efx_stream_status(_ctx, 0, &status);
+        if (status & ~(uint32_t)EFX_STREAM_TRUNCATED)
+            fprintf(stderr, "MpegDecoder: stream status %u (see efx.h)\n", status);
+        for (int i = 0; i < n; i++) {
+            int64_t pts = -1;
+            int slot = 0;
+            efx_picture_pts(_ctx, 0, i, &pts);
+            _pts = pts;        // what picture() finds latched (player.cpp:417-418,700)
+            flush_picture(0);  // picture start: push the previous picture, swap buffers (player.cpp:704-706)
+            Frame* dst = _fb[_fb_index & 1];
+            efx_stream_picture_slot(_ctx, 0, i, &slot);
+            efx_download_frame(_ctx, 0, slot, &_frame[0]);
+            for (int s = 0; s < FB_SLICES; s++)
+                memcpy(dst->_slices[s], &_frame[(size_t)s * EFX_STRIP_BYTES], EFX_STRIP_BYTES);
+            _have_last = true;
+        }
+        if (!(status & EFX_STREAM_TRUNCATED) || n <= 0)
+            break;
+        first += n;
+    }
+    _win.erase(_win.begin(), _win.begin() + (ptrdiff_t)bytes);
+    _cut = 0;
+    _win_pictures = 0;
+}
+
+namespace efx_player_detail {
+inline int64_t parse_pts(const uint8_t* d, int flags)  // player.cpp:299-307
+{
+    flags = (flags >> 2) & 0x30;
+    if ((d[0] & 0xF0) != flags)
+        return -1;
+    int64_t n = ((int64_t)(d[0] & 0x0E)) << 29;
+    n |= (int64_t)d[1] << 22;
+    n |= (int64_t)(d[2] & 0xFE) << 14;
+    n |= (int64_t)d[3] << 7;
+    n |= d[4] >> 1;
+    return n;
+}
+}  // namespace efx_player_detail
+
+// One Buffer of transport packets: audio goes to push_audio() at once (player.cpp:421-433), video
+// accumulates in the window, which is decoded at cut points (see the header of this file).
+void MpegDecoder::feed(const uint8_t* pk, size_t bytes)
+{
+    for (size_t o = 0; o + 188 <= bytes; o += 188) {
+        const uint8_t* d = pk + o;
+        if (d[0] != 0x47) {  // "ts lost sync": the reference feeds a zero byte and drops the rest of the Buffer (player.cpp:476-480)
+            _win.insert(_win.end(), d, d + 188);
+            continue;
+        }
+        const int pid = ((d[1] << 8) + d[2]) & 0x1FFF;
+        const bool pusi = d[1] & 0x40;
+        const uint8_t* data = d + 4;
+        if (d[3] & 0x20)
+            data = d + 5 + d[4];
+        const uint8_t* end = d + 188;
+        const bool has_payload = d[3] & 0x10;
+        if (pid == 0x100) {
+            if (has_payload && pusi && data + 13 <= end) {
+                const uint8_t* es = data + 9 + data[8];  // PES payload (player.cpp:391-393)
+                if (es + 4 <= end && es[0] == 0 && es[1] == 0 && es[2] == 1 && (es[3] == 0xB3 || es[3] == 0xB8 || es[3] == 0x00)) {
+                    // a picture (group, sequence) starts a PES here: everything before this packet is whole pictures
+                    const size_t at = _win.size();
+                    if (at && (es[3] == 0xB3 || _win_pictures >= kWindowPictures || at + 188 > (size_t)kWindowBytes)) {
+                        decode_window(at);
+                    } else if (at)
+                        _cut = at;
+                    _win_pictures++;
+                }
+            }
+            if (_win.size() + 188 > (size_t)kWindowBytes && _cut) {
+                decode_window(_cut);
+            }
+            _win.insert(_win.end(), d, d + 188);
+        } else if ((pid == 0x101 || pid == 0x102) && has_payload) {
+            int64_t pts = -1;
+            int expected = 0;
+            const uint8_t* payload = data;
+            if (pusi && data + 14 <= end) {
+                expected = (data[4] << 8) | data[5];
+                const int flags = (data[6] << 8) | data[7];
+                payload = data + 9 + data[8];
+                if (expected)
+                    expected -= 3 + data[8];
+                if (flags & 0x0080)
+                    pts = efx_player_detail::parse_pts(data + 9, flags);
+            }
+            if (pusi) {
+                _audio_expected = expected;
+                _audio_mark = 0;
+                _audio_pts = pts;
+            }
+            if (_audio_pts != -1 && payload <= end) {
+                _audio_mark += (int)(end - payload);
+                push_audio(payload, (int)(end - payload), pts, _audio_mark == _audio_expected);
+            }
+        }
+    }
 }
 
 void MpegDecoder::run()  // player.cpp:1355-1367
@@ -339,13 +481,12 @@ void MpegDecoder::run()  // player.cpp:1355-1367
         Buffer* b = (Buffer*)_full_q.pop();
         if (!b)
             continue;
-        bool eos = b->len == 0 || b->len > sizeof(b->data);
+        const bool eos = (int32_t)b->len <= 0 || b->len > sizeof(b->data);
         if (!eos)
-            _ts.insert(_ts.end(), b->data, b->data + b->len);
+            feed(b->data, b->len);
         _empty_q.push(b);
-        if (eos) {  // zero-length Buffer: the decoder pads with a sequence_end code and pauses
-            decode_accumulated();
-            _ts.clear();
+        if (eos) {  // zero-length Buffer: the decoder pads with a sequence_end code and pauses (player.cpp:469-473,1324-1327)
+            decode_window(_win.size());
             pause();
         }
     }

@@ -2,8 +2,9 @@
 // (Frame, Buffer, MpegDecoder, push_video, video_init/video_isr, write_pcm_16, event flags) --
 // the same calls ESPFlix::play_rom / decode_next / load_poster make (reference
 // src/espflix.cpp:723-737,1043-1068) -- compiled against include/efx_player.hpp.
-// Prints one line per pushed frame "F <idx> <pts> <fnv>", then "V <fnv>" for one composite
-// field of the last frame and "A <fnv>" for three write_pcm_16 calls.
+// Prints one line per pushed frame "F <idx> <pts> <fnv>", "U <bytes> <fnv>" for the audio bytes handed
+// to push_audio, then "V <fnv>" for one composite field of the last frame, "W" for a slide under the
+// overlay, "A <fnv>" for three write_pcm_16 calls and "B <fnv>" for beep() + six more.
 #include <stdio.h>
 #include <unistd.h>
 
@@ -33,7 +34,13 @@ void push_video(Frame* f, int front, int64_t pts, int mode)
     g_frames = f;
     g_front = front;
 }
-void push_audio(const uint8_t*, int, int64_t, bool) {}
+static uint64_t g_audio_in = 0xcbf29ce484222325ull;
+static long g_audio_bytes = 0;
+void push_audio(const uint8_t* d, int n, int64_t, bool)  // the bytes the SBC decoder would receive (video.cpp:1006-1019)
+{
+    g_audio_in = fnv(d, (size_t)n, g_audio_in);
+    g_audio_bytes += n;
+}
 
 static uint64_t g_audio = 0xcbf29ce484222325ull;
 static void audio_sink(const uint16_t* w, int n) { g_audio = fnv((const uint8_t*)w, (size_t)n * 2, g_audio); }
@@ -66,6 +73,7 @@ int main(int argc, char** argv)
     }
     wait_events(DECODER_PAUSED);
     dec.flush_picture(1);  // as load_poster does: show the last picture too
+    printf("U %ld %016llx\n", g_audio_bytes, (unsigned long long)g_audio_in);
 
     video_init(1);
     efx_video_present(g_frames, g_front);
@@ -99,6 +107,15 @@ int main(int argc, char** argv)
         write_pcm_16(c == 1 ? 0 : pcm, 128, 1);
     }
     printf("A %016llx\n", (unsigned long long)g_audio);
+    // beep(): the key-press feedback tone, five 128-sample bursts in place of the PCM (espflix.ino:109-135)
+    g_audio = 0xcbf29ce484222325ull;
+    beep();
+    for (int c = 0; c < 6; c++) {
+        for (int i = 0; i < 128; i++)
+            pcm[i] = (int16_t)((i * 11 + c * 300) % 2001 - 1000);
+        write_pcm_16(pcm, 128, 1);
+    }
+    printf("B %016llx\n", (unsigned long long)g_audio);
     fflush(stdout);
     _exit(0);
 }

@@ -53,3 +53,51 @@ def test_reference_style_host_program(tmp_path, clip, golden):
         words.append(oracle.write_pcm_16(st, beep, None if c == 1 else pcm))
     a = [r for r in rows if r[0] == "A"][0][1]
     assert a == f"{oracle.fnv1a64(np.concatenate(words).view(np.uint8)):016x}"
+    # beep(): five tone bursts replace the PCM, the sixth call is PCM again
+    beep.value = 5
+    words = []
+    for c in range(6):
+        pcm = np.array([(i * 11 + c * 300) % 2001 - 1000 for i in range(128)], dtype=np.int16)
+        words.append(oracle.write_pcm_16(st, beep, pcm))
+    b = [r for r in rows if r[0] == "B"][0][1]
+    assert b == f"{oracle.fnv1a64(np.concatenate(words).view(np.uint8)):016x}"
+    # the audio bytes push_audio() received (PID 0x102 of the clip)
+    u = [r for r in rows if r[0] == "U"][0]
+    es = oracle.ts_audio_es(ts)
+    assert int(u[1]) == es.size and u[2] == f"{oracle.fnv1a64(es):016x}"
+
+
+def test_streaming_play_of_a_thousand_pictures(tmp_path):
+    """A play far longer than one decode window (84 GOPs): the adapter decodes window by window while the
+    Buffers arrive, the decoder state travels on the device; every pushed frame and PTS against the oracle."""
+    from espflix_amd import gen
+    exe = build(tmp_path)
+    ts = gen.Batch(3, 1, 1008, 12, 0).ts(0)
+    path = str(tmp_path / "long.ts")
+    ts.tofile(path)
+    p = subprocess.run([exe, path], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    frames = [l.split() for l in p.stdout.splitlines() if l.startswith("F ")]
+    n, h, pts, _ = oracle.decode(ts, 1, flush_last=True, max_frames=1100)
+    assert n == 1008 and len(frames) == 1008
+    assert [int(r[3], 16) for r in frames] == [int(x) for x in h]
+    assert [int(r[2]) for r in frames] == [int(x) for x in pts]
+    assert "status" not in p.stderr and "without a picture-aligned" not in p.stderr
+
+
+def test_unaligned_pes_stream_is_decoded_at_its_end(tmp_path):
+    """PES packets that never start at a picture (hostile muxing) offer no cut point: the adapter decodes the
+    play in one window when the zero-length Buffer arrives -- same frames, same PTS."""
+    import common
+    from espflix_amd import gen
+    exe = build(tmp_path)
+    es = gen.Batch(5, 1, 24, 12, 0).es(0).tobytes()
+    ts = np.frombuffer(common.hostile_ts(es, 77), dtype=np.uint8)
+    path = str(tmp_path / "hostile.ts")
+    ts.tofile(path)
+    p = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    frames = [l.split() for l in p.stdout.splitlines() if l.startswith("F ")]
+    n, h, pts, _ = oracle.decode(ts, 1, flush_last=True)
+    assert [int(r[3], 16) for r in frames] == [int(x) for x in h]
+    assert [int(r[2]) for r in frames] == [int(x) for x in pts]

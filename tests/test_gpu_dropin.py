@@ -1,0 +1,57 @@
+"""The real binding: the reference's UNMODIFIED host player src/espflix.cpp and platform layer src/streamer.cpp,
+compiled (by `make dropin`, in the build container, where the reference tree is) against libefx's drop-in
+headers include/espflix_dropin/{player,video}.h instead of src/player.h / src/video.h -- src/player.cpp and
+src/video.cpp are not in the build.  ESPFlix::run() -> play_rom(splash_ts) (src/espflix.cpp:1043-1058) then
+drives MpegDecoder exactly as on the device; every push_video() up-call must carry the frame and PTS the
+reference decoder delivers."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def run_dropin(name, tmp_path):
+    exe = os.path.join(ROOT, "tests", "_build", name)
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} was not built (`make dropin` needs the reference tree)")
+    log = str(tmp_path / "dropin.log")
+    # The reference's desktop event word (src/streamer.cpp:305-339) is a plain int with unlocked read-modify-write
+    # and a condition variable that can miss a notify: a play can stall in wait_events() with either decoder.  The
+    # harness's watchdog reports that as exit code 3; such a run says nothing about the decoder and is repeated.
+    for attempt in range(4):
+        p = subprocess.run([exe], env=dict(os.environ, EFX_DROPIN_LOG=log, EFX_DROPIN_TIMEOUT="15"), capture_output=True,
+                           text=True, timeout=120)
+        if p.returncode != 3:
+            break
+    assert p.returncode == 0, (open(log).read()[-500:], p.stderr[-2000:])
+    rows = [l.split() for l in open(log).read().splitlines()]
+    return [r for r in rows if r[0] == "F"], [r for r in rows if r[0] == "DONE"][0], p.stderr
+
+
+def test_unmodified_espflix_plays_the_splash_clip(tmp_path, golden):
+    frames, done, err = run_dropin("espflix_dropin", tmp_path)
+    g = golden["clips"]["splash"]
+    n = g["pushed_without_flush"]            # play_rom never flushes the last picture (player.cpp:692-702)
+    assert len(frames) == n == int(done[1])
+    assert [r[3] for r in frames] == g["hashes"][:n]
+    assert [int(r[2]) for r in frames] == g["pts"][:n]
+    ts = np.fromfile(os.path.join(ROOT, "tests", "golden", "splash.ts"), dtype=np.uint8)
+    assert int(done[2]) == oracle.ts_audio_es(ts).size   # the audio bytes went to push_audio()
+    assert "MpegDecoder:" not in err
+
+
+def test_unmodified_espflix_plays_a_thousand_pictures(tmp_path):
+    frames, done, err = run_dropin("espflix_dropin_long", tmp_path)
+    path = os.path.join(ROOT, "tests", "_build", "dropin_long", "long.ts")
+    ts = np.fromfile(path, dtype=np.uint8)
+    n, h, pts, _ = oracle.decode(ts, 1, flush_last=False, max_frames=1100)
+    assert n == 1007 and len(frames) == n
+    assert [int(r[3], 16) for r in frames] == [int(x) for x in h]
+    assert [int(r[2]) for r in frames] == [int(x) for x in pts]
+    assert "MpegDecoder:" not in err
