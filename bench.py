@@ -289,6 +289,33 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
         if not np.array_equal(chains, want):
             raise SystemExit(f"parity gate ({workload}): gathered chain hashes differ from the reference on {int((chains != want).sum())} streams")
 
+    # ingest included: every step uploads the batch from host memory again (staging copy, H2D on the copy stream
+    # into the bitstream buffer the running decode does not read) and decodes it; upload n+1 overlaps decode n
+    ingest = None
+    if want_serial:
+        prep = dec.prepare_upload(streams)
+        isteps = max(4, min(steps, 20))
+        for _ in range(2):
+            dec.upload_prepared(prep, 0)
+            dec.decode(sync=False)
+        dec.sync()
+        job.barrier()
+        t0 = time.perf_counter()
+        for _ in range(isteps):
+            dec.upload_prepared(prep, 0)
+            dec.decode(sync=False)
+        dec.sync()
+        job.barrier()
+        dt = edist.max_over_ranks(time.perf_counter() - t0, job.dist, job.device)
+        hashes = dec.frame_hashes()
+        for p in (P - 2, P - 1):
+            if p >= 0 and not np.array_equal(hashes[:, dec.picture_slot(p)], got[:, p]):
+                raise SystemExit(f"parity gate ({workload}, ingest leg): picture {p} differs from the reference decoder")
+        ingest = {"pcie_inclusive_frames_per_s": totals[0] * isteps / dt, "ms_per_step": dt / isteps * 1e3, "steps": isteps,
+                  "what": "efx_upload_streams from pageable host buffers (threaded staging copy into pinned memory, H2D on the "
+                          "copy stream) + efx_decode per step, two bitstream buffers: the upload of step n+1 runs under the "
+                          "decode of step n"}
+
     serial_ms = None
     if want_serial:
         # outside the timed region: the same stages one call at a time (no overlap between calls), for
@@ -303,7 +330,7 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
         csum = int(np.bitwise_xor.reduce(chains * edist.GOLDEN)) if chains.size else 0
     return {"workload": workload, "S": S, "P": P, "es_bytes": es_bytes, "n_i": n_i, "n_p": n_p, "elapsed": elapsed,
             "stage_ms": stage_ms, "serial_ms": serial_ms, "timed_calls": timed_calls, "n_coefs": int(n_coefs),
-            "gen_seconds": t_gen, "batch0": batches[0][1], "job_pictures": totals[0], "job_es_bytes": totals[1],
+            "gen_seconds": t_gen, "batch0": batches[0][1], "ingest": ingest, "job_pictures": totals[0], "job_es_bytes": totals[1],
             "checksum": csum, "streams_checked": int(chains.size), "first_id": int(ids[0]), "last_id": int(ids[-1])}
 
 
@@ -446,6 +473,7 @@ def run(job, args):
                                 "ranks gathered and compared on rank 0", "passed": True},
         "checksum_of_checksums": f"{r['checksum']:016x}",
         "gen_seconds": r["gen_seconds"],
+        "ingest": r["ingest"],
         "fixed_batch_8192": fixed,
         "other_workloads": others,
         "cpu_baseline": cpu,

@@ -265,6 +265,18 @@ class Decoder:
         _check(self._ctx, self._lib.efx_upload_streams(self._ctx, n, ptrs, lens, fmt))
         self.n_streams = n
 
+    def prepare_upload(self, streams):
+        """The ctypes argument arrays of upload() for a batch that is uploaded repeatedly (ingest benchmarks)."""
+        arrs = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray, memoryview))
+                else np.ascontiguousarray(s, dtype=np.uint8) for s in streams]
+        n = len(arrs)
+        return arrs, (_P * n)(*[a.ctypes.data for a in arrs]), (C.c_size_t * n)(*[a.size for a in arrs]), n
+
+    def upload_prepared(self, prepared, fmt: int = FORMAT_ES):
+        _, ptrs, lens, n = prepared
+        _check(self._ctx, self._lib.efx_upload_streams(self._ctx, n, ptrs, lens, fmt))
+        self.n_streams = n
+
     def reset(self):
         _check(self._ctx, self._lib.efx_reset(self._ctx))
 

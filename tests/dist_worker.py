@@ -29,13 +29,20 @@ class OracleDecoder:
             self.tab.append(h[:n])
         self.S = len(streams)
 
-    def decode(self, sync=True):
+    def prepare_upload(self, streams):
+        return streams
+
+    def upload_prepared(self, prepared, fmt=0):
+        if not hasattr(self, "tab"):
+            self.upload(prepared, fmt)
+
+    def decode(self, sync=True, first_picture=0):
         self.calls += 1
 
     def sync(self):
         pass
 
-    def picture_slot(self, p):
+    def picture_slot(self, p, stream=0):
         return (p + 1) % self.D
 
     def picture_count(self, i):
