@@ -376,9 +376,11 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         idct8(v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
+        // the final rounding "(x + 128) >> 8" (player.cpp:985-994) keeps its shift for the byte permutes below: a
+        // residual fits 16 bits, so bytes 1 and 2 of x + 128 ARE the shifted value
 #pragma unroll
         for (int c = 0; c < 8; c++)
-            v[r * 8 + c] = (v[r * 8 + c] + 128) >> 8;
+            v[r * 8 + c] += 128;
         asm volatile("" : "+v"(v[r * 8]), "+v"(v[r * 8 + 1]), "+v"(v[r * 8 + 2]), "+v"(v[r * 8 + 3]), "+v"(v[r * 8 + 4]),
                      "+v"(v[r * 8 + 5]), "+v"(v[r * 8 + 6]), "+v"(v[r * 8 + 7]));
     }
@@ -390,28 +392,37 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     const bool stored = live && !(intra && my_cnt == 0);
     const bool clamped = !(intra && dc_only);
 
+    // copy_block[_dc] / add_block[_dc], player.cpp:1151-1236, two pixels per instruction: residual pairs come out
+    // of the 32-bit registers by byte permutes (which also apply the >> 8), prediction bytes are widened the same
+    // way, then packed 16-bit add, max 0, min 248 (PIN, player.cpp:183-236) and one permute back to four bytes
+    typedef short pk16 __attribute__((ext_vector_type(2)));
+    auto pair = [](int hi, int lo) {  // (hi + 128) >> 8 : (lo + 128) >> 8 as two int16
+        return __builtin_bit_cast(pk16, __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x06050201u));
+    };
+    auto widen = [](uint32_t p, bool upper) {  // bytes 0, 1 (or 2, 3) of p as two uint16
+        return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(0u, p, upper ? 0x0C030C02u : 0x0C010C00u));
+    };
+    const pk16 zero = {0, 0}, top = {248, 248};
+    uint32_t flat4 = (uint32_t)(v[0] >> 8);  // intra DC-only block: replicated exactly as copy_block_dc does, unclamped and
+    flat4 |= flat4 << 8;                      // unmasked (player.cpp:1175-1187)
+    flat4 |= flat4 << 16;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint32_t p_lo = pr_lo[r], p_hi = pr_hi[r];
-        // copy_block[_dc] / add_block[_dc], player.cpp:1151-1236
-        uint32_t lo, hi;
-        if (my_cnt == 0) {  // prediction only (skipped macroblock, or block without coefficients)
-            lo = p_lo;
-            hi = p_hi;
-        } else if (!clamped) {
-            uint32_t w = (uint32_t)v[0];
-            w |= w << 8;
-            w |= w << 16;
-            lo = hi = w;
-        } else {
-            const int* q = v + r * 8;
-            lo = (uint32_t)clampi(q[0] + (int)(p_lo & 0xFF), 0, 248) | ((uint32_t)clampi(q[1] + (int)((p_lo >> 8) & 0xFF), 0, 248) << 8) |
-                 ((uint32_t)clampi(q[2] + (int)((p_lo >> 16) & 0xFF), 0, 248) << 16) |
-                 ((uint32_t)clampi(q[3] + (int)(p_lo >> 24), 0, 248) << 24);
-            hi = (uint32_t)clampi(q[4] + (int)(p_hi & 0xFF), 0, 248) | ((uint32_t)clampi(q[5] + (int)((p_hi >> 8) & 0xFF), 0, 248) << 8) |
-                 ((uint32_t)clampi(q[6] + (int)((p_hi >> 16) & 0xFF), 0, 248) << 16) |
-                 ((uint32_t)clampi(q[7] + (int)(p_hi >> 24), 0, 248) << 24);
+        const int* q = v + r * 8;
+        uint32_t w[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t pp = h ? p_hi : p_lo;
+            pk16 a = pair(q[4 * h + 1], q[4 * h]) + widen(pp, false);
+            pk16 b = pair(q[4 * h + 3], q[4 * h + 2]) + widen(pp, true);
+            a = __builtin_elementwise_min(__builtin_elementwise_max(a, zero), top);
+            b = __builtin_elementwise_min(__builtin_elementwise_max(b, zero), top);
+            w[h] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 0x06040200u);
         }
+        // prediction only (skipped macroblock, block without coefficients) / intra DC-only replica / the clamped sum
+        const uint32_t lo = my_cnt == 0 ? p_lo : (clamped ? w[0] : flat4);
+        const uint32_t hi = my_cnt == 0 ? p_hi : (clamped ? w[1] : flat4);
         if (stored)
             *reinterpret_cast<uint2*>(cur + dst0 + r * kStride) = make_uint2(lo, hi);
     }
