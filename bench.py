@@ -292,7 +292,7 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
     # ingest included: every step uploads the batch from host memory again (staging copy, H2D on the copy stream
     # into the bitstream buffer the running decode does not read) and decodes it; upload n+1 overlaps decode n
     ingest = None
-    if want_serial:
+    if want_serial and not args.timed_only:
         prep = dec.prepare_upload(streams)
         isteps = max(4, min(steps, 20))
         for _ in range(2):
@@ -317,7 +317,9 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
                           "decode of step n"}
 
     serial_ms = None
-    if want_serial:
+    if want_serial and args.timed_only:
+        serial_ms = [float(x) for x in stage_ms]
+    elif want_serial:
         # outside the timed region: the same stages one call at a time (no overlap between calls), for
         # the uncontended per-kernel figures quoted next to the timed-region ones
         dec.set_timing(True)
@@ -505,6 +507,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=5.0, help="wall-time target of the CPU baseline leg")
     ap.add_argument("--no-overlap", action="store_true", help="synchronise after every step (no cross-step pipelining)")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="profiling aid: skip the ingest and one-call-at-a-time legs so that (nearly) every kernel launch of the "
+                         "process belongs to the timed region (serial_* fields then repeat the timed-region figures)")
     return ap.parse_args(argv)
 
 

@@ -4,10 +4,14 @@
 # --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ).  Every pass is bounded by `timeout`.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$1; mkdir -p $out
-timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o pipelined -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/bench_pipelined.log 2>&1
-timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o serial -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-overlap > $out/bench_serial.log 2>&1
+# --timed-only + 200 steps: 2400 of the 2470 k_recon launches of the process belong to the timed region, so the
+# average rocprofv3 reports is the one bench.py measures with HIP events (roofline.avg_launch_ms)
+B="python bench.py --steps 200 --warmup 3 --no-cpu-baseline --no-fixed-batch --no-other-workloads --timed-only"
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o pipelined -- $B > $out/bench_pipelined.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o serial -- $B --no-overlap > $out/bench_serial.log 2>&1
+S="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fixed-batch --no-other-workloads --no-overlap"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 90 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap > /dev/null 2>&1
+  timeout 120 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -o p -- $S > /dev/null 2>&1
 done
-timeout 90 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out/pmc_SQ -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap > /dev/null 2>&1
+timeout 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out/pmc_SQ -o p -- $S > /dev/null 2>&1
 grep "^{" $out/bench_pipelined.log | cut -c1-200; ls $out
