@@ -26,39 +26,41 @@ namespace efx {
 namespace {
 
 
-// one 8-point pass of the reference's scaled integer IDCT (player.cpp:938-995).
+__device__ inline int rnd8(int x) { return (x + 128) >> 8; }  // the reference's "(... + 128) >> 8" rounding points
+
+// One 8-point pass of the reference's scaled integer IDCT (player.cpp:938-995): the same products
+// and the same rounding points (integer sums are associative, so only those matter for the bits),
+// written as an even / odd decomposition.
 // The products use the full-rate 24-bit multiplier (v_mul_i32_i24 / v_mad_i32_i24; a 32-bit
 // v_mul_lo_u32 issues at quarter rate): every multiplied operand is a combination of AC
-// coefficients only -- the DC term v0 enters through x1 / x3 and is never multiplied -- and AC
-// coefficients are clamped to +-2048 and scaled by a premultiplier <= 62, which bounds the operands
-// by 2^19 in the column pass and 2^22.5 in the row pass (L1 norm of the linear map).  The low 32
-// bits of the 48-bit product equal the reference's wrapped 32-bit product.
+// coefficients only -- the DC term v0 enters through dc_sum / dc_dif and is never multiplied --
+// and AC coefficients are clamped to +-2048 and scaled by a premultiplier <= 62, which bounds the
+// operands by 2^19 in the column pass and 2^22.5 in the row pass (L1 norm of the linear map).  The
+// low 32 bits of the 48-bit product equal the reference's wrapped 32-bit product.
 __device__ inline void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v5, int& v6, int& v7)
 {
-    int b3 = v2 + v6;
-    int b4 = v5 - v3;
-    int t1 = v1 + v7;
-    int t2 = v3 + v5;
-    int b6 = v1 - v7;
-    int b7 = t1 + t2;
-    int x4 = ((__mul24(b6, 473) - __mul24(b4, 196) + 128) >> 8) - b7;
-    int x0 = x4 - ((__mul24(t1 - t2, 362) + 128) >> 8);
-    int x1 = v0 - v4;
-    int x2 = ((__mul24(v2 - v6, 362) + 128) >> 8) - b3;
-    int x3 = v0 + v4;
-    int y3 = x1 + x2;
-    int y4 = x3 + b3;
-    int y5 = x1 - x2;
-    int y6 = x3 - b3;
-    int y7 = -x0 - ((__mul24(b4, 473) + __mul24(b6, 196) + 128) >> 8);
-    v0 = b7 + y4;
-    v1 = x4 + y3;
-    v2 = y5 - x0;
-    v3 = y6 - y7;
-    v4 = y6 + y7;
-    v5 = x0 + y5;
-    v6 = y3 - x4;
-    v7 = y4 - b7;
+    // even half: inputs 0, 4 as sum / difference; inputs 2, 6 through one rotation (362 / 256)
+    const int dc_sum = v0 + v4, dc_dif = v0 - v4;
+    const int c_sum = v2 + v6;
+    const int c_rot = rnd8(__mul24(v2 - v6, 362)) - c_sum;
+    const int even0 = dc_sum + c_sum, even3 = dc_sum - c_sum;
+    const int even1 = dc_dif + c_rot, even2 = dc_dif - c_rot;
+    // odd half: inputs 1, 7 and 3, 5 as sums and differences, three rotations (473, 196, 362 over 256)
+    const int p17 = v1 + v7, m17 = v1 - v7;
+    const int p35 = v3 + v5, m53 = v5 - v3;
+    const int odd_all = p17 + p35;
+    const int odd_a = rnd8(__mul24(m17, 473) - __mul24(m53, 196)) - odd_all;
+    const int odd_b = odd_a - rnd8(__mul24(p17 - p35, 362));
+    const int odd_c = -odd_b - rnd8(__mul24(m53, 473) + __mul24(m17, 196));
+    // output butterflies
+    v0 = even0 + odd_all;
+    v7 = even0 - odd_all;
+    v1 = even1 + odd_a;
+    v6 = even1 - odd_a;
+    v2 = even2 - odd_b;
+    v5 = even2 + odd_b;
+    v3 = even3 - odd_c;
+    v4 = even3 + odd_c;
 }
 
 __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
