@@ -229,6 +229,29 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
             return bail(EFX_ERR_DEVICE);
         ctx->own_stream = true;
     }
+    {
+        // The parse kernel is a few thousand long-running waves: give it the higher priority so its workgroups are
+        // placed as soon as the reconstruction kernels of the previous call free a slot.
+        // The runtime creates a stream's hardware queue at its first launch, and queues are dealt onto the
+        // command processor's pipes in creation order: left to first use (reconstruction stream, first parse stream,
+        // copy stream, and the second parse stream only at the second decode) the second parse stream ends up
+        // taking turns with the reconstruction stream instead of running beside it -- 2.2 instead of 1.6 ms per step
+        // (measured on the first context of a process, tools/exp/overlap_probe.py).  So every queue is instantiated
+        // here, in this order, by an empty launch.
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess)
+            return bail(EFX_ERR_DEVICE);
+        for (auto& ps : ctx->parse_streams)
+            if (hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, hi) != hipSuccess)
+                return bail(EFX_ERR_DEVICE);
+        if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess)
+            return bail(EFX_ERR_DEVICE);
+        for (hipStream_t st : {ctx->stream, ctx->parse_streams[0], ctx->parse_streams[1], ctx->copy_stream}) {
+            hipLaunchKernelGGL(k_fill, dim3(1), dim3(64), 0, st, (uint32_t*)nullptr, 0u, (size_t)0);
+            if (hipStreamSynchronize(st) != hipSuccess)
+                return bail(EFX_ERR_DEVICE);
+        }
+    }
     const size_t n = (size_t)cfg->max_streams, P = (size_t)cfg->max_pictures, D = (size_t)ctx->cfg.ring_depth;
     ctx->es_cap = ctx->cfg.max_stream_bytes + n * (kEsTailBytes + 32) + kEsGuardBytes;
     ctx->es_cap = (ctx->es_cap + 255) & ~(size_t)255;
@@ -241,7 +264,6 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     };
     A(dalloc(&ctx->d_tables, 1));
     A(dalloc(&ctx->d_state, n));
-    A(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     for (auto& u : ctx->up) {
         A(dalloc(&u.d_es, ctx->es_cap));
         A(dalloc(&u.d_stream_off, n + 1));
@@ -266,14 +288,6 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         A(dalloc(&sl.d_slice_base, n * P + 1));
         A(dalloc(&sl.d_descs, n * P * kMaxSlicesPerPicture));
         A(dalloc(&sl.d_call_pos, 2 * n));
-    }
-    {
-        // the parse kernel is a few thousand long-running waves: give it the higher priority so its
-        // workgroups are placed as soon as the reconstruction kernels of the previous call free a slot
-        int lo = 0, hi = 0;
-        A(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        for (auto& ps : ctx->parse_streams)
-            A(hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, hi));
     }
     A(dalloc(&ctx->d_frames, n * D * kFrameBytes + 8192));  // slack: k_recon's window rows may over-read the last frame
     A(dalloc(&ctx->d_video[0], 1));

@@ -269,9 +269,9 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     // is used -- a wave is alive for as many memory round trips as it makes one after the other, and with
     // one load per loop trip the entries alone cost it three (-5.5 % per launch).
     constexpr int kPerRound = 3;
-    for (uint32_t i0 = lane; i0 < total + lane; i0 += 64 * kPerRound) {  // (uniform trip count: i0 - lane < total)
-        int own[kPerRound];
-        uint32_t ent[kPerRound];
+    int own[kPerRound];
+    uint32_t ent[kPerRound];
+    auto fetch = [&](uint32_t i0) {
 #pragma unroll
         for (int k = 0; k < kPerRound; k++) {
             const uint32_t i = i0 + 64 * k;
@@ -280,8 +280,12 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             for (int step = 32; step > 0; step >>= 1)
                 L += (uint32_t)s_pre[L + step] <= i ? step : 0;
             own[k] = L;
-            ent[k] = i < total ? coefs[s_base[L] + (i - (uint32_t)s_pre[L])] : 0u;
+            // (always a load, beyond the end from entry 0: the compiler then knows how many loads are in flight and
+            // the prediction below waits for the windows only)
+            ent[k] = coefs[i < total ? s_base[L] + (i - (uint32_t)s_pre[L]) : 0u];
         }
+    };
+    auto apply = [&](uint32_t i0) {
 #pragma unroll
         for (int k = 0; k < kPerRound; k++) {
             if (i0 + 64 * k >= total)
@@ -311,21 +315,12 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
                 cfh[L * kLaneHalfwords + (t & 63)] = (int16_t)val;
             }
         }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int dc_raw = s_dc[lane];   // intra DC value (entry at scan position 0)
-    const bool zf = s_zf[lane] != 0;  // an entry sits at scan position 0
+    };
+    fetch(lane);  // (also when the wave has no entry at all: the same three loads in flight on every path)
 
-    // A block whose only coefficient sits at scan position 0 takes the reference's "n == 1"
-    // shortcut (player.cpp:1133-1140): dc = b[0] >> 8 (floor), no IDCT; for intra blocks the
-    // byte is replicated WITHOUT the 0..248 clamp (copy_block_dc, player.cpp:1175-1187).
-    const bool dc_only = my_cnt == 1 && zf;
-
-    // ---- 2-D IDCT in registers (idct(), player.cpp:922-996) --------------------------------------------
-    // ---- prediction of the 8 rows first: the 27 window registers die here, before the 64 IDCT
-    // registers come alive ---------------------------------------------------------------------------
+    // ---- prediction of the 8 rows, in the shadow of the entry loads just issued (a wave's life is its chain of
+    // memory round trips: record -> owner search -> entries; this arithmetic needs only the windows, which were
+    // requested before) -- the 27 window registers die here, before the 64 IDCT registers come alive -----------
     uint32_t pr_lo[8], pr_hi[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -355,6 +350,28 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         pr_hi[r] = p_hi;
     }
 
+
+    if (total) {
+        for (uint32_t i0 = lane;;) {  // (uniform trip count: i0 - lane < total)
+            apply(i0);
+            i0 += 64 * kPerRound;
+            if (i0 - lane >= total)
+                break;
+            fetch(i0);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int dc_raw = s_dc[lane];   // intra DC value (entry at scan position 0)
+    const bool zf = s_zf[lane] != 0;  // an entry sits at scan position 0
+
+    // A block whose only coefficient sits at scan position 0 takes the reference's "n == 1"
+    // shortcut (player.cpp:1133-1140): dc = b[0] >> 8 (floor), no IDCT; for intra blocks the
+    // byte is replicated WITHOUT the 0..248 clamp (copy_block_dc, player.cpp:1175-1187).
+    const bool dc_only = my_cnt == 1 && zf;
+
+    // ---- 2-D IDCT in registers (idct(), player.cpp:922-996) --------------------------------------------
     // Blocks without entries run the butterflies on zeros (which stay zero).  A dc_only block has its
     // single value X at raster position 0; the butterflies turn that into X at all 64 positions
     // exactly, so clearing X's low byte makes the final (x + 128) >> 8 deliver X >> 8, the shortcut.
