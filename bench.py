@@ -260,9 +260,11 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
     n_i = S * ((P + 11) // 12)
     n_p = S * P - n_i
 
+    # (the timed decoder is created before the gate's: a context's streams get their hardware queues at creation, and
+    # the first context of a process is dealt the pipes in the order efx_create asks for)
+    dec = job.make_decoder(S, P, 2, es_bytes + 64 * S)
     got = gate_against_golden(job.make_decoder, streams, ids, golden, P, f"{workload}, before timing")
 
-    dec = job.make_decoder(S, P, 2, es_bytes + 64 * S)
     dec.upload(streams, 0)  # bitstreams resident in HBM from here on
     dec.set_timing(True)
     elapsed = timed_region(job, dec, steps, warmup, overlap=not args.no_overlap)

@@ -25,4 +25,5 @@ def run(tag, **kw):
     print(tag, 'step %.3f ms' % (dt * 1e3), 'stages index %.3f parse %.3f recon %.3f' % (t.index_ms, t.parse_ms, t.recon_ms))
     dec.close()
 tot = sum(x.size for x in blobs)
-run('first ctx order=%s' % os.environ.get('EFX_STREAM_ORDER'), max_stream_bytes=tot + 65536)
+for k in range(5):
+    run('ctx %d' % k, max_stream_bytes=tot + 65536)
