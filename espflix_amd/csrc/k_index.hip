@@ -372,7 +372,16 @@ __global__ __launch_bounds__(256) void k_slice_emit(const PicInfo* __restrict__ 
     d.stream = (uint32_t)s;
     d.pic_code_flags = (uint32_t)p | ((st.len_code & 0xFF) << 8) | ((uint32_t)pi.type << 16) | ((uint32_t)pi.full_pel << 18) |
                        ((uint32_t)pi.r_size << 19) | ((uint32_t)pi.custom_q << 22);
-    d.reserved[0] = d.reserved[1] = 0;
+    // a slice that runs on past the first macroblock of the next slice (damaged streams only) stops there
+    uint32_t limit = kMbCount;
+    if (k + 1 < (int)pi.n_slices) {
+        const uint32_t code = st.len_code & 0xFF;
+        const uint32_t next = slices_tmp[(size_t)s * max_pictures * kMaxSlicesPerPicture + pi.first_slice + k + 1].len_code & 0xFF;
+        if (next > code && (next - 1) * kMbW < (uint32_t)kMbCount)
+            limit = (next - 1) * kMbW;
+    }
+    d.mb_limit = limit;
+    d.reserved = 0;
     descs[slice_base[i] + k] = d;
 }
 

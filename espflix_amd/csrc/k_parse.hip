@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
     const bool custom_q = (d.pic_code_flags >> 22) & 1;  // recorded per macroblock for k_recon's dequantiser
 
     MbRec* recs = mbrecs + ((size_t)d.stream * max_pictures + pic) * kMbCount;
+    const int mb_limit = (int)d.mb_limit;
     uint32_t coef_idx = d.es_off * kCoefsPerEsByte;
     // An entry costs at least 3 bits of slice data, so a slice never outgrows its own region of
     // kCoefsPerEsByte entries per byte; a damaged slice that runs on is parked on its last slot.
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                 dc_y = dc_cr = dc_cb = 128;  // reset_predictors(), player.cpp:1280-1281
                 mv_h = mv_v = 0;
             }
-            while (inc > 1 && mb_addr + 1 < kMbCount) {  // skipped macroblocks copy the reference (1283-1288)
+            while (inc > 1 && mb_addr + 1 < mb_limit) {  // skipped macroblocks copy the reference (1283-1288)
                 mb_addr++;
                 MbRec r;
                 r.coef_base = coef_idx;
@@ -327,8 +328,9 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
             }
             mb_addr++;
         }
-        if (mb_addr >= kMbCount) {
-            st |= EFX_STREAM_MB_OVERRUN;
+        if (mb_addr >= mb_limit) {  // past the picture, or into the macroblocks of the next slice (SliceDesc::mb_limit)
+            if (mb_limit == kMbCount)
+                st |= EFX_STREAM_MB_OVERRUN;
             break;
         }
 

@@ -144,3 +144,28 @@ def test_epoch_tags_wrap_under_back_to_back_decodes(efx):
             assert np.array_equal(dec.frame_hashes(), want), i
             assert all(dec.stream_status(k) == 0 and dec.picture_count(k) == 4 for k in range(3))
     dec.close()
+
+
+def test_damaged_slice_that_runs_on_into_the_next_row(efx):
+    """A bit flip can leave a slice syntactically valid but longer: it then decodes macroblocks of the row below,
+    which the next slice decodes as well.  The reference (and the oracle) decode in bitstream order, so the later
+    slice's macroblocks stay; here the two slices are parsed by two lanes at once, and the earlier one stops at
+    the first macroblock of the later one (SliceDesc::mb_limit).  Two frame buffers, as in the reference:
+    what a damaged slice leaves untouched is the picture before last."""
+    from espflix_amd import gen
+    b = gen.Batch(0, 8, 6)
+    flips = [(7, 435, 2), (5, 6106, 4), (3, 7699, 3), (0, 41536, 3), (2, 22544, 7), (5, 8489, 5), (6, 11012, 3)]
+    streams = []
+    for k, pos, bit in flips:
+        es = b.es(k).copy()
+        es[pos] ^= 1 << bit
+        streams.append(es)
+    dec = efx.Decoder(len(streams), 8, 2, max_stream_bytes=sum(s.size for s in streams) + 4096)
+    dec.upload(streams, efx.FORMAT_ES)
+    dec.decode()
+    h = dec.frame_hashes()
+    for i, es in enumerate(streams):
+        n, oh, _, _ = oracle.decode(es, 0, True)
+        assert dec.picture_count(i) == n == 6, flips[i]
+        assert [int(h[i, dec.picture_slot(p, i)]) for p in (n - 2, n - 1)] == [int(x) for x in oh[-2:]], flips[i]
+    dec.close()
