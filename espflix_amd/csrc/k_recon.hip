@@ -269,9 +269,9 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     // is used -- a wave is alive for as many memory round trips as it makes one after the other, and with
     // one load per loop trip the entries alone cost it three (-5.5 % per launch).
     constexpr int kPerRound = 3;
-    int own[kPerRound];
-    uint32_t ent[kPerRound];
-    auto fetch = [&](uint32_t i0) {
+    int own[kPerRound], own_next[kPerRound];
+    uint32_t ent[kPerRound], ent_next[kPerRound];
+    auto fetch = [&](uint32_t i0, int (&own)[kPerRound], uint32_t (&ent)[kPerRound]) {
 #pragma unroll
         for (int k = 0; k < kPerRound; k++) {
             const uint32_t i = i0 + 64 * k;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             }
         }
     };
-    fetch(lane);  // (also when the wave has no entry at all: the same three loads in flight on every path)
+    fetch(lane, own, ent);  // (also when the wave has no entry at all: the same three loads in flight on every path)
 
     // ---- prediction of the 8 rows, in the shadow of the entry loads just issued (a wave's life is its chain of
     // memory round trips: record -> owner search -> entries; this arithmetic needs only the windows, which were
@@ -353,11 +353,19 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
 
     if (total) {
         for (uint32_t i0 = lane;;) {  // (uniform trip count: i0 - lane < total)
+            // the next round's owners are searched and its entries requested before this round's are applied
+            const bool more = i0 - lane + 64 * kPerRound < total;
+            if (more)
+                fetch(i0 + 64 * kPerRound, own_next, ent_next);
             apply(i0);
-            i0 += 64 * kPerRound;
-            if (i0 - lane >= total)
+            if (!more)
                 break;
-            fetch(i0);
+            i0 += 64 * kPerRound;
+#pragma unroll
+            for (int k = 0; k < kPerRound; k++) {
+                own[k] = own_next[k];
+                ent[k] = ent_next[k];
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
