@@ -271,6 +271,7 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
     t = dec.timing()
     stage_ms = np.array([t.index_ms, t.parse_ms, t.recon_ms])
     timed_calls = t.timed_calls
+    groups = max(1, int(getattr(t, "groups", 1)))  # a call runs as this many groups of streams, one launch set each
 
     # the double buffer now holds pictures P-2 and P-1 of every stream: compare them with the reference again
     assert t.pictures == S * P, (t.pictures, S * P)
@@ -333,7 +334,7 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
     with np.errstate(over="ignore"):
         csum = int(np.bitwise_xor.reduce(chains * edist.GOLDEN)) if chains.size else 0
     return {"workload": workload, "S": S, "P": P, "es_bytes": es_bytes, "n_i": n_i, "n_p": n_p, "elapsed": elapsed,
-            "stage_ms": stage_ms, "serial_ms": serial_ms, "timed_calls": timed_calls, "n_coefs": int(n_coefs),
+            "stage_ms": stage_ms, "serial_ms": serial_ms, "timed_calls": timed_calls, "groups": groups, "n_coefs": int(n_coefs),
             "gen_seconds": t_gen, "batch0": batches[0][1], "ingest": ingest, "job_pictures": totals[0], "job_es_bytes": totals[1],
             "checksum": csum, "streams_checked": int(chains.size), "first_id": int(ids[0]), "last_id": int(ids[-1])}
 
@@ -438,8 +439,10 @@ def run(job, args):
     # The roofline object is k_recon's: it is the kernel that moves SURVEY 8d's algorithmic bytes (the
     # frames); k_parse, which only reads the bitstream and writes 4 B per coefficient + 16 B per
     # macroblock, is reported next to it.
-    alg_launch = alg / P
-    dur_s = stage_ms[2] / 1e3 / P
+    # libefx runs a call as G groups of streams, one k_recon launch per group and picture index: P * G launches per step
+    G = r["groups"]
+    alg_launch = alg / (P * G)
+    dur_s = stage_ms[2] / 1e3 / (P * G)
     achieved = alg_launch / dur_s / 1e9
     parse_bytes = r["es_bytes"] + 4 * r["n_coefs"] + 16 * S * P * 264
     traffic, traffic_src = pmc_traffic("efx::k_recon", S, P)
@@ -457,7 +460,8 @@ def run(job, args):
         "roofline": {"bound": "hbm", "limiter": "dependent steps of a wave's life at 16 waves per CU, VALU ~3/4 busy (DESIGN.md section 6)", "kernel": names[2], "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": alg_launch, "avg_launch_ms": dur_s * 1e3,
+                     "algorithmic_bytes_per_launch": alg_launch, "avg_launch_ms": dur_s * 1e3, "launches_per_step": P * G,
+                     "streams_per_launch": S // G,
                      "whole_step_achieved_GBs": alg / (r["elapsed"] / steps) / 1e9,
                      "whole_step_frac": alg / (r["elapsed"] / steps) / 1e9 / HBM_PEAK_GBS,
                      "stage_ms": dict(zip(names, [float(x) for x in stage_ms])),
@@ -466,10 +470,10 @@ def run(job, args):
                              "later steps shares the GPU with k_recon; serial_* = the same stages one call at a "
                              "time, measured after the timed region",
                      "serial_stage_ms": dict(zip(names, [float(x) for x in serial_ms])),
-                     "serial_frac": alg / P / (serial_ms[2] / P / 1e3) / 1e9 / HBM_PEAK_GBS,
-                     "k_parse": {"algorithmic_bytes_per_launch": parse_bytes, "avg_launch_ms": float(stage_ms[1]),
+                     "serial_frac": alg / (serial_ms[2] / 1e3) / 1e9 / HBM_PEAK_GBS,
+                     "k_parse": {"algorithmic_bytes_per_launch": parse_bytes / G, "avg_launch_ms": float(stage_ms[1]) / G,
                                  "achieved": parse_bytes / (stage_ms[1] / 1e3) / 1e9,
-                                 "serial_launch_ms": float(serial_ms[1]), "traffic": ptraffic,
+                                 "serial_launch_ms": float(serial_ms[1]) / G, "traffic": ptraffic,
                                  "bound": "serial symbol chains (VALU issue), not bandwidth"}},
         "parity_gate": {"reference": "tests/golden/bench_gop12.u64 (unmodified reference decoder, tests/golden/make_bench_golden.py)",
                         "streams_checked": r["streams_checked"], "pictures_checked_per_stream": P,

@@ -74,7 +74,8 @@ class _IdxRec(C.Structure):
 class _Timing(C.Structure):
     _fields_ = [("index_ms", C.c_float), ("parse_ms", C.c_float), ("recon_ms", C.c_float), ("total_ms", C.c_float),
                 ("pictures", C.c_uint64), ("slices", C.c_uint64), ("coefficients", C.c_uint64), ("es_bytes", C.c_uint64),
-                ("demux_ms", C.c_float), ("timed_calls", C.c_uint32), ("ts_bytes", C.c_uint64)]
+                ("demux_ms", C.c_float), ("timed_calls", C.c_uint32), ("ts_bytes", C.c_uint64), ("groups", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 # every symbol include/efx.h declares: (name, restype, argtypes)
@@ -198,6 +199,7 @@ class Timing:
     demux_ms: float = 0.0
     ts_bytes: int = 0
     timed_calls: int = 0
+    groups: int = 1  # a call runs as this many groups of streams (stage times are sums over them)
 
 
 class DeviceBuffer:
@@ -423,4 +425,4 @@ class Decoder:
         t = _Timing()
         _check(self._ctx, self._lib.efx_get_timing(self._ctx, C.byref(t)))
         return Timing(t.index_ms, t.parse_ms, t.recon_ms, t.total_ms, t.pictures, t.slices, t.coefficients, t.es_bytes,
-                      t.demux_ms, t.ts_bytes, t.timed_calls)
+                      t.demux_ms, t.ts_bytes, t.timed_calls, max(1, t.groups))

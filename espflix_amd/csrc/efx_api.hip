@@ -24,14 +24,14 @@ __global__ void k_demux_audio(const uint8_t*, const uint64_t*, const uint32_t*, 
 __global__ void k_ts_sequences(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, PesEntry*, IdxInfo*);
 __global__ void k_idx_bins(const PesEntry*, const uint32_t*, const IdxInfo*, uint32_t, uint32_t*, size_t);
 __global__ void k_index(const uint8_t*, const uint64_t*, int, PicInfo*, SliceTmp*, uint32_t*, uint32_t*, uint32_t*,
-                        const uint32_t*, const PesEntry*, const uint32_t*, const uint32_t*, int64_t*, int);
-__global__ void k_advance(StreamState*, const uint32_t*, int64_t*, const PesEntry*, const uint32_t*, const uint32_t*, int, int, int32_t*);
+                        const uint32_t*, const PesEntry*, const uint32_t*, const uint32_t*, int64_t*, int, int);
+__global__ void k_advance(StreamState*, const uint32_t*, int64_t*, const PesEntry*, const uint32_t*, const uint32_t*, int, int, int, int32_t*);
 __global__ void k_slice_scan(const PicInfo*, const uint32_t*, int, int, const uint32_t*, uint32_t*, DecodeCounters*);
 __global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, const uint64_t*, const uint32_t*, int, int,
                              const uint32_t*, SliceDesc*);
 __global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const ParseTables*, MbRec*, uint32_t*, uint32_t*,
                         int, int);
-__global__ void k_recon(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, const int32_t*, int);
+__global__ void k_recon(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, const int32_t*, int, int);
 __global__ void k_frame_hash(const uint8_t*, int, uint64_t*);
 __global__ void k_fill(uint32_t*, uint32_t, size_t);
 __global__ void k_composite(const uint8_t*, const VideoTables*, const VideoLineTemplates*, FieldArgs, uint16_t*);
@@ -41,9 +41,21 @@ __global__ void k_sbc(const uint8_t*, size_t, int, int, SbcState*, const SbcTabl
 
 using namespace efx;
 
-constexpr int kParseStreams = 2;  // parse halves in flight at once (latency-bound kernels: two overlap well)
+#ifndef EFX_PARSE_STREAMS
+#define EFX_PARSE_STREAMS 2
+#endif
+#ifndef EFX_SLOTS
+#define EFX_SLOTS 3
+#endif
+constexpr int kParseStreams = EFX_PARSE_STREAMS;  // parse halves in flight at once (latency-bound kernels: two overlap well)
+constexpr int kMaxGroups = 8;       // an efx_decode call runs as up to this many groups of streams, one after the other
+#ifndef EFX_GROUP_STREAMS
+#define EFX_GROUP_STREAMS 512
+#endif
+constexpr int kGroupStreams = EFX_GROUP_STREAMS;
+constexpr double kGroupMaxSliceBytes = 640;  // ... when the slices are short (see efx_decode_from)  // ... of about this many streams each (see efx_decode_from)
 constexpr int kTimingRing = 64;   // efx_decode calls whose stage times efx_get_timing can average
-constexpr int kSlots = 3;         // parse -> recon hand-over buffer sets (one being reconstructed + two being parsed)
+constexpr int kSlots = EFX_SLOTS;         // parse -> recon hand-over buffer sets (one being reconstructed + two being parsed)
 constexpr int kUploads = 2;       // bitstream buffers: one being decoded, one being filled
 
 struct efx_ctx {
@@ -80,7 +92,7 @@ struct efx_ctx {
         size_t es_used = 0, ts_bytes = 0;
         bool ts_input = false, valid = false;
         hipEvent_t uploaded = nullptr;                                  // H2D (+ k_demux) done, copy stream
-        hipEvent_t last_read[kParseStreams] = {nullptr, nullptr};       // newest parse half that reads this buffer
+        hipEvent_t last_read[kParseStreams] = {};       // newest parse half that reads this buffer
         hipEvent_t ev_demux[2] = {nullptr, nullptr};
         bool demux_timed = false;
     } up[kUploads];
@@ -105,7 +117,7 @@ struct efx_ctx {
     struct Slot {
         uint32_t* d_pic_count = nullptr;
         uint32_t* d_status = nullptr;
-        DecodeCounters* d_counters = nullptr;
+        DecodeCounters* d_counters = nullptr;  // kMaxGroups of them: one per group of a call
         MbRec* d_mbrecs = nullptr;
         uint32_t* d_coefs = nullptr;
         // index / slice-list scratch of this call (per slot: two parse halves run concurrently)
@@ -125,11 +137,18 @@ struct efx_ctx {
     struct TimingEvents {
         hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // parse start, index end, parse end, recon end, recon start
     };
-    std::vector<TimingEvents> timing_ring;  // kTimingRing sets, created by efx_set_timing
+    std::vector<TimingEvents> timing_ring;  // kTimingRing x kMaxGroups sets, created by efx_set_timing
     uint64_t timed_calls = 0;               // calls recorded since timing was (re-)enabled
-    int cur = 0;        // slot of the most recent efx_decode
-    uint64_t calls = 0;
-    hipStream_t parse_streams[kParseStreams] = {nullptr, nullptr};
+    struct Group {
+        int slot, first, count;  // hand-over slot, streams [first, first + count)
+    };
+    Group groups[kMaxGroups];  // of the most recent efx_decode
+    int n_groups = 0;
+    int last_upload = 0;       // batch the most recent efx_decode read
+    uint64_t subcalls = 0;     // groups launched so far: group k uses slot k % kSlots and parse stream k % kParseStreams
+    uint8_t timing_groups[kTimingRing] = {};
+    uint32_t* h_hint = nullptr;  // pinned: {slices, streams} of the first group of a recent call (copied back asynchronously)
+    hipStream_t parse_streams[kParseStreams] = {};
     VideoTables* d_video[2] = {nullptr, nullptr};  // [0] PAL, [1] NTSC
     VideoLineTemplates* d_video_lines[2] = {nullptr, nullptr};
     SbcTables* d_sbc_tables = nullptr;
@@ -146,6 +165,25 @@ struct efx_ctx {
 };
 
 namespace {
+
+// An efx_decode call may run as G groups of about kGroupStreams streams, one after the other: each group is a complete
+// parse half + reconstruction half with its own hand-over slot, so that the parse half of the next group (and of the
+// one after) runs beside the reconstruction of this one.  Streams are independent, so the result does not depend on
+// G; the granularity of the pipeline does.  With short slices (the 12-slice pictures of SURVEY 8d: 315 bytes per
+// slice, parse half 1.1 ms whatever the batch) two groups of 512 streams take 1.60 ms where one of 1024 takes 1.70;
+// with the 1.2 kB slices of ffmpeg's 5-slice pictures a parse half is 2.5 ms long however few streams it holds, and
+// halving the streams per parse half halves the throughput.  So the call is split only when the previous call's slices
+// were short: k_slice_scan's count comes back through a pinned word, read here without waiting for it.
+int group_count(int n_streams)
+{
+    int g = (n_streams + kGroupStreams / 2) / kGroupStreams;
+    return g < 1 ? 1 : (g > kMaxGroups ? kMaxGroups : g);
+}
+// streams [first, end) of group g: boundaries on multiples of 8, so that a stream's workgroups stay on one XCD
+int group_first(int n_streams, int groups, int g)
+{
+    return g >= groups ? n_streams : (int)(((int64_t)n_streams * g / groups) & ~7);
+}
 
 int fail(efx_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
 {
@@ -246,7 +284,11 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
                 return bail(EFX_ERR_DEVICE);
         if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess)
             return bail(EFX_ERR_DEVICE);
-        for (hipStream_t st : {ctx->stream, ctx->parse_streams[0], ctx->parse_streams[1], ctx->copy_stream}) {
+        std::vector<hipStream_t> order = {ctx->stream};
+        for (auto ps : ctx->parse_streams)
+            order.push_back(ps);
+        order.push_back(ctx->copy_stream);
+        for (hipStream_t st : order) {
             hipLaunchKernelGGL(k_fill, dim3(1), dim3(64), 0, st, (uint32_t*)nullptr, 0u, (size_t)0);
             if (hipStreamSynchronize(st) != hipSuccess)
                 return bail(EFX_ERR_DEVICE);
@@ -263,6 +305,9 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
             e = r;
     };
     A(dalloc(&ctx->d_tables, 1));
+    A(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_hint), 2 * sizeof(uint32_t), hipHostMallocDefault));
+    if (ctx->h_hint)
+        ctx->h_hint[0] = ctx->h_hint[1] = 0;
     A(dalloc(&ctx->d_state, n));
     for (auto& u : ctx->up) {
         A(dalloc(&u.d_es, ctx->es_cap));
@@ -279,7 +324,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     for (auto& sl : ctx->slot) {
         A(dalloc(&sl.d_pic_count, n));
         A(dalloc(&sl.d_status, n));
-        A(dalloc(&sl.d_counters, 1));
+        A(dalloc(&sl.d_counters, kMaxGroups));
         A(dalloc(&sl.d_mbrecs, n * P * kMbCount));
         A(dalloc(&sl.d_coefs, ctx->es_cap * kCoefsPerEsByte));
         A(dalloc(&sl.d_pics, n * P));
@@ -364,8 +409,11 @@ void efx_destroy(efx_ctx* ctx)
             (void)hipHostFree(u.h_es);
         if (u.h_meta)
             (void)hipHostFree(u.h_meta);
-        hipEvent_t evs[] = {u.uploaded, u.last_read[0], u.last_read[1], u.ev_demux[0], u.ev_demux[1]};
+        hipEvent_t evs[] = {u.uploaded, u.ev_demux[0], u.ev_demux[1]};
         for (auto ev : evs)
+            if (ev)
+                (void)hipEventDestroy(ev);
+        for (auto ev : u.last_read)
             if (ev)
                 (void)hipEventDestroy(ev);
     }
@@ -387,6 +435,8 @@ void efx_destroy(efx_ctx* ctx)
         (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream && ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
+    if (ctx->h_hint)
+        (void)hipHostFree(ctx->h_hint);
     delete ctx;
 }
 
@@ -534,7 +584,13 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
     // first, so that a wave's 64 slices have similar bit rates (and the long waves start early)
     for (int i = 0; i < n_streams; i++)
         m_perm[i] = (uint32_t)i;
-    std::stable_sort(m_perm, m_perm + n_streams, [&](uint32_t a, uint32_t b) { return len[a] > len[b]; });
+    {
+        // (sorted inside every group of streams that efx_decode runs as a unit)
+        const int G = group_count(n_streams);
+        for (int g = 0; g < G; g++)
+            std::stable_sort(m_perm + group_first(n_streams, G, g), m_perm + group_first(n_streams, G, g + 1),
+                             [&](uint32_t a, uint32_t b) { return len[a] > len[b]; });
+    }
     EFX_HIP(hipMemcpyAsync(u.d_stream_off, m_off, ((size_t)n_streams + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     EFX_HIP(hipMemcpyAsync(u.d_stream_perm, m_perm, (size_t)n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     u.ts_bytes = 0;
@@ -658,56 +714,75 @@ int efx_decode_from(efx_ctx* ctx, int first_picture)
     if (ctx->cur_up < 0)
         return fail(ctx, EFX_ERR_STATE, "efx_decode: no streams uploaded");
     efx_ctx::Upload& u = ctx->up[ctx->cur_up];
-    const int n = u.n_streams, P = ctx->cfg.max_pictures, D = ctx->cfg.ring_depth;
-    const int pi = (int)(ctx->calls % kParseStreams);
-    hipStream_t sp = ctx->parse_streams[pi], sr = ctx->stream;
-    ctx->cur = (int)(ctx->calls++ % kSlots);
-    efx_ctx::Slot& sl = ctx->slot[ctx->cur];
-    sl.upload = ctx->cur_up;
-
-    // ---- parse half (parse stream): index -> slice list -> VLC parse ---------------------------------------
-    EFX_HIP(hipStreamWaitEvent(sp, u.uploaded, 0));     // the batch is in HBM (H2D and k_demux on the copy stream)
-    EFX_HIP(hipStreamWaitEvent(sp, sl.recon_done, 0));  // the call kSlots back has released this slot
-    // macroblock records carry the epoch that wrote them; recycle the tag space by clearing
-    if (++sl.epoch > 255) {
-        EFX_HIP(hipMemsetAsync(sl.d_mbrecs, 0, (size_t)ctx->cfg.max_streams * P * kMbCount * sizeof(MbRec), sp));
-        sl.epoch = 1;
+    const int n_all = u.n_streams, P = ctx->cfg.max_pictures, D = ctx->cfg.ring_depth;
+    int G = 1;
+    if (group_count(n_all) > 1 && ctx->h_hint) {
+        const uint32_t hint_slices = ctx->h_hint[0], hint_streams = ctx->h_hint[1];
+        if (hint_slices && hint_streams && (double)u.es_used * hint_streams / n_all / hint_slices < kGroupMaxSliceBytes)
+            G = group_count(n_all);
     }
-    efx_ctx::TimingEvents* te = nullptr;
-    if (ctx->timing && !ctx->timing_ring.empty())
-        te = &ctx->timing_ring[ctx->timed_calls++ % kTimingRing];
-    if (te)
-        EFX_HIP(hipEventRecord(te->ev[0], sp));
-    hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, sp, u.d_es, u.d_stream_off, P, sl.d_pics, sl.d_slices_tmp, sl.d_pic_count,
-                       sl.d_status, sl.d_qtab, ctx->d_tables->scan, u.d_pes, u.d_pkt_base, u.d_pes_count,
-                       u.ts_input ? sl.d_pts : nullptr, first_picture);
-    hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, sl.d_pics, sl.d_pic_count, n, P, u.d_stream_perm, sl.d_slice_base,
-                       sl.d_counters);
-    hipLaunchKernelGGL(k_slice_emit, dim3((n * P * kMaxSlicesPerPicture + 255) / 256), dim3(256), 0, sp, sl.d_pics,
-                       sl.d_slices_tmp, sl.d_pic_count, u.d_stream_off, sl.d_slice_base, n, P, u.d_stream_perm, sl.d_descs);
-    if (te)
-        EFX_HIP(hipEventRecord(te->ev[1], sp));
-    const int max_slices = n * P * kMaxSlicesPerPicture;
-    hipLaunchKernelGGL(k_parse, dim3((max_slices + 255) / 256), dim3(256), 0, sp, u.d_es, sl.d_descs, sl.d_counters,
-                       ctx->d_tables, sl.d_mbrecs, sl.d_coefs, sl.d_status, P, sl.epoch);
-    if (te)
-        EFX_HIP(hipEventRecord(te->ev[2], sp));
-    EFX_HIP(hipEventRecord(sl.parse_done, sp));
-    EFX_HIP(hipEventRecord(u.last_read[pi], sp));  // the bitstream buffer is free for the upload after next
+    hipStream_t sr = ctx->stream;
+    int timing_slot = -1;
+    if (ctx->timing && !ctx->timing_ring.empty()) {
+        timing_slot = (int)(ctx->timed_calls++ % kTimingRing);
+        ctx->timing_groups[timing_slot] = (uint8_t)G;
+    }
+    ctx->n_groups = G;
+    ctx->last_upload = ctx->cur_up;
+    for (int g = 0; g < G; g++) {
+        const int s0 = group_first(n_all, G, g), n = group_first(n_all, G, g + 1) - s0;
+        const int pi = (int)(ctx->subcalls % kParseStreams);
+        hipStream_t sp = ctx->parse_streams[pi];
+        const int slot = (int)(ctx->subcalls++ % kSlots);
+        ctx->groups[g] = {slot, s0, n};
+        efx_ctx::Slot& sl = ctx->slot[slot];
+        sl.upload = ctx->cur_up;
+        DecodeCounters* counters = sl.d_counters + g;
 
-    // ---- reconstruction half (context stream): one launch per picture index ------------------------------
-    EFX_HIP(hipStreamWaitEvent(sr, sl.parse_done, 0));
-    if (te)
-        EFX_HIP(hipEventRecord(te->ev[4], sr));
-    // ring positions of this call's pictures; the reconstruction stream orders the calls
-    hipLaunchKernelGGL(k_advance, dim3((n + 255) / 256), dim3(256), 0, sr, ctx->d_state, sl.d_pic_count, u.ts_input ? sl.d_pts : nullptr,
-                       u.d_pes, u.d_pkt_base, u.d_pes_count, n, P, sl.d_call_pos);
-    for (int p = 0; p < P; p++)
-        hipLaunchKernelGGL(k_recon, dim3(n, (kMbCount * 6 + 63) / 64), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs, ctx->d_tables->scan,
-                           sl.d_qtab, ctx->d_frames, P, D, p, sl.d_call_pos, sl.epoch);
-    if (te)
-        EFX_HIP(hipEventRecord(te->ev[3], sr));
-    EFX_HIP(hipEventRecord(sl.recon_done, sr));
+        // ---- parse half (parse stream): index -> slice list -> VLC parse ---------------------------------------
+        EFX_HIP(hipStreamWaitEvent(sp, u.uploaded, 0));     // the batch is in HBM (H2D and k_demux on the copy stream)
+        EFX_HIP(hipStreamWaitEvent(sp, sl.recon_done, 0));  // the group kSlots back has released this slot
+        // macroblock records carry the epoch that wrote them; recycle the tag space by clearing
+        if (++sl.epoch > 255) {
+            EFX_HIP(hipMemsetAsync(sl.d_mbrecs, 0, (size_t)ctx->cfg.max_streams * P * kMbCount * sizeof(MbRec), sp));
+            sl.epoch = 1;
+        }
+        efx_ctx::TimingEvents* te = timing_slot >= 0 ? &ctx->timing_ring[(size_t)timing_slot * kMaxGroups + g] : nullptr;
+        if (te)
+            EFX_HIP(hipEventRecord(te->ev[0], sp));
+        hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, sp, u.d_es, u.d_stream_off, P, sl.d_pics, sl.d_slices_tmp, sl.d_pic_count,
+                           sl.d_status, sl.d_qtab, ctx->d_tables->scan, u.d_pes, u.d_pkt_base, u.d_pes_count,
+                           u.ts_input ? sl.d_pts : nullptr, first_picture, s0);
+        hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, sl.d_pics, sl.d_pic_count, n, P, u.d_stream_perm + s0,
+                           sl.d_slice_base, counters);
+        hipLaunchKernelGGL(k_slice_emit, dim3((n * P * kMaxSlicesPerPicture + 255) / 256), dim3(256), 0, sp, sl.d_pics,
+                           sl.d_slices_tmp, sl.d_pic_count, u.d_stream_off, sl.d_slice_base, n, P, u.d_stream_perm + s0, sl.d_descs);
+        if (g == 0 && ctx->h_hint)
+            EFX_HIP(hipMemcpyAsync(ctx->h_hint, counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, sp));
+        if (te)
+            EFX_HIP(hipEventRecord(te->ev[1], sp));
+        const int max_slices = n * P * kMaxSlicesPerPicture;
+        hipLaunchKernelGGL(k_parse, dim3((max_slices + 255) / 256), dim3(256), 0, sp, u.d_es, sl.d_descs, counters, ctx->d_tables,
+                           sl.d_mbrecs, sl.d_coefs, sl.d_status, P, sl.epoch);
+        if (te)
+            EFX_HIP(hipEventRecord(te->ev[2], sp));
+        EFX_HIP(hipEventRecord(sl.parse_done, sp));
+        EFX_HIP(hipEventRecord(u.last_read[pi], sp));  // the bitstream buffer is free for the upload after next
+
+        // ---- reconstruction half (context stream): one launch per picture index ------------------------------
+        EFX_HIP(hipStreamWaitEvent(sr, sl.parse_done, 0));
+        if (te)
+            EFX_HIP(hipEventRecord(te->ev[4], sr));
+        // ring positions of this call's pictures; the reconstruction stream orders the calls
+        hipLaunchKernelGGL(k_advance, dim3((n + 255) / 256), dim3(256), 0, sr, ctx->d_state, sl.d_pic_count,
+                           u.ts_input ? sl.d_pts : nullptr, u.d_pes, u.d_pkt_base, u.d_pes_count, s0, n, P, sl.d_call_pos);
+        for (int p = 0; p < P; p++)
+            hipLaunchKernelGGL(k_recon, dim3(n, (kMbCount * 6 + 63) / 64), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs,
+                               ctx->d_tables->scan, sl.d_qtab, ctx->d_frames, P, D, p, sl.d_call_pos, sl.epoch, s0);
+        if (te)
+            EFX_HIP(hipEventRecord(te->ev[3], sr));
+        EFX_HIP(hipEventRecord(sl.recon_done, sr));
+    }
     EFX_HIP(hipGetLastError());
     ctx->decoded = true;
     ctx->results_valid = false;
@@ -732,21 +807,35 @@ static int fetch_results(efx_ctx* ctx)
     int r = sync_all(ctx);
     if (r)
         return r;
-    const efx_ctx::Slot& sl = ctx->slot[ctx->cur];
-    const efx_ctx::Upload& u = ctx->up[sl.upload];
+    const efx_ctx::Upload& u = ctx->up[ctx->last_upload];
     ctx->n_streams = u.n_streams;
+    const size_t P = (size_t)ctx->cfg.max_pictures;
     ctx->h_pic_count.resize(ctx->n_streams);
     ctx->h_status.resize(ctx->n_streams);
     ctx->h_call_pos.resize(2 * (size_t)ctx->n_streams);
-    EFX_HIP(hipMemcpy(ctx->h_pic_count.data(), sl.d_pic_count, ctx->n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    EFX_HIP(hipMemcpy(ctx->h_status.data(), sl.d_status, ctx->n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    EFX_HIP(hipMemcpy(ctx->h_call_pos.data(), sl.d_call_pos, 2 * (size_t)ctx->n_streams * sizeof(int32_t), hipMemcpyDeviceToHost));
-    EFX_HIP(hipMemcpy(&ctx->h_counters, sl.d_counters, sizeof(DecodeCounters), hipMemcpyDeviceToHost));
-    if (u.ts_input) {
-        ctx->h_pts.resize((size_t)ctx->n_streams * ctx->cfg.max_pictures);
-        EFX_HIP(hipMemcpy(ctx->h_pts.data(), sl.d_pts, ctx->h_pts.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-    } else
+    if (u.ts_input)
+        ctx->h_pts.resize((size_t)ctx->n_streams * P);
+    else
         ctx->h_pts.clear();
+    ctx->h_counters = DecodeCounters{};
+    // every group of the call left the results of ITS streams in its own hand-over slot
+    for (int g = 0; g < ctx->n_groups; g++) {
+        const efx_ctx::Group& gr = ctx->groups[g];
+        const efx_ctx::Slot& sl = ctx->slot[gr.slot];
+        const size_t f = (size_t)gr.first, c = (size_t)gr.count;
+        if (!c)
+            continue;
+        EFX_HIP(hipMemcpy(ctx->h_pic_count.data() + f, sl.d_pic_count + f, c * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        EFX_HIP(hipMemcpy(ctx->h_status.data() + f, sl.d_status + f, c * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        EFX_HIP(hipMemcpy(ctx->h_call_pos.data() + 2 * f, sl.d_call_pos + 2 * f, 2 * c * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (u.ts_input)
+            EFX_HIP(hipMemcpy(ctx->h_pts.data() + f * P, sl.d_pts + f * P, c * P * sizeof(int64_t), hipMemcpyDeviceToHost));
+        DecodeCounters dc;
+        EFX_HIP(hipMemcpy(&dc, sl.d_counters + g, sizeof(dc), hipMemcpyDeviceToHost));
+        ctx->h_counters.total_slices += dc.total_slices;
+        ctx->h_counters.coefficients += dc.coefficients;
+        ctx->h_counters.macroblocks += dc.macroblocks;
+    }
     ctx->results_valid = true;
     return EFX_OK;
 }
@@ -1168,7 +1257,7 @@ int efx_set_timing(efx_ctx* ctx, int enable)
     if (!ctx)
         return EFX_ERR_ARG;
     if (enable && ctx->timing_ring.empty()) {
-        ctx->timing_ring.resize(kTimingRing);
+        ctx->timing_ring.resize((size_t)kTimingRing * kMaxGroups);
         for (auto& te : ctx->timing_ring)
             for (auto& ev : te.ev)
                 EFX_HIP(hipEventCreate(&ev));
@@ -1190,16 +1279,23 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out)
     // fetch_results() has synchronised both streams, so every recorded event is complete
     const uint64_t n_timed = std::min<uint64_t>(ctx->timed_calls, kTimingRing);
     for (uint64_t k = 0; k < n_timed; k++) {
-        const efx_ctx::TimingEvents& te = ctx->timing_ring[(ctx->timed_calls - 1 - k) % kTimingRing];
-        float a = 0, b = 0, c = 0, d = 0;
-        EFX_HIP(hipEventElapsedTime(&a, te.ev[0], te.ev[1]));
-        EFX_HIP(hipEventElapsedTime(&b, te.ev[1], te.ev[2]));
-        EFX_HIP(hipEventElapsedTime(&c, te.ev[4], te.ev[3]));
-        EFX_HIP(hipEventElapsedTime(&d, te.ev[0], te.ev[3]));
-        t.index_ms += a / n_timed;
-        t.parse_ms += b / n_timed;
-        t.recon_ms += c / n_timed;
+        // a call's stage time = the sum over its groups of streams (they run one after the other on their stream)
+        const size_t call = (size_t)((ctx->timed_calls - 1 - k) % kTimingRing);
+        const int G = ctx->timing_groups[call];
+        for (int g = 0; g < G; g++) {
+            const efx_ctx::TimingEvents& te = ctx->timing_ring[call * kMaxGroups + g];
+            float a = 0, b = 0, c = 0;
+            EFX_HIP(hipEventElapsedTime(&a, te.ev[0], te.ev[1]));
+            EFX_HIP(hipEventElapsedTime(&b, te.ev[1], te.ev[2]));
+            EFX_HIP(hipEventElapsedTime(&c, te.ev[4], te.ev[3]));
+            t.index_ms += a / n_timed;
+            t.parse_ms += b / n_timed;
+            t.recon_ms += c / n_timed;
+        }
+        float d = 0;
+        EFX_HIP(hipEventElapsedTime(&d, ctx->timing_ring[call * kMaxGroups].ev[0], ctx->timing_ring[call * kMaxGroups + G - 1].ev[3]));
         t.total_ms += d / n_timed;
+        t.groups = (uint32_t)G;
     }
     t.timed_calls = (uint32_t)n_timed;
     for (int i = 0; i < ctx->n_streams; i++)
@@ -1207,7 +1303,7 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out)
     t.slices = ctx->h_counters.total_slices;
     t.coefficients = ctx->h_counters.coefficients;
     {
-        efx_ctx::Upload& u = ctx->up[ctx->slot[ctx->cur].upload];
+        efx_ctx::Upload& u = ctx->up[ctx->last_upload];
         t.es_bytes = u.es_used;
         t.ts_bytes = u.ts_bytes;
         if (u.ts_input && u.demux_timed)

@@ -96,7 +96,7 @@ struct ParseTables {
 
 struct DecodeCounters {
     uint32_t total_slices;
-    uint32_t pad;
+    uint32_t streams;  // streams of the group of streams these counters belong to (k_slice_scan)
     unsigned long long coefficients;
     unsigned long long macroblocks;
 };

@@ -49,13 +49,13 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
                                               const uint32_t* __restrict__ scan_tab, const PesEntry* __restrict__ pes,
                                               const uint32_t* __restrict__ pkt_base,
                                               const uint32_t* __restrict__ pes_count, int64_t* __restrict__ pts_out,
-                                              int first_picture)
+                                              int first_picture, int stream0)
 {
     __shared__ uint32_t u_off[kMaxUnitsPerStream];
     __shared__ uint32_t u_info[kMaxUnitsPerStream];
     __shared__ uint32_t sh_misc[4];
 
-    const int s = blockIdx.x;
+    const int s = stream0 + blockIdx.x;  // (a call runs as groups of streams: efx_decode_from)
     const int lane = threadIdx.x;
     const uint8_t* base = es + stream_off[s];
     const uint32_t len = (uint32_t)(stream_off[s + 1] - stream_off[s]);  // padded, multiple of 16
@@ -265,11 +265,13 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
 // orders the calls.
 __global__ void k_advance(StreamState* __restrict__ state, const uint32_t* __restrict__ pic_count, int64_t* __restrict__ pts,
                           const PesEntry* __restrict__ pes, const uint32_t* __restrict__ pkt_base,
-                          const uint32_t* __restrict__ pes_count, int n_streams, int max_pictures, int32_t* __restrict__ call_pos)
+                          const uint32_t* __restrict__ pes_count, int stream0, int n_streams, int max_pictures,
+                          int32_t* __restrict__ call_pos)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_streams)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_streams)
         return;
+    const int s = stream0 + t;
     StreamState st = state[s];
     const int n = (int)pic_count[s];
     int f = st.pts_seen ? -1 : n;  // first picture of this call whose header latched a PTS
@@ -340,6 +342,7 @@ __global__ __launch_bounds__(1024) void k_slice_scan(const PicInfo* __restrict__
     }
     if (tid == 0) {
         counters->total_slices = carry;
+        counters->streams = (uint32_t)n_streams;
         counters->coefficients = 0;
         counters->macroblocks = 0;
         slice_base[n] = carry;

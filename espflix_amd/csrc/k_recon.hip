@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
                                               const uint32_t* __restrict__ scan_tab,
                                               const uint32_t* __restrict__ qtab_custom, uint8_t* __restrict__ frames,
                                               int max_pictures, int ring_depth, int pic, const int32_t* __restrict__ call_pos,
-                                              int epoch)
+                                              int epoch, int stream0)
 {
     __shared__ int16_t cfh[64 * kLaneHalfwords];
     __shared__ uint32_t qt_a[64], qt_b[64];  // default / this picture's custom scan + quantiser table
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     __shared__ int s_dc[64];
 
     const int lane = threadIdx.x;
-    const int s = blockIdx.x;
+    const int s = stream0 + blockIdx.x;
     const int b_raw = blockIdx.y * 64 + lane;
     const bool have = b_raw < kBlocksPerPicture;
     const int b = have ? b_raw : kBlocksPerPicture - 1;

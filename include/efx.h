@@ -261,6 +261,9 @@ typedef struct efx_timing {
     float demux_ms;    /* k_demux of the last EFX_FORMAT_TS upload (0 for ES input or timing off at upload) */
     uint32_t timed_calls; /* efx_decode calls averaged in the stage times */
     uint64_t ts_bytes; /* transport-stream bytes of the last upload */
+    uint32_t groups;   /* a call runs as this many groups of streams, one after the other (each one k_index ... k_parse
+                          and one k_recon launch per picture index); the stage times above are sums over them */
+    uint32_t reserved;
 } efx_timing;
 /* Enable HIP-event timing of the decode stages (events recorded on the kernels' own streams);
  * enabling (again) starts a new averaging window. */

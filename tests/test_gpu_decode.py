@@ -157,7 +157,11 @@ def test_config3_batch1024_gop12_every_stream(efx):
     assert all(dec.picture_count(i) == 12 and dec.stream_status(i) == 0 for i in range(1024))
     slots1 = [dec.picture_slot(p) for p in range(12)]
     assert np.array_equal(picture_table(dec, 1024, 12), want)
-    dec.decode()  # the same GOP again: P pictures start from the I picture, the ring position moves on
+    # the same GOP again: P pictures start from the I picture, the ring position moves on.  The first call ran as one
+    # group of streams; its slices were short, so this one runs as two groups of 512, each with its own hand-over slot
+    dec.set_timing(True)
+    dec.decode()
+    assert dec.timing().groups == 2
     assert [dec.picture_slot(p) for p in range(12)] == [(s + 12) % 13 for s in slots1]
     assert np.array_equal(picture_table(dec, 1024, 12), want)
     perm = np.random.default_rng(0).permutation(1024)
