@@ -48,7 +48,7 @@ using namespace efx;
 #define EFX_SLOTS 3
 #endif
 constexpr int kParseStreams = EFX_PARSE_STREAMS;  // parse halves in flight at once (latency-bound kernels: two overlap well)
-constexpr int kMaxGroups = 8;       // an efx_decode call runs as up to this many groups of streams, one after the other
+constexpr int kMaxGroups = 16;      // an efx_decode call runs as up to this many groups of streams, one after the other
 #ifndef EFX_GROUP_STREAMS
 #define EFX_GROUP_STREAMS 512
 #endif

@@ -29,15 +29,23 @@ for s in a.stats:
 
 summary = collections.defaultdict(dict)
 for d in a.pmc:
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    # per kernel only the dispatches of its most frequent grid size: libefx runs the first call of a context as one
+    # group of streams and later ones as groups of ~512 (efx_decode_from), and a mean over both would be neither
+    rows = collections.defaultdict(list)
     for f in os.listdir(d):
         if not f.endswith("counter_collection.csv"):
             continue
         for r in csv.DictReader(open(os.path.join(d, f))):
             k = r["Kernel_Name"].split("(")[0]
             if k.startswith("efx::"):
-                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, cs in agg.items():
+                rows[k].append((int(r["Grid_Size"]), r["Counter_Name"], float(r["Counter_Value"])))
+    for k, rs in rows.items():
+        grid = collections.Counter(g for g, _, _ in rs).most_common(1)[0][0]
+        summary[k]["grid_size"] = grid
+        cs = collections.defaultdict(list)
+        for g, c, v in rs:
+            if g == grid:
+                cs[c].append(v)
         for c, v in cs.items():
             summary[k][c] = sum(v) / len(v)
             summary[k]["dispatches_" + c] = len(v)
