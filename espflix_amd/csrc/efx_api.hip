@@ -748,6 +748,9 @@ int efx_decode_from(efx_ctx* ctx, int first_picture)
             sl.epoch = 1;
         }
         efx_ctx::TimingEvents* te = timing_slot >= 0 ? &ctx->timing_ring[(size_t)timing_slot * kMaxGroups + g] : nullptr;
+        if (te && !te->ev[0])
+            for (auto& ev : te->ev)
+                EFX_HIP(hipEventCreate(&ev));
         if (te)
             EFX_HIP(hipEventRecord(te->ev[0], sp));
         hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, sp, u.d_es, u.d_stream_off, P, sl.d_pics, sl.d_slices_tmp, sl.d_pic_count,
@@ -1257,10 +1260,7 @@ int efx_set_timing(efx_ctx* ctx, int enable)
     if (!ctx)
         return EFX_ERR_ARG;
     if (enable && ctx->timing_ring.empty()) {
-        ctx->timing_ring.resize((size_t)kTimingRing * kMaxGroups);
-        for (auto& te : ctx->timing_ring)
-            for (auto& ev : te.ev)
-                EFX_HIP(hipEventCreate(&ev));
+        ctx->timing_ring.resize((size_t)kTimingRing * kMaxGroups);  // (the events of a set are created at its first use)
     }
     ctx->timing = enable != 0;
     ctx->timed_calls = 0;  // (re-)enabling starts a new averaging window
