@@ -119,7 +119,9 @@ int efx_erase_frames(efx_ctx* ctx);
  * reconstructed into ring slot (p + s(i)) % ring_depth from slot (p + s(i) - 1) % ring_depth,
  * s(i) = i + 1 once a picture has latched a PES PTS, else max(0, i - f) with f the first picture of
  * the call that does: the reference does not swap its two buffers before the first PTS.  Elementary-
- * stream input counts every picture as carrying one.  ring_depth 2 is the reference's pair. */
+ * stream input counts every picture as carrying one.  ring_depth 2 is the reference's pair.
+ * Streams are independent; a large batch whose slices are short runs as several groups of streams one
+ * after the other (finer pipeline, efx_timing::groups) -- the results do not depend on it. */
 int efx_decode(efx_ctx* ctx);
 /* The same, starting at picture `first_picture` of every uploaded stream (earlier pictures are walked
  * for their header state only): a stream with more than max_pictures pictures (EFX_STREAM_TRUNCATED)
