@@ -171,6 +171,29 @@ def test_config3_batch1024_gop12_every_stream(efx):
     dec.close()
 
 
+def test_groups_of_streams_with_transport_stream_input(efx):
+    """A call that runs as two groups of streams (the second decode of 1024 short-slice streams) gathers its
+    per-stream results -- picture counts, status, PTS, ring positions -- from the hand-over slots of both groups."""
+    from espflix_amd import gen
+    want = bench_golden("bench_gop12.u64", 8192, 12)[:1024]
+    b = gen.Batch(0, 1024, 12, 12, 0)
+    ts = [b.ts(k) for k in range(1024)]
+    dec = efx.Decoder(1024, 12, 13, max_stream_bytes=sum(len(t) for t in ts) + 65536)
+    dec.upload(ts, efx.FORMAT_TS)
+    dec.decode()
+    dec.set_timing(True)
+    dec.decode()
+    assert dec.timing().groups == 2
+    assert all(dec.picture_count(i) == 12 and dec.stream_status(i) == 0 for i in range(1024))
+    pts = [129003 + 3003 * f for f in range(12)]
+    for i in (0, 1, 7, 255, 511, 512, 513, 777, 1023):  # (both sides of the group boundary)
+        assert [dec.picture_pts(i, p) for p in range(12)] == pts, i
+    h = dec.frame_hashes()
+    got = np.stack([[h[i, dec.picture_slot(p, i)] for p in range(12)] for i in range(1024)])
+    assert np.array_equal(got, want)
+    dec.close()
+
+
 def test_real_stream_shape_every_stream(efx):
     """The service's stream shape (5 slices per picture over 2-3 macroblock rows, ~6.25 kB per picture): 256 streams
     against the reference decoder's output (bench_wide1500k.u64)."""
