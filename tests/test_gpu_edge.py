@@ -169,3 +169,42 @@ def test_damaged_slice_that_runs_on_into_the_next_row(efx):
         assert dec.picture_count(i) == n == 6, flips[i]
         assert [int(h[i, dec.picture_slot(p, i)]) for p in (n - 2, n - 1)] == [int(x) for x in oh[-2:]], flips[i]
     dec.close()
+
+
+@pytest.mark.parametrize("ts_input", [False, True])
+def test_heavily_damaged_streams_come_back(efx, ts_input):
+    """Bit flips, overwritten and zeroed ranges, truncation and inserted start codes, as elementary and as transport
+    streams: every decode returns (no hang, no fault), windows included, and what went wrong is in the status."""
+    from espflix_amd import gen
+    rng = np.random.default_rng(99)
+    b = gen.Batch(0, 16, 6)
+    base = [np.frombuffer(b.ts(k), dtype=np.uint8).copy() if ts_input else b.es(k).copy() for k in range(16)]
+    blobs = []
+    for i in range(640):
+        x = base[i % 16].copy()
+        kind = i % 5
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 17))):
+                x[int(rng.integers(0, x.size))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            a, n = int(rng.integers(0, x.size - 64)), int(rng.integers(1, 2000))
+            x[a:a + n] = rng.integers(0, 256, min(n, x.size - a), dtype=np.uint8)
+        elif kind == 2:
+            x = x[:int(rng.integers(1, x.size))].copy()
+        elif kind == 3:
+            for _ in range(int(rng.integers(1, 9))):
+                a = int(rng.integers(0, x.size - 8))
+                x[a:a + 4] = [0, 0, 1, int(rng.integers(0, 256))]
+        else:
+            a, n = int(rng.integers(0, x.size - 64)), int(rng.integers(1, 4000))
+            x[a:a + n] = 0
+        blobs.append(x)
+    dec = efx.Decoder(len(blobs), 16, 2, max_stream_bytes=sum(x.size for x in blobs) + 65536)
+    dec.upload(blobs, efx.FORMAT_TS if ts_input else efx.FORMAT_ES)
+    dec.decode(first_picture=3)
+    dec.sync()
+    dec.decode()
+    status = np.array([dec.stream_status(i) for i in range(len(blobs))])
+    counts = np.array([dec.picture_count(i) for i in range(len(blobs))])
+    assert counts.max() <= 16 and (status != 0).sum() > len(blobs) // 2
+    dec.close()
