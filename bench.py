@@ -535,7 +535,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: espflix_amd has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("EFX_BENCH_FORCE_DIST"):  # (the variable: the RCCL code path with a single rank, for testing)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
