@@ -106,7 +106,8 @@ __device__ constexpr double kAan[8] = {1.0,          1.3870398453221475, 1.30656
 __device__ constexpr int premul_at(int r, int c) { return (int)(32.0 * kAan[r] * kAan[c] + 0.5); }
 
 constexpr int kBlocksPerPicture = kMbCount * 6;
-constexpr int kLaneHalfwords = 66;  // per-lane LDS block: 64 int16 + 2 pad = 33 dwords (odd: lanes fan out over the banks)
+constexpr int kLaneDwords = 33;  // per-lane LDS block: 64 int16 + one dword (see k_recon)
+constexpr int kLaneHalfwords = 2 * kLaneDwords;
 
 // grid = (streams, 25): blockIdx.x = stream, blockIdx.y = group of 64 consecutive 8x8 blocks of the
 // picture in plane-row order (see below); ONE LANE PER BLOCK.  With a stream count that
@@ -125,14 +126,17 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
                                               int max_pictures, int ring_depth, int pic, const int32_t* __restrict__ call_pos,
                                               int epoch, int stream0)
 {
-    __shared__ int16_t cfh[64 * kLaneHalfwords];
-    __shared__ uint32_t qt_a[64], qt_b[64];  // default / this picture's custom scan + quantiser table
-    // per block: entries before it in the wave (<= 64 * 64), first entry, flags, DC level, "entry at scan position 0".
-    // Kept narrow: LDS, not registers, bounds the occupancy (9.7 KB per wave -> 16 waves per CU)
-    __shared__ uint16_t s_pre[64];
-    __shared__ uint32_t s_base[64];
-    __shared__ uint8_t s_info[64], s_zf[64];
-    __shared__ int s_dc[64];
+    // 8640 bytes of LDS per wave (18 waves per CU; the 91 registers allow 20).  Per lane 33 dwords: 64 int16
+    // coefficients and, in the 33rd (which makes the stride odd: lanes fan out over the banks), entry `lane` of the
+    // default scan / quantiser table; the wave's prefix counts for the owner search; 64 bytes of per-block flags.
+    // What else a lane needs to know about another lane's block (first entry, quantiser) is fetched from that lane's
+    // registers (ds_bpermute).  Measured: this layout at 16 / 18 / 19 waves per CU 8.07 / 8.16 / 7.85 M frames/s
+    // (19 with the search through ds_bpermute as well), the previous one (9.7 KB, 16 waves) 7.78.
+    __shared__ uint32_t lds[64 * kLaneDwords + 32 + 16];
+    int16_t* const cfh = reinterpret_cast<int16_t*>(lds);
+    uint16_t* const s_pre = reinterpret_cast<uint16_t*>(lds + 64 * kLaneDwords);  // entries before the block in the wave
+    uint8_t* const s_zd = reinterpret_cast<uint8_t*>(lds + 64 * kLaneDwords + 32);  // bit 7: an entry sits at scan position 0;
+                                                                                    // bits 0-5: intra DC value >> 16
 
     const int lane = threadIdx.x;
     const int s = stream0 + blockIdx.x;
@@ -162,8 +166,8 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     const uint8_t* ref = frames + ((size_t)s * ring_depth + ref_slot) * kFrameBytes;
 
     // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
-    qt_a[lane] = scan_tab[lane];
-    qt_b[lane] = qtab_custom[((size_t)s * max_pictures + pic) * 64 + lane];  // garbage unless a record says "custom": never used then
+    lds[lane * kLaneDwords + 32] = scan_tab[lane];
+    const uint32_t* const qt_custom = qtab_custom + ((size_t)s * max_pictures + pic) * 64;  // (read only where a record says "custom")
 
     const uint4 rw = *reinterpret_cast<const uint4*>(mbrecs + ((size_t)s * max_pictures + pic) * kMbCount + mb);
     const uint32_t w_base = rw.x, w_cnt = rw.y, w_misc = rw.z, w_mv = rw.w;
@@ -239,10 +243,10 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     {
         uint32_t* z = reinterpret_cast<uint32_t*>(mine);
 #pragma unroll
-        for (int k = 0; k < kLaneHalfwords / 2; k++)
+        for (int k = 0; k < 32; k++)
             z[k] = 0;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // qt_a / qt_b written above, read below by other lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the table written above is read below by other lanes
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // The 64 blocks of the wave hold very different numbers of entries (3 on average, a dozen at the
@@ -257,11 +261,10 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         incl += lane >= d ? o : 0u;
     }
     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-    s_pre[lane] = (uint16_t)(incl - (uint32_t)my_cnt);
-    s_base[lane] = my_base;
-    s_info[lane] = (uint8_t)flags;  // bit0 intra, bits 2-6 quantiser_scale, bit7 custom matrices
-    s_dc[lane] = 0;
-    s_zf[lane] = 0;
+    const uint32_t pre = incl - (uint32_t)my_cnt;  // entries before this block in the wave (<= 64 * 64)
+    const uint32_t pre_flags = pre | (flags << 16);  // flags: bit0 intra, bits 2-6 quantiser_scale, bit7 custom matrices
+    s_zd[lane] = 0;
+    s_pre[lane] = (uint16_t)pre;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -279,10 +282,12 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
 #pragma unroll
             for (int step = 32; step > 0; step >>= 1)
                 L += (uint32_t)s_pre[L + step] <= i ? step : 0;
-            own[k] = L;
+            const uint32_t o_pf = (uint32_t)__builtin_amdgcn_ds_bpermute(L * 4, (int)pre_flags);
+            const uint32_t o_base = (uint32_t)__builtin_amdgcn_ds_bpermute(L * 4, (int)my_base);
+            own[k] = L | (int)(o_pf >> 16 << 8);  // owner lane | its flags << 8
             // (always a load, beyond the end from entry 0: the compiler then knows how many loads are in flight and
             // the prediction below waits for the windows only)
-            ent[k] = coefs[i < total ? s_base[L] + (i - (uint32_t)s_pre[L]) : 0u];
+            ent[k] = coefs[i < total ? o_base + (i - (o_pf & 0xFFFF)) : 0u];
         }
     };
     auto apply = [&](uint32_t i0) {
@@ -290,18 +295,23 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         for (int k = 0; k < kPerRound; k++) {
             if (i0 + 64 * k >= total)
                 continue;
-            const int L = own[k];
+            const int L = own[k] & 63;
             const uint32_t e = ent[k];
-            const uint32_t f = s_info[L];
+            const uint32_t f = (uint32_t)own[k] >> 8;
             const bool o_intra = f & 1;
             const int n = e & 63, level = (int)e >> 6;
             // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
-            const uint32_t t = ((f & 0x80) ? qt_b : qt_a)[n];
-            if (n == 0)
-                s_zf[L] = 1;
-            if (o_intra && n == 0)
-                s_dc[L] = level;  // b[0] = dc << 8 (player.cpp:1065); kept out of the int16 block
-            else {
+            uint32_t t = lds[n * kLaneDwords + 32];
+            if (f & 0x80)
+                t = qt_custom[n];
+            if (o_intra && n == 0) {
+                // b[0] = dc << 8 (player.cpp:1065) does not fit the int16 block: the value is kept as it is, its low
+                // half in position 0 (no other entry of an intra block lands there), the rest beside the flag
+                cfh[L * kLaneHalfwords] = (int16_t)level;
+                s_zd[L] = (uint8_t)(0x80 | ((level >> 16) & 0x3F));
+            } else {
+                if (n == 0)
+                    s_zd[L] = 0x80;
                 // dequantise, player.cpp:1110-1121; |2 level +- 1| <= 511, qscale <= 31, q <= 255
                 const int q = o_intra ? (int)((t >> 16) & 0xFF) : (int)(t >> 24);
                 int val = level << 1;
@@ -371,8 +381,10 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int dc_raw = s_dc[lane];   // intra DC value (entry at scan position 0)
-    const bool zf = s_zf[lane] != 0;  // an entry sits at scan position 0
+    const uint32_t zd = s_zd[lane];
+    const bool zf = (zd & 0x80) != 0;  // an entry sits at scan position 0
+    // intra DC value (22 bits: a slice adds at most 1584 differentials of +-255 to the predictor)
+    const int dc_raw = (int)((uint32_t)(uint16_t)mine[0] | ((uint32_t)((int)(zd << 26) >> 26) << 16));
 
     // A block whose only coefficient sits at scan position 0 takes the reference's "n == 1"
     // shortcut (player.cpp:1133-1140): dc = b[0] >> 8 (floor), no IDCT; for intra blocks the
