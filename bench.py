@@ -457,7 +457,7 @@ def run(job, args):
                    "streams_per_gpu": S, "streams_total": S * world, "pictures_per_stream": P, "es_bytes_per_gpu": r["es_bytes"],
                    "mean_bytes_per_picture": r["es_bytes"] / (S * P), "parallelism": f"stream-partition x{world}",
                    "coefficients_per_gpu": r["n_coefs"], "ring_depth": 2},
-        "roofline": {"bound": "hbm", "limiter": "dependent steps of a wave's life at 16 waves per CU, VALU ~3/4 busy (DESIGN.md section 6)", "kernel": names[2], "achieved": achieved,
+        "roofline": {"bound": "hbm", "limiter": "dependent steps of a wave's life (record -> owner search -> entry loads -> scatter -> IDCT -> stores) at 18 waves per CU; neither fewer instructions nor more occupancy shortens it (DESIGN.md section 6)", "kernel": names[2], "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_launch, "avg_launch_ms": dur_s * 1e3, "launches_per_step": P * G,
