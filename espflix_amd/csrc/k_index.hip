@@ -77,40 +77,50 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
             wv[u][3] = d.w;
             wv[u][4] = *reinterpret_cast<const uint32_t*>(p + 16);
         }
+        // start codes of the four kilobytes: one 16-bit mask per lane and kilobyte, then ONE pair of wave scans for
+        // all four (counts packed two to a register; a kilobyte holds at most 342 codes) and the appends -- the wave
+        // is alone on its SIMD, what it pays for is instructions and branches, not bytes
+        uint32_t mask[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
             const uint32_t pos = chunk + u * 1024 + lane * 16;
-            const bool live = pos < len;
             uint32_t* w = wv[u];
             if (pos + 16 >= len)
                 w[4] = 0;  // never look into the next stream
-            uint32_t mask = 0;
+            uint32_t m = 0;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 // bytes i, i+1, i+2 as a little-endian 24-bit value must be 0x010000
                 uint32_t lo = w[i >> 2], hi = w[(i >> 2) + 1];
                 uint32_t v = (i & 3) ? __builtin_amdgcn_alignbyte(hi, lo, i & 3) : lo;
                 if ((v & 0xFFFFFF) == 0x010000)
-                    mask |= 1u << i;
+                    m |= 1u << i;
             }
-            if (!live)
-                mask = 0;
-            uint32_t cnt = __popc(mask);
-            if (__ballot(cnt != 0)) {
-                uint32_t total;
-                uint32_t idx = n_units + wave_excl_scan(cnt, &total);
-                while (mask) {
-                    int i = __ffs(mask) - 1;
-                    mask &= mask - 1;
-                    if (idx < kMaxUnitsPerStream) {
-                        uint32_t lo = w[(i + 3) >> 2];
+            mask[u] = pos < len ? m : 0u;
+        }
+        static_assert(kUnroll == 4, "the packed scans below are written for four kilobytes per trip");
+        if (__ballot((mask[0] | mask[1] | mask[2] | mask[3]) != 0)) {
+            uint32_t t01, t23;
+            const uint32_t e01 = wave_excl_scan(__popc(mask[0]) | (__popc(mask[1]) << 16), &t01);
+            const uint32_t e23 = wave_excl_scan(__popc(mask[2]) | (__popc(mask[3]) << 16), &t23);
+            const uint32_t tot[4] = {t01 & 0xFFFF, t01 >> 16, t23 & 0xFFFF, t23 >> 16};
+            const uint32_t before[4] = {e01 & 0xFFFF, e01 >> 16, e23 & 0xFFFF, e23 >> 16};
+            uint32_t first = n_units;
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                // positions in stream order: kilobyte, lane, byte (the start code value is read in phase 2)
+                uint32_t idx = first + before[u], m = mask[u];
+                const uint32_t pos = chunk + u * 1024 + lane * 16;
+                while (m) {
+                    const int i = __ffs(m) - 1;
+                    m &= m - 1;
+                    if (idx < kMaxUnitsPerStream)
                         u_off[idx] = pos + i + 4;
-                        u_info[idx] = (lo >> (((i + 3) & 3) * 8)) & 0xFF;
-                    }
                     idx++;
                 }
-                n_units += total;
+                first += tot[u];
             }
+            n_units = first;
         }
     }
     uint32_t st = 0;
@@ -122,8 +132,10 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
 
     // ---- 2. lane-parallel header pre-parse -------------------------------------------------
     for (uint32_t i = lane; i < n_units; i += 64) {
-        uint32_t code = u_info[i], off = u_off[i];
+        const uint32_t off = u_off[i];
         const uint8_t* p = base + off;
+        const uint32_t code = p[-1];  // the start code value
+        u_info[i] = code;
         if (code == 0x00) {  // picture: temporal_reference 10, type 3, vbv_delay 16, [full_pel 1, f_code 3]
             uint32_t type = load_bits(p, 10, 3);
             uint32_t fp = load_bits(p, 29, 1), fc = load_bits(p, 30, 3);
