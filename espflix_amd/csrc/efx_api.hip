@@ -753,7 +753,7 @@ int efx_decode_from(efx_ctx* ctx, int first_picture)
                 EFX_HIP(hipEventCreate(&ev));
         if (te)
             EFX_HIP(hipEventRecord(te->ev[0], sp));
-        hipLaunchKernelGGL(k_index, dim3(n), dim3(64), 0, sp, u.d_es, u.d_stream_off, P, sl.d_pics, sl.d_slices_tmp, sl.d_pic_count,
+        hipLaunchKernelGGL(k_index, dim3(n), dim3(64 * kIndexWaves), 0, sp, u.d_es, u.d_stream_off, P, sl.d_pics, sl.d_slices_tmp, sl.d_pic_count,
                            sl.d_status, sl.d_qtab, ctx->d_tables->scan, u.d_pes, u.d_pkt_base, u.d_pes_count,
                            u.ts_input ? sl.d_pts : nullptr, first_picture, s0);
         hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, sl.d_pics, sl.d_pic_count, n, P, u.d_stream_perm + s0,

@@ -18,6 +18,7 @@ namespace efx {
 constexpr int kMbW = 22, kMbH = 12, kMbCount = 264;
 constexpr int kStride = 528, kStripBytes = 8448, kFrameBytes = 101376;
 constexpr int kMaxSlicesPerPicture = 16;   // slice start codes kept per picture
+constexpr int kIndexWaves = 4;             // waves of a k_index workgroup (one workgroup per stream)
 constexpr int kMaxUnitsPerStream = 4096;   // start codes indexed per stream per decode
 constexpr int kCoefsPerEsByte = 3;         // a coefficient costs >= 3 bits (2 + EOB for singletons)
 constexpr int kEsTailBytes = 9;            // 00 | 00 00 01 B7 | 00 00 01 B7   (player.cpp:456,472)

@@ -42,86 +42,116 @@ __device__ inline uint32_t load_bits(const uint8_t* p, uint32_t bitpos, int n)  
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, const uint64_t* __restrict__ stream_off,
-                                              int max_pictures, PicInfo* __restrict__ pics,
-                                              SliceTmp* __restrict__ slices_tmp, uint32_t* __restrict__ pic_count,
-                                              uint32_t* __restrict__ status, uint32_t* __restrict__ qtab,
-                                              const uint32_t* __restrict__ scan_tab, const PesEntry* __restrict__ pes,
-                                              const uint32_t* __restrict__ pkt_base,
-                                              const uint32_t* __restrict__ pes_count, int64_t* __restrict__ pts_out,
-                                              int first_picture, int stream0)
+__global__ __launch_bounds__(64 * kIndexWaves) void k_index(
+    const uint8_t* __restrict__ es, const uint64_t* __restrict__ stream_off, int max_pictures, PicInfo* __restrict__ pics,
+    SliceTmp* __restrict__ slices_tmp, uint32_t* __restrict__ pic_count, uint32_t* __restrict__ status, uint32_t* __restrict__ qtab,
+    const uint32_t* __restrict__ scan_tab, const PesEntry* __restrict__ pes, const uint32_t* __restrict__ pkt_base,
+    const uint32_t* __restrict__ pes_count, int64_t* __restrict__ pts_out, int first_picture, int stream0)
 {
     __shared__ uint32_t u_off[kMaxUnitsPerStream];
     __shared__ uint32_t u_info[kMaxUnitsPerStream];
     __shared__ uint32_t sh_misc[4];
+    constexpr int kKbPerWave = 16, kKbPerRound = kKbPerWave * kIndexWaves;
+    static_assert(kKbPerRound == 64, "one wave scans the kilobyte counts of a round: one per lane");
+    __shared__ uint32_t kb_count[kKbPerRound];  // start codes per kilobyte of the round, then their exclusive prefix
+    __shared__ uint32_t round_total;
 
     const int s = stream0 + blockIdx.x;  // (a call runs as groups of streams: efx_decode_from)
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint8_t* base = es + stream_off[s];
     const uint32_t len = (uint32_t)(stream_off[s + 1] - stream_off[s]);  // padded, multiple of 16
 
     // ---- 1. start-code scan -------------------------------------------------------------
+    // The scan is instructions, not bytes (a wave alone on its SIMD: 117 us for 45 KB when one wave did it all), so
+    // the stream is scanned 64 KB at a time by four waves, 16 KB each, a lane 16 bytes of every kilobyte: a 16-bit
+    // mask per lane and kilobyte, packed wave scans for the position of a lane's codes inside its kilobyte, the
+    // kilobytes' totals through LDS for the position of the kilobyte in the stream's list -- the list is in stream
+    // order whatever the wave that found the code.
     uint32_t n_units = 0;
-    constexpr int kUnroll = 4;  // 4 KiB per wave iteration: four 16-byte loads per lane in flight
-    for (uint32_t chunk = 0; chunk < len; chunk += 64 * 16 * kUnroll) {
-        uint32_t wv[kUnroll][5];
+    constexpr int kUnroll = 4;  // four 16-byte loads per lane in flight
+    for (uint32_t round = 0; round < len; round += kKbPerRound * 1024) {
+        uint32_t mask[kKbPerWave];
+        uint32_t before2[kKbPerWave / 2];  // codes before this lane's in its kilobyte, two kilobytes to a register
+        const uint32_t wave_base = round + wave * kKbPerWave * 1024;
 #pragma unroll
-        for (int u = 0; u < kUnroll; u++) {
-            const uint32_t pos = chunk + u * 1024 + lane * 16;
-            // reads past the stream end stay inside the ES buffer (next stream / guard) and are masked below
-            const uint8_t* p = base + (pos < len ? pos : 0);
-            uint4 d = *reinterpret_cast<const uint4*>(p);
-            wv[u][0] = d.x;
-            wv[u][1] = d.y;
-            wv[u][2] = d.z;
-            wv[u][3] = d.w;
-            wv[u][4] = *reinterpret_cast<const uint32_t*>(p + 16);
-        }
-        // start codes of the four kilobytes: one 16-bit mask per lane and kilobyte, then ONE pair of wave scans for
-        // all four (counts packed two to a register; a kilobyte holds at most 342 codes) and the appends -- the wave
-        // is alone on its SIMD, what it pays for is instructions and branches, not bytes
-        uint32_t mask[kUnroll];
+        for (int k = 0; k < kKbPerWave / kUnroll; k++) {
+            if (wave_base + k * kUnroll * 1024 >= len) {  // (uniform) nothing of the stream in these four kilobytes
 #pragma unroll
-        for (int u = 0; u < kUnroll; u++) {
-            const uint32_t pos = chunk + u * 1024 + lane * 16;
-            uint32_t* w = wv[u];
-            if (pos + 16 >= len)
-                w[4] = 0;  // never look into the next stream
-            uint32_t m = 0;
+                for (int u = 0; u < kUnroll; u++)
+                    mask[k * kUnroll + u] = 0;
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                // bytes i, i+1, i+2 as a little-endian 24-bit value must be 0x010000
-                uint32_t lo = w[i >> 2], hi = w[(i >> 2) + 1];
-                uint32_t v = (i & 3) ? __builtin_amdgcn_alignbyte(hi, lo, i & 3) : lo;
-                if ((v & 0xFFFFFF) == 0x010000)
-                    m |= 1u << i;
+                for (int h = 0; h < kUnroll / 2; h++)
+                    before2[(k * kUnroll) / 2 + h] = 0;
+                if (lane < kUnroll)
+                    kb_count[wave * kKbPerWave + k * kUnroll + lane] = 0;
+                continue;
             }
-            mask[u] = pos < len ? m : 0u;
-        }
-        static_assert(kUnroll == 4, "the packed scans below are written for four kilobytes per trip");
-        if (__ballot((mask[0] | mask[1] | mask[2] | mask[3]) != 0)) {
-            uint32_t t01, t23;
-            const uint32_t e01 = wave_excl_scan(__popc(mask[0]) | (__popc(mask[1]) << 16), &t01);
-            const uint32_t e23 = wave_excl_scan(__popc(mask[2]) | (__popc(mask[3]) << 16), &t23);
-            const uint32_t tot[4] = {t01 & 0xFFFF, t01 >> 16, t23 & 0xFFFF, t23 >> 16};
-            const uint32_t before[4] = {e01 & 0xFFFF, e01 >> 16, e23 & 0xFFFF, e23 >> 16};
-            uint32_t first = n_units;
+            uint32_t wv[kUnroll][5];
 #pragma unroll
             for (int u = 0; u < kUnroll; u++) {
-                // positions in stream order: kilobyte, lane, byte (the start code value is read in phase 2)
-                uint32_t idx = first + before[u], m = mask[u];
-                const uint32_t pos = chunk + u * 1024 + lane * 16;
-                while (m) {
-                    const int i = __ffs(m) - 1;
-                    m &= m - 1;
-                    if (idx < kMaxUnitsPerStream)
-                        u_off[idx] = pos + i + 4;
-                    idx++;
-                }
-                first += tot[u];
+                const uint32_t pos = wave_base + (k * kUnroll + u) * 1024 + lane * 16;
+                // reads past the stream end stay inside the ES buffer (next stream / guard) and are masked below
+                const uint8_t* p = base + (pos < len ? pos : 0);
+                uint4 d = *reinterpret_cast<const uint4*>(p);
+                wv[u][0] = d.x;
+                wv[u][1] = d.y;
+                wv[u][2] = d.z;
+                wv[u][3] = d.w;
+                wv[u][4] = *reinterpret_cast<const uint32_t*>(p + 16);
             }
-            n_units = first;
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                const uint32_t pos = wave_base + (k * kUnroll + u) * 1024 + lane * 16;
+                uint32_t* w = wv[u];
+                if (pos + 16 >= len)
+                    w[4] = 0;  // never look into the next stream
+                uint32_t m = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    // bytes i, i+1, i+2 as a little-endian 24-bit value must be 0x010000
+                    uint32_t lo = w[i >> 2], hi = w[(i >> 2) + 1];
+                    uint32_t v = (i & 3) ? __builtin_amdgcn_alignbyte(hi, lo, i & 3) : lo;
+                    if ((v & 0xFFFFFF) == 0x010000)
+                        m |= 1u << i;
+                }
+                mask[k * kUnroll + u] = pos < len ? m : 0u;
+            }
+#pragma unroll
+            for (int h = 0; h < kUnroll / 2; h++) {
+                const int kb = k * kUnroll + 2 * h;
+                uint32_t t2;  // (a kilobyte holds at most 342 codes: the two 16-bit fields never carry)
+                before2[kb / 2] = wave_excl_scan(__popc(mask[kb]) | (__popc(mask[kb + 1]) << 16), &t2);
+                if (lane == 0) {
+                    kb_count[wave * kKbPerWave + kb] = t2 & 0xFFFF;
+                    kb_count[wave * kKbPerWave + kb + 1] = t2 >> 16;
+                }
+            }
         }
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t tot;
+            const uint32_t ex = wave_excl_scan(kb_count[lane], &tot);
+            kb_count[lane] = ex;
+            if (lane == 0)
+                round_total = tot;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < kKbPerWave; kb++) {
+            uint32_t m = mask[kb];
+            // positions in stream order: kilobyte, lane, byte (the start code value is read in phase 2)
+            uint32_t idx = n_units + kb_count[wave * kKbPerWave + kb] + ((before2[kb / 2] >> (16 * (kb & 1))) & 0xFFFF);
+            const uint32_t pos = wave_base + kb * 1024 + lane * 16;
+            while (m) {
+                const int i = __ffs(m) - 1;
+                m &= m - 1;
+                if (idx < kMaxUnitsPerStream)
+                    u_off[idx] = pos + i + 4;
+                idx++;
+            }
+        }
+        n_units += round_total;
+        __syncthreads();  // (kb_count and round_total are written again in the next round)
     }
     uint32_t st = 0;
     if (n_units > kMaxUnitsPerStream) {
@@ -131,7 +161,7 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
     __syncthreads();
 
     // ---- 2. lane-parallel header pre-parse -------------------------------------------------
-    for (uint32_t i = lane; i < n_units; i += 64) {
+    for (uint32_t i = tid; i < n_units; i += 64 * kIndexWaves) {
         const uint32_t off = u_off[i];
         const uint8_t* p = base + off;
         const uint32_t code = p[-1];  // the start code value
@@ -153,7 +183,7 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
     // ---- 3. sequential state walk (one lane; the list is a few hundred entries at most) ------
     PicInfo* mypics = pics + (size_t)s * max_pictures;
     SliceTmp* myslices = slices_tmp + (size_t)s * max_pictures * kMaxSlicesPerPicture;
-    if (lane == 0) {
+    if (tid == 0) {
         // pictures before `first_picture` (efx_decode_from: a stream longer than max_pictures is decoded in
         // several passes) are walked for their state -- sequence matrices, the P pictures' f_code -- and dropped
         int pic = -1 - first_picture;
@@ -236,7 +266,7 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
     if (pts_out) {
         const PesEntry* mp = pes + pkt_base[s];
         const uint32_t np = pes_count[s];
-        for (uint32_t p = lane; p < npics; p += 64) {
+        for (uint32_t p = tid; p < npics; p += 64 * kIndexWaves) {
             const uint32_t limit = mypics[p].start_off + 1;
             uint32_t a = 0, b = np;  // first entry with es_off > limit
             while (a < b) {
@@ -250,7 +280,7 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t* __restrict__ es, co
         }
     }
 
-    for (uint32_t p = 0; p < npics; p++) {
+    for (uint32_t p = wave; p < npics; p += kIndexWaves) {  // (one wave per picture, a lane per table entry)
         PicInfo pi = mypics[p];
         if (!pi.custom_q)
             continue;
