@@ -4,8 +4,9 @@
 # --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ).  Every pass is bounded by `timeout`.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$1; mkdir -p $out
-# --timed-only + 200 steps: 2400 of the 2470 k_recon launches of the process belong to the timed region, so the
-# average rocprofv3 reports is the one bench.py measures with HIP events (roofline.avg_launch_ms)
+# --timed-only + 200 steps: 4800 of the 4860 k_recon launches of the process (24 per step: two groups of 512 streams x 12
+# picture indexes) belong to the timed region, so the average rocprofv3 reports is the one bench.py measures with HIP
+# events (roofline.avg_launch_ms)
 B="python bench.py --steps 200 --warmup 3 --no-cpu-baseline --no-fixed-batch --no-other-workloads --timed-only"
 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o pipelined -- $B > $out/bench_pipelined.log 2>&1
 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o serial -- $B --no-overlap > $out/bench_serial.log 2>&1
