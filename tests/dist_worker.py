@@ -63,7 +63,7 @@ class OracleDecoder:
 
     def timing(self):
         return types.SimpleNamespace(index_ms=0.1, parse_ms=1.0, recon_ms=1.0, total_ms=2.1, pictures=sum(len(h) for h in self.tab),
-                                     coefficients=1000 * self.S, timed_calls=self.calls, slices=0, es_bytes=0)
+                                     coefficients=1000 * self.S, timed_calls=self.calls, slices=0, es_bytes=0, groups=2)
 
     def close(self):
         pass

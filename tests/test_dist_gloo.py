@@ -63,6 +63,10 @@ def test_two_rank_gloo_job_runs_the_bench_control_flow():
     assert out["fixed_batch_8192"]["streams_total"] == 9 and out["fixed_batch_8192"]["scaling"] == "strong"
     assert out["fixed_batch_8192"]["streams_per_gpu"] in (4, 5)      # ceil / floor split of 9 over 2 ranks
     assert out["cpu_baseline"] is not None and out["cpu_baseline"]["value"] > 0   # rank 0, N > 1 too
+    # a call that runs as two groups of streams is 24 k_recon launches per step: per-launch figures follow
+    r = out["roofline"]
+    assert r["launches_per_step"] == 24 and abs(r["avg_launch_ms"] * 24 - r["stage_ms"]["k_recon x12"]) < 1e-9
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] / 1e3) / 1e9) < 1e-6
     # value = pictures of ALL ranks / max-over-ranks time
     assert abs(out["value"] * out["ms_per_step"] / 1e3 - 6 * 12) < 1e-6
     # the same job in one process: same per-stream hashes, hence the same checksum of checksums
