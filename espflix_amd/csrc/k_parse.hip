@@ -86,6 +86,40 @@ struct BitReader {
         return (uint32_t)((((((uint64_t)hi) << 32) | lo) << (pos & 31)) >> 32);
     }
     __device__ inline void advance(uint32_t n) { pos += n; }
+
+    // The coefficient loop keeps the window in registers: dwords i, i + 1, i + 2 of the stream (i = pos >> 5), so that
+    // the chain  position -> window -> table -> length -> position  holds ONE LDS round trip (the table) instead of
+    // two.  A symbol is at most 28 bits, so a trip crosses at most one dword boundary; the dword that then becomes
+    // i + 2 is requested at once and put in place at the top of the next trip, where its latency sits in the shadow of
+    // that trip's table look-up.
+    struct Regs {
+        uint32_t hi, lo, nx, pend;
+        bool crossed;
+    };
+    __device__ inline void load_regs(Regs& r) const
+    {
+        const uint32_t i = pos >> 5;
+        r.hi = ring[(i % kRingDwords) * 64];
+        r.lo = ring[((i + 1) % kRingDwords) * 64];
+        r.nx = ring[((i + 2) % kRingDwords) * 64];
+        r.pend = 0;
+        r.crossed = false;
+    }
+    __device__ inline uint32_t window(const Regs& r) const
+    {
+        return (uint32_t)((((((uint64_t)r.hi) << 32) | r.lo) << (pos & 31)) >> 32);
+    }
+    __device__ inline void settle(Regs& r) const { r.nx = r.crossed ? r.pend : r.nx; }
+    __device__ inline void advance(Regs& r, uint32_t n)
+    {
+        const uint32_t np = pos + n;
+        const bool c = ((np ^ pos) >> 5) != 0;
+        pos = np;
+        r.hi = c ? r.lo : r.hi;
+        r.lo = c ? r.nx : r.lo;
+        r.crossed = c;
+        r.pend = ring[(((np >> 5) + 2) % kRingDwords) * 64];
+    }
 };
 
 struct SharedTables {
@@ -427,15 +461,18 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
             }
             bool dropped = false;
             uint32_t cont;
+            BitReader::Regs wr3;
+            br.load_regs(wr3);
             do {
                 br.topup();
-                win = br.window();
+                win = br.window(wr3);
                 const uint32_t pk = win >> 16;
                 const uint32_t ent = (pk >= 0x0400) ? sh.t.dct_hi[pk >> 8] : sh.t.dct_lo[pk & 0x3FF];
+                br.settle(wr3);
                 coefs[min(coef_idx, coef_last)] = ((uint32_t)pend_level << 6) | (uint32_t)pend_n;
                 coef_idx += pend_valid;
                 const DctSymbol y = decode_symbol(win, ent);
-                br.advance(y.len);
+                br.advance(wr3, y.len);
                 const int n_new = n + (int)y.run;
                 const bool drop = !y.eob && !y.bad && n_new >= 64;  // player.cpp:1106-1107: block abandoned
                 cont = !(y.eob || y.bad || drop);
