@@ -24,8 +24,8 @@ __global__ void k_demux_audio(const uint8_t*, const uint64_t*, const uint32_t*, 
 __global__ void k_ts_sequences(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, PesEntry*, IdxInfo*);
 __global__ void k_idx_bins(const PesEntry*, const uint32_t*, const IdxInfo*, uint32_t, uint32_t*, size_t);
 __global__ void k_index(const uint8_t*, const uint64_t*, int, PicInfo*, SliceTmp*, uint32_t*, uint32_t*, uint32_t*,
-                        const uint32_t*, const PesEntry*, const uint32_t*, const uint32_t*, int64_t*, int, int);
-__global__ void k_advance(StreamState*, const uint32_t*, int64_t*, const PesEntry*, const uint32_t*, const uint32_t*, int, int, int, int32_t*);
+                        const uint32_t*, const PesEntry*, const uint32_t*, const uint32_t*, int64_t*, int64_t*, int, int);
+__global__ void k_advance(StreamState*, const uint32_t*, int64_t*, const int64_t*, int, int, int, int32_t*);
 __global__ void k_slice_scan(const PicInfo*, const uint32_t*, int, int, const uint32_t*, uint32_t*, DecodeCounters*);
 __global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, const uint64_t*, const uint32_t*, int, int,
                              const uint32_t*, SliceDesc*);
@@ -126,7 +126,8 @@ struct efx_ctx {
         uint32_t* d_qtab = nullptr;  // per (stream, picture) custom quantiser tables, read by k_recon
         uint32_t* d_slice_base = nullptr;
         SliceDesc* d_descs = nullptr;
-        int64_t* d_pts = nullptr;    // per (stream, picture): PTS latched at the picture header (TS input)
+        int64_t* d_pts = nullptr;    // per (stream, picture): PTS latched at the picture header (TS input); then, per
+                                     // stream, the newest PES PTS of the upload (k_index -> k_advance)
         int32_t* d_call_pos = nullptr;  // per stream: ring position of this call's first picture, first picture with a PTS
         hipEvent_t parse_done = nullptr, recon_done = nullptr;
         int epoch = 0;
@@ -145,6 +146,8 @@ struct efx_ctx {
     Group groups[kMaxGroups];  // of the most recent efx_decode
     int n_groups = 0;
     int last_upload = 0;       // batch the most recent efx_decode read
+    int last_n_streams = 0;    // ... its stream count and format, as they were when the decode was queued (a later upload may
+    bool last_ts_input = false;  // have recycled the Upload record by the time the results are fetched)
     uint64_t subcalls = 0;     // groups launched so far: group k uses slot k % kSlots and parse stream k % kParseStreams
     uint8_t timing_groups[kTimingRing] = {};
     uint32_t* h_hint = nullptr;  // pinned: {slices, streams} of the first group of a recent call (copied back asynchronously)
@@ -468,7 +471,7 @@ static int ensure_ts_buffers(efx_ctx* ctx)
     if (e == hipSuccess) e = dalloc(&ctx->d_idx_base, n_max);
     if (e == hipSuccess) e = dalloc(&ctx->d_idx_seq, ctx->pes_cap);
     for (auto& sl : ctx->slot)
-        if (e == hipSuccess) e = dalloc(&sl.d_pts, n_max * (size_t)ctx->cfg.max_pictures);
+        if (e == hipSuccess) e = dalloc(&sl.d_pts, n_max * (size_t)ctx->cfg.max_pictures + n_max);
     if (e != hipSuccess)
         return fail(ctx, EFX_ERR_DEVICE, "transport-stream buffers", e);
     ctx->ts_ready = true;
@@ -729,6 +732,8 @@ int efx_decode_from(efx_ctx* ctx, int first_picture)
     }
     ctx->n_groups = G;
     ctx->last_upload = ctx->cur_up;
+    ctx->last_n_streams = u.n_streams;
+    ctx->last_ts_input = u.ts_input;
     for (int g = 0; g < G; g++) {
         const int s0 = group_first(n_all, G, g), n = group_first(n_all, G, g + 1) - s0;
         const int pi = (int)(ctx->subcalls % kParseStreams);
@@ -755,7 +760,8 @@ int efx_decode_from(efx_ctx* ctx, int first_picture)
             EFX_HIP(hipEventRecord(te->ev[0], sp));
         hipLaunchKernelGGL(k_index, dim3(n), dim3(64 * kIndexWaves), 0, sp, u.d_es, u.d_stream_off, P, sl.d_pics, sl.d_slices_tmp, sl.d_pic_count,
                            sl.d_status, sl.d_qtab, ctx->d_tables->scan, u.d_pes, u.d_pkt_base, u.d_pes_count,
-                           u.ts_input ? sl.d_pts : nullptr, first_picture, s0);
+                           u.ts_input ? sl.d_pts : nullptr, u.ts_input ? sl.d_pts + (size_t)ctx->cfg.max_streams * P : nullptr,
+                           first_picture, s0);
         hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, sl.d_pics, sl.d_pic_count, n, P, u.d_stream_perm + s0,
                            sl.d_slice_base, counters);
         hipLaunchKernelGGL(k_slice_emit, dim3((n * P * kMaxSlicesPerPicture + 255) / 256), dim3(256), 0, sp, sl.d_pics,
@@ -778,7 +784,8 @@ int efx_decode_from(efx_ctx* ctx, int first_picture)
             EFX_HIP(hipEventRecord(te->ev[4], sr));
         // ring positions of this call's pictures; the reconstruction stream orders the calls
         hipLaunchKernelGGL(k_advance, dim3((n + 255) / 256), dim3(256), 0, sr, ctx->d_state, sl.d_pic_count,
-                           u.ts_input ? sl.d_pts : nullptr, u.d_pes, u.d_pkt_base, u.d_pes_count, s0, n, P, sl.d_call_pos);
+                           u.ts_input ? sl.d_pts : nullptr, u.ts_input ? sl.d_pts + (size_t)ctx->cfg.max_streams * P : nullptr, s0, n,
+                           P, sl.d_call_pos);
         for (int p = 0; p < P; p++)
             hipLaunchKernelGGL(k_recon, dim3(n, (kMbCount * 6 + 63) / 64), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs,
                                ctx->d_tables->scan, sl.d_qtab, ctx->d_frames, P, D, p, sl.d_call_pos, sl.epoch, s0);
@@ -810,13 +817,13 @@ static int fetch_results(efx_ctx* ctx)
     int r = sync_all(ctx);
     if (r)
         return r;
-    const efx_ctx::Upload& u = ctx->up[ctx->last_upload];
-    ctx->n_streams = u.n_streams;
+    const bool ts_input = ctx->last_ts_input;
+    ctx->n_streams = ctx->last_n_streams;
     const size_t P = (size_t)ctx->cfg.max_pictures;
     ctx->h_pic_count.resize(ctx->n_streams);
     ctx->h_status.resize(ctx->n_streams);
     ctx->h_call_pos.resize(2 * (size_t)ctx->n_streams);
-    if (u.ts_input)
+    if (ts_input)
         ctx->h_pts.resize((size_t)ctx->n_streams * P);
     else
         ctx->h_pts.clear();
@@ -831,7 +838,7 @@ static int fetch_results(efx_ctx* ctx)
         EFX_HIP(hipMemcpy(ctx->h_pic_count.data() + f, sl.d_pic_count + f, c * sizeof(uint32_t), hipMemcpyDeviceToHost));
         EFX_HIP(hipMemcpy(ctx->h_status.data() + f, sl.d_status + f, c * sizeof(uint32_t), hipMemcpyDeviceToHost));
         EFX_HIP(hipMemcpy(ctx->h_call_pos.data() + 2 * f, sl.d_call_pos + 2 * f, 2 * c * sizeof(int32_t), hipMemcpyDeviceToHost));
-        if (u.ts_input)
+        if (ts_input)
             EFX_HIP(hipMemcpy(ctx->h_pts.data() + f * P, sl.d_pts + f * P, c * P * sizeof(int64_t), hipMemcpyDeviceToHost));
         DecodeCounters dc;
         EFX_HIP(hipMemcpy(&dc, sl.d_counters + g, sizeof(dc), hipMemcpyDeviceToHost));

@@ -52,6 +52,8 @@ struct StreamState {
     int64_t pts_carry;  // newest PES PTS of the uploads so far (-1: none)
 };
 
+constexpr int64_t kNoPts = INT64_MIN;  // "this upload carried no PES PTS for the stream" (k_index -> k_advance)
+
 struct SliceTmp {
     uint32_t off;       // stream-relative offset of the first byte after the slice start code
     uint32_t len_code;  // (bytes up to the next start code) << 8 | slice start code value

@@ -5,9 +5,9 @@
 // sequence (player.cpp:658-678) and picture headers (704-724), and hand each slice
 // (0x01..0xAF) to the slice decoder together with the picture state in force.
 //
-// k_index: ONE WAVE PER STREAM.  Lanes read 16 contiguous bytes each (1 KiB per wave load,
-// four loads in flight per lane), test 16 byte positions, and append hits to an LDS unit list in stream
-// order via a wave prefix sum.  Header fields of all units are then pre-parsed lane-parallel
+// k_index: one workgroup of kIndexWaves waves per stream.  Lanes read 16 contiguous bytes each (1 KiB per
+// wave load, four loads in flight per lane), test 16 byte positions, and append hits to an LDS unit list in
+// stream order via wave prefix sums.  Header fields of all units are then pre-parsed lane-parallel
 // and one lane walks the (short) unit list to apply the reference's sequential state rules.
 #include <hip/hip_runtime.h>
 
@@ -40,13 +40,54 @@ __device__ inline uint32_t load_bits(const uint8_t* p, uint32_t bitpos, int n)  
     return (w << (bitpos & 7)) >> (32 - n);
 }
 
+// The reference does not look for start codes, it HUNTS for markers bit by bit (MpegDecoder::run, player.cpp:1360-1363):
+//   while (peek_bits(24) == 0) get_bit();   get_bits(24);   marker(get_bits(8));
+// -- the 24 bits are not compared with 00 00 01.  After a header whose fields it has consumed (or ignored: user data,
+// extension, a picture header of a type other than I / P, player.cpp:710-717,1328-1330) the hunt therefore arrives at
+// the next real start code only if everything in between is zero bits, or is swallowed in 32-bit steps whose last byte
+// is a marker value without effect (a slice row beyond the picture, user data, extension, an unknown code).  This
+// restates the hunt from stream-relative bit `bit` and says whether it reaches the start code whose value byte is at
+// next_off - 1 exactly; if not the reference decodes something else from here on (a phantom picture, a slice parsed
+// from the middle of a header ...) which this decoder, indexing byte-aligned start codes, does not reproduce: the
+// stream gets EFX_STREAM_SERIAL_HUNT.
+__device__ inline bool hunt_arrives(const uint8_t* base, uint32_t bit, uint32_t next_off)
+{
+    const uint32_t target = next_off * 8;  // position after the next unit's start code
+    for (int step = 0; step < 4096; step++) {
+        // first set bit at or after `bit` (the '1' of the next start code at the latest)
+        uint32_t f = bit;
+        {
+            uint32_t by = f >> 3;
+            uint32_t v = (uint32_t)base[by] & (0xFFu >> (f & 7));
+            while (!v && by + 1 < next_off) {
+                by++;
+                v = base[by];
+            }
+            if (!v)
+                return false;
+            f = by * 8 + (uint32_t)(__clz((int)v) - 24);
+        }
+        const uint32_t at = f - bit >= 24 ? f - 23 : bit;  // zero bits are dropped until the 24-bit window holds a one
+        if (at + 32 == target)
+            return true;
+        if (at + 32 > target)
+            return false;
+        const uint32_t m = load_bits(base, at + 24, 8);
+        if (m < 0x0E || m == 0xB3 || m == 0xB7 || m == 0xB8)
+            return false;  // picture / slice / sequence / sequence_end / group: the reference acts on a phantom
+        bit = at + 32;
+    }
+    return false;
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(64 * kIndexWaves) void k_index(
     const uint8_t* __restrict__ es, const uint64_t* __restrict__ stream_off, int max_pictures, PicInfo* __restrict__ pics,
     SliceTmp* __restrict__ slices_tmp, uint32_t* __restrict__ pic_count, uint32_t* __restrict__ status, uint32_t* __restrict__ qtab,
     const uint32_t* __restrict__ scan_tab, const PesEntry* __restrict__ pes, const uint32_t* __restrict__ pkt_base,
-    const uint32_t* __restrict__ pes_count, int64_t* __restrict__ pts_out, int first_picture, int stream0)
+    const uint32_t* __restrict__ pes_count, int64_t* __restrict__ pts_out, int64_t* __restrict__ pts_newest, int first_picture,
+    int stream0)
 {
     __shared__ uint32_t u_off[kMaxUnitsPerStream];
     __shared__ uint32_t u_info[kMaxUnitsPerStream];
@@ -161,22 +202,39 @@ __global__ __launch_bounds__(64 * kIndexWaves) void k_index(
     __syncthreads();
 
     // ---- 2. lane-parallel header pre-parse -------------------------------------------------
+    // bit 31 of a unit's info: the reference's marker hunt does not get from this unit to the next one (hunt_arrives)
+    constexpr uint32_t kHuntLost = 1u << 31;
+    if (tid == 0)
+        sh_misc[1] = n_units && !hunt_arrives(base, 0, u_off[0]);  // whatever precedes the first start code
     for (uint32_t i = tid; i < n_units; i += 64 * kIndexWaves) {
         const uint32_t off = u_off[i];
         const uint8_t* p = base + off;
         const uint32_t code = p[-1];  // the start code value
-        u_info[i] = code;
+        uint32_t info = code;
+        uint32_t consumed = ~0u;  // bits of the unit the reference reads before it resumes its marker hunt (slices: k_parse)
         if (code == 0x00) {  // picture: temporal_reference 10, type 3, vbv_delay 16, [full_pel 1, f_code 3]
             uint32_t type = load_bits(p, 10, 3);
             uint32_t fp = load_bits(p, 29, 1), fc = load_bits(p, 30, 3);
-            u_info[i] = code | (type << 8) | (fp << 11) | (fc << 12);
+            info = code | (type << 8) | (fp << 11) | (fc << 12);
+            consumed = type == 1 ? 29 : (type == 2 ? 33 : 13);  // player.cpp:704-724
         } else if (code == 0xB3) {  // sequence: 12+12+4+4+18+12 bits, then the two load flags
             uint32_t wdt = load_bits(p, 0, 12), hgt = load_bits(p, 12, 12);
             uint32_t li = load_bits(p, 62, 1);
             uint32_t ln = load_bits(p, li ? 63 + 512 : 63, 1);
             uint32_t bad = (wdt != EFX_FRAME_WIDTH || hgt != EFX_FRAME_HEIGHT);
-            u_info[i] = code | (bad << 16) | (li << 17) | (ln << 18);
+            info = code | (bad << 16) | (li << 17) | (ln << 18);
+            consumed = 64 + 512 * (li + ln);  // player.cpp:658-678
+        } else if (code == 0xB8)
+            consumed = 32;  // player.cpp:680-690
+        else if (code >= 0x0E)
+            consumed = 0;  // user data, extension (player.cpp:1328-1330), unknown codes, slice rows beyond the picture
+                           // (player.cpp:1255-1258): nothing is read
+        if (consumed != ~0u && code != 0xB7 && i + 1 < n_units) {
+            // (a header longer than its unit -- truncated -- has the reference read into the next unit)
+            if (off * 8 + consumed > (u_off[i + 1] - 4) * 8 || !hunt_arrives(base, off * 8 + consumed, u_off[i + 1]))
+                info |= kHuntLost;
         }
+        u_info[i] = info;
     }
     __syncthreads();
 
@@ -192,10 +250,14 @@ __global__ __launch_bounds__(64 * kIndexWaves) void k_index(
         uint32_t seq_flags = 0, seq_off = 0;
         uint16_t nsl = 0;
         bool dead = false;
+        if (sh_misc[1])
+            st |= EFX_STREAM_SERIAL_HUNT;
         for (uint32_t i = 0; i < n_units; i++) {
             uint32_t info = u_info[i], code = info & 0xFF;
             if (code == 0xB7)  // sequence_end: the reference pauses here (player.cpp:1324-1327)
                 break;
+            if (info & kHuntLost)
+                st |= EFX_STREAM_SERIAL_HUNT;
             if (code == 0xB3) {
                 seq_flags = (info >> 17) & 3;
                 seq_off = u_off[i];
@@ -266,6 +328,10 @@ __global__ __launch_bounds__(64 * kIndexWaves) void k_index(
     if (pts_out) {
         const PesEntry* mp = pes + pkt_base[s];
         const uint32_t np = pes_count[s];
+        // the newest PES PTS of this upload, for k_advance: that kernel runs on the reconstruction stream, possibly
+        // after a later upload has recycled this upload's lists -- it must not read them itself
+        if (tid == 0)
+            pts_newest[s] = np ? mp[np - 1].pts : kNoPts;
         for (uint32_t p = tid; p < npics; p += 64 * kIndexWaves) {
             const uint32_t limit = mypics[p].start_off + 1;
             uint32_t a = 0, b = np;  // first entry with es_off > limit
@@ -302,12 +368,12 @@ __global__ __launch_bounds__(64 * kIndexWaves) void k_index(
 //   picture i is reconstructed into slot (pos0 + swaps(i)) % D from slot (pos0 + swaps(i) - 1) % D,
 //   swaps(i) = i + 1 if a PTS was seen before this call, else max(0, i - f), f = first picture with a PTS,
 // (call_pos[2 s] = pos0, call_pos[2 s + 1] = f or -1), patches the PTS of pictures that precede this
-// upload's first PES with the carried one, and advances the state.  Elementary-stream input has no PES
+// upload's first PES with the carried one, and advances the state.  It reads hand-over slot memory only (what k_index
+// left there), never the upload's buffers: an upload two batches on may already be overwriting those.  Elementary-stream input has no PES
 // layer: every picture counts as carrying a PTS (its index).  Runs on the reconstruction stream, which
 // orders the calls.
 __global__ void k_advance(StreamState* __restrict__ state, const uint32_t* __restrict__ pic_count, int64_t* __restrict__ pts,
-                          const PesEntry* __restrict__ pes, const uint32_t* __restrict__ pkt_base,
-                          const uint32_t* __restrict__ pes_count, int stream0, int n_streams, int max_pictures,
+                          const int64_t* __restrict__ pts_newest, int stream0, int n_streams, int max_pictures,
                           int32_t* __restrict__ call_pos)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -325,9 +391,8 @@ __global__ void k_advance(StreamState* __restrict__ state, const uint32_t* __res
             if (f == n && my[i] != -1)
                 f = i;
         }
-        const uint32_t np = pes_count[s];
-        if (np)
-            st.pts_carry = pes[pkt_base[s] + np - 1].pts;
+        if (pts_newest[s] != kNoPts)  // (k_index: newest PES PTS of the upload this call decoded)
+            st.pts_carry = pts_newest[s];
     } else if (!st.pts_seen)
         f = 0;
     call_pos[2 * s] = (int32_t)st.fb_index;

@@ -2,7 +2,7 @@
 //
 // One entry per code word: the code's bits right-aligned in `code`, its length, and the value
 // it stands for.  The decoder builds flat look-up tables from these at context creation
-// (vlc_tables.cpp); the synthetic-stream encoder (gen/efx_gen.cpp) uses them to emit bits.
+// (build_parse_tables, efx_tables.cpp); the synthetic-stream encoder (gen/efx_gen.cpp) uses them to emit bits.
 // The reference carries the same books as packed binary-tree tables (player.cpp:59-116) and
 // as a hand-unrolled prefix decoder for the DCT coefficients (player.cpp:532-644);
 // tests/test_codebook_vs_reference.py walks those and compares them with this file.

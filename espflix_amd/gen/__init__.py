@@ -16,6 +16,8 @@ FLAG_WIDE_SLICES = 4
 FLAG_LONG_SKIPS = 8
 FLAG_FLAT_BRIGHT = 16
 FLAG_RATE_1500K = 32   # mean picture ~6.25 kB (1.5 Mbit/s at 30 Hz, the service's profile)
+FLAG_HUGE_LEVELS = 64  # AC levels up to +-255 / -256, every escape form of player.cpp:1092-1099, coded zeros, runs > 31
+FLAG_ODD_HEADERS = 128  # B / D / reserved picture types on P-coded pictures, user_data / extension units, varying f_code
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libefx_gen.so")

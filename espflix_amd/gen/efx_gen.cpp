@@ -37,7 +37,19 @@ enum : uint32_t {
     FLAG_FLAT_BRIGHT = 16,   // source has flat 255 areas (unclamped DC-only intra blocks)
     FLAG_RATE_1500K = 32,    // quantiser chosen per stream so that the mean picture is ~6.25 kB: the service's
                              // 1.5 Mbit/s at 30 Hz (reference indexer/indexer.cpp:306-309)
+    FLAG_HUGE_LEVELS = 64,   // quantiser_scale 1 (with jumps to 31) on a full-range step / checker / noise source: AC levels
+                             // up to +-255 and -256, i.e. the 16-bit escape forms "000001 run 00 xx" and "... 80 xx"
+                             // (player.cpp:1092-1099); escapes are also forced on levels that have a code, in both
+                             // forms, incl. a coded level 0 and runs beyond 31
+    FLAG_ODD_HEADERS = 128,  // header quirks (player.cpp:704-724,1328-1330): some P-coded pictures carry a B / D / reserved
+                             // picture_coding_type (header ignored, slices decoded with the P books and the f_code of the
+                             // last real P header, which varies from picture to picture); user_data and extension start
+                             // codes after sequence / GOP / picture headers and between slices.  Everything the
+                             // reference's bit-serial marker hunt (player.cpp:1360-1363) walks through is shaped so that
+                             // the hunt arrives at the next real start code: zero bits only after an ignored header,
+                             // user data in 4-byte groups whose last byte is a harmless marker value
 };
+constexpr int kCodedZero = 1 << 20;  // levels[]: a coefficient coded with level 0 (escape "00 00"): decoded, not skipped
 
 struct Lcg {
     uint32_t s;
@@ -161,8 +173,11 @@ inline void idct_pass(int* b, int st, bool final)
 
 inline int clamp248(int v) { return v < 0 ? 0 : (v > 248 ? 248 : v); }
 
-// levels[64] in scan order (levels[0] = DC value for intra).  Writes/adds into dst (stride).
-void reconstruct(const int* levels, bool intra, int qscale, const uint8_t* qm, uint8_t* dst, int stride)
+// levels[64] in scan order (levels[0] = DC value for intra).  Writes/adds into dst (stride) when `commit`.
+// Returns false when a value handed to the decoder's clamp leaves -256..511: the reference clamps through a
+// 768-entry table (PIN, player.cpp:183-236) and reads whatever lies beside it for anything else, so such a
+// block is outside the domain on which the reference is defined (FLAG_HUGE_LEVELS keeps its streams inside).
+bool reconstruct(const int* levels, bool intra, int qscale, const uint8_t* qm, uint8_t* dst, int stride, bool commit = true)
 {
     const Books& B = books();
     int coef[64] = {0};
@@ -175,6 +190,8 @@ void reconstruct(const int* levels, bool intra, int qscale, const uint8_t* qm, u
         int v = levels[n];
         if (!v)
             continue;
+        if (v == kCodedZero)
+            v = 0;  // decoded like any other level (player.cpp:1110-1121): 0 -> +-1 -> ... -> odd
         int zz = kZigZag[n];
         v <<= 1;
         if (!intra)
@@ -189,7 +206,7 @@ void reconstruct(const int* levels, bool intra, int qscale, const uint8_t* qm, u
     // the decoder's "n == 1" shortcut: exactly one coefficient, at scan position 0
     bool dc_only = last == 0 && (intra || levels[0] != 0);
     if (last < 0)
-        return;
+        return true;
     if (dc_only) {
         bool only_first = true;
         for (int n = 1; n < 64; n++)
@@ -197,19 +214,25 @@ void reconstruct(const int* levels, bool intra, int qscale, const uint8_t* qm, u
                 only_first = false;
         if (only_first) {
             int dc = coef[0] >> 8;
-            for (int y = 0; y < 8; y++)
+            for (int y = 0; y < 8 && commit; y++)
                 for (int x = 0; x < 8; x++)
                     dst[y * stride + x] = intra ? (uint8_t)dc : (uint8_t)clamp248(dc + dst[y * stride + x]);
-            return;
+            return true;  // dc + pixel lies in -256..503
         }
     }
     for (int c = 0; c < 8; c++)
         idct_pass(coef + c, 8, false);
     for (int r = 0; r < 8; r++)
         idct_pass(coef + r * 8, 1, true);
+    bool in_range = true;
     for (int y = 0; y < 8; y++)
-        for (int x = 0; x < 8; x++)
-            dst[y * stride + x] = (uint8_t)clamp248(coef[y * 8 + x] + (intra ? 0 : dst[y * stride + x]));
+        for (int x = 0; x < 8; x++) {
+            const int v = coef[y * 8 + x] + (intra ? 0 : dst[y * stride + x]);
+            in_range &= v >= -256 && v <= 511;
+            if (commit)
+                dst[y * stride + x] = (uint8_t)clamp248(v);
+        }
+    return in_range;
 }
 
 // forward DCT of an 8x8 block of ints (orthonormal scaling: DC = 8 x mean)
@@ -252,6 +275,8 @@ struct Encoder {
     {
         rng.s = 0xE5F10000u + stream;
         qscale_base = q_override ? q_override : 4 + (int)(stream & 7);
+        if ((fl & FLAG_HUGE_LEVELS) && !q_override)
+            qscale_base = 1;
         f_code = (stream & 1) ? 2 : 1;
         full_pel = (stream & 7) == 7;
         memcpy(intra_q, efx::kDefaultIntraQ, 64);
@@ -273,6 +298,21 @@ struct Encoder {
                     val = 255;
                 else
                     val = std::min(std::max(val, 16), 235);
+                if (flags & FLAG_HUGE_LEVELS) {
+                    // per 8x8 source block: vertical / horizontal step, checkerboard, impulse, white noise, or the
+                    // smooth texture above -- full range, so that at quantiser_scale 1 the levels leave +-127
+                    uint32_t hb = (uint32_t)((u >> 3) * 2654435761u) ^ (uint32_t)((v >> 3) * 40503u) ^ (k * 97u);
+                    hb = hb * 1664525u + 1013904223u;
+                    switch (hb >> 27) {  // (6 blocks in 32)
+                    case 0: val = (u & 4) ? 255 : 0; break;
+                    case 1: val = (v & 4) ? 0 : 255; break;
+                    case 2: val = ((u ^ v) & 1) ? 250 : 5; break;
+                    case 3: val = ((u & 7) == 3 && (v & 7) == 4) ? 255 : 0; break;
+                    case 4: val = (int)(h >> 24); break;
+                    case 5: val = (int)(rng.next() >> 24); break;  // differs from picture to picture: big residuals
+                    default: break;
+                    }
+                }
                 src.y[y * W + x] = (uint8_t)val;
             }
         for (int y = 0; y < CH; y++)
@@ -323,10 +363,47 @@ struct Encoder {
         bw.put(0, 5);
     }
 
-    void picture_header(int temporal, int type)
+    // FLAG_ODD_HEADERS: user_data / extension units the decoder must pass over (player.cpp:1328-1330).  The
+    // reference does not skip a payload, it resumes its marker hunt INSIDE it (24 bits discarded, 8 bits taken as the
+    // next marker, player.cpp:1360-1363): the user data here is 4-byte groups whose fourth byte is a marker value
+    // without effect (a slice row beyond the picture, user data, extension, an unknown code) and an extension
+    // carries zero bytes only, so the hunt arrives at the next real start code.
+    void odd_units()
+    {
+        if (!(flags & FLAG_ODD_HEADERS))
+            return;
+        const uint32_t r = rng.next();
+        if ((r >> 30) == 0) {
+            bw.start_code(0xB2);
+            static const uint8_t harmless[8] = {'!', 'x', 0xB2, 0xB5, 0xB9, 0xFF, 0x0E, 0xAF};
+            const int groups = 1 + (int)((r >> 8) & 3);
+            for (int g = 0; g < groups; g++) {
+                bw.put('a' + ((r >> (g * 3)) & 15), 8);
+                bw.put('A' + ((r >> (g * 2 + 4)) & 15), 8);
+                bw.put('0' + ((r >> (g + 12)) & 7), 8);
+                bw.put(harmless[(r >> (16 + 3 * g)) & 7], 8);
+            }
+        }
+        if (((r >> 28) & 3) == 1) {
+            bw.start_code(0xB5);
+            for (int z = (int)((r >> 5) & 3); z > 0; z--)
+                bw.put(0, 8);
+        }
+    }
+
+    void picture_header(int temporal, int type, int hdr_type)
     {
         bw.start_code(0x00);
         bw.put(temporal, 10);
+        if (hdr_type != type) {
+            // a picture_coding_type the decoder ignores (player.cpp:710-717): it returns after these 13 bits and its
+            // marker hunt must find nothing but zero bits up to the next start code
+            bw.put(hdr_type, 3);
+            bw.align();
+            for (int z = temporal % 3; z > 0; z--)
+                bw.put(0, 8);
+            return;
+        }
         bw.put(type, 3);
         bw.put(0xFFFF, 16);
         if (type == 2) {
@@ -374,6 +451,30 @@ struct Encoder {
                 run++;
                 continue;
             }
+            if (flags & FLAG_HUGE_LEVELS) {
+                // every form of the escape the decoder accepts (player.cpp:1092-1099): "xx" for -127..127, "00 xx" = 0..255,
+                // "80 xx" = xx - 256 = -256..-1; a quarter of the levels that have a code are escaped as well
+                const uint32_t r = rng.next();
+                const int lv = v == kCodedZero ? 0 : v;
+                const bool has_code = lv != 0 && std::abs(lv) <= 40 && run < 32 && (B.dct_len[run][std::abs(lv)] || (run == 0 && std::abs(lv) == 1));
+                if (!has_code || (r >> 30) == 0) {
+                    bw.put(efx::kDctEscapeCode, efx::kDctEscapeLen);
+                    bw.put(run, 6);
+                    const bool can_short = lv != 0 && lv >= -127 && lv <= 127;
+                    if (can_short && ((r >> 28) & 1))
+                        bw.put(lv & 0xFF, 8);
+                    else if (lv >= 0) {
+                        bw.put(0, 8);
+                        bw.put(lv, 8);
+                    } else {
+                        bw.put(128, 8);
+                        bw.put(lv + 256, 8);
+                    }
+                    first = false;
+                    run = 0;
+                    continue;
+                }
+            }
             int a = std::abs(v);
             if (run == 0 && a == 1) {
                 if (first)
@@ -403,7 +504,7 @@ struct Encoder {
     }
 
     // quantise one block; returns true if any level is non-zero (intra: always true)
-    bool quantise(const int* pix, bool intra, int qscale, int* levels)
+    bool quantise(const int* pix, bool intra, int qscale, int* levels, bool inject = true)
     {
         float F[64];
         fdct(pix, F);
@@ -420,10 +521,37 @@ struct Encoder {
                 l = (int)(F[zz] * 8 / (qscale * qm[zz]));  // dead zone
             if (!(intra && n == 0))
                 l = std::min(std::max(l, -255), 255);
+            if ((flags & FLAG_HUGE_LEVELS) && inject && !(intra && n == 0)) {
+                const uint32_t r = rng.next();
+                if (l <= -250 && (r >> 31))
+                    l = -256;  // "80 00"
+                else if (l == 0 && (r >> 23) == 0)
+                    l = kCodedZero;  // "00 00", one position in 512
+                else if ((r >> 20) == 1)
+                    l = (int)((r >> 8) & 0x1FF) - 256;  // a full-range level anywhere (also behind runs > 31), one in 4096
+            }
             levels[n] = l;
             any |= l != 0;
         }
         return any || intra;
+    }
+
+    // quantise(), and for FLAG_HUGE_LEVELS make sure the decoder's clamp stays inside its table (see reconstruct):
+    // first without the injected levels, then with the AC levels halved until the block fits
+    bool quantise_in_domain(const int* pix, bool intra, int qscale, int* levels, const uint8_t* qm, uint8_t* dp, int dst_st)
+    {
+        bool any = quantise(pix, intra, qscale, levels);
+        if (!(flags & FLAG_HUGE_LEVELS) || reconstruct(levels, intra, qscale, qm, dp, dst_st, false))
+            return any;
+        any = quantise(pix, intra, qscale, levels, false);
+        while (!reconstruct(levels, intra, qscale, qm, dp, dst_st, false)) {
+            any = intra;
+            for (int n = intra ? 1 : 0; n < 64; n++) {
+                levels[n] /= 2;
+                any |= levels[n] != 0;
+            }
+        }
+        return any;
     }
 
     static void plane_ptr(Picture& p, int blk, int mbx, int mby, uint8_t*& ptr, int& stride)
@@ -483,10 +611,11 @@ struct Encoder {
         bw.put(a & ((1 << r) - 1), r);
     }
 
-    void encode_picture(int f, int type, int dxg, int dyg)
+    void encode_picture(int f, int type, int hdr_type, int dxg, int dyg)
     {
         const Books& B = books();
-        picture_header(f, type);
+        picture_header(f, type, hdr_type);
+        odd_units();
         // slice layout: start rows of the slices
         std::vector<int> starts;
         if (flags & FLAG_WIDE_SLICES) {
@@ -499,6 +628,8 @@ struct Encoder {
             int row0 = starts[si], row1 = si + 1 < starts.size() ? starts[si + 1] : MBH;
             int first_mb = row0 * MBW, last_mb = row1 * MBW - 1;
             int qscale = qscale_base;
+            if (si && (flags & FLAG_ODD_HEADERS) && (rng.next() >> 29) == 0)
+                odd_units();
             bw.start_code(row0 + 1);
             bw.put(qscale, 5);
             bw.put(0, 1);  // extra_bit_slice
@@ -539,6 +670,10 @@ struct Encoder {
                 int new_q = qscale;
                 if ((roll & 0x1F00) == 0x1F00)
                     new_q = std::min(std::max(qscale_base + (int)((roll >> 5) & 3) - 1, 1), 31);
+                if ((flags & FLAG_HUGE_LEVELS) && (roll & 0x700) == 0x300) {
+                    static const int jumps[4] = {1, 2, 31, 9};  // 31: the +-2047 / -2048 clamp of player.cpp:1117-1120
+                    new_q = jumps[(roll >> 5) & 3];
+                }
                 bool quant = new_q != qscale;
 
                 if (decision == 0) {  // intra macroblock
@@ -564,7 +699,7 @@ struct Encoder {
                         for (int y = 0; y < 8; y++)
                             for (int x = 0; x < 8; x++)
                                 pix[y * 8 + x] = sp[y * sst + x];
-                        quantise(pix, true, qscale, levels);
+                        quantise_in_domain(pix, true, qscale, levels, intra_q, dp, dst_st);
                         int comp = blk < 4 ? 0 : blk - 3;
                         put_dc(levels[0] - dc_pred[comp], blk < 4);
                         dc_pred[comp] = levels[0];
@@ -616,7 +751,7 @@ struct Encoder {
                         for (int y = 0; y < 8; y++)
                             for (int x = 0; x < 8; x++)
                                 pix[y * 8 + x] = (int)sp[y * sst + x] - (int)dp[y * dst_st + x];
-                        if (quantise(pix, false, new_q, levels[blk]))
+                        if (quantise_in_domain(pix, false, new_q, levels[blk], non_intra_q, dp, dst_st))
                             cbp |= 0x20 >> blk;
                     }
                 }
@@ -671,13 +806,26 @@ struct Encoder {
             make_source(f);
             bw.align();
             pic_offsets.push_back((uint32_t)bw.buf.size());
+            int hdr_type = type;
+            if ((flags & FLAG_ODD_HEADERS) && type == 2) {
+                const int g = f % gop;
+                if (g >= 2 && g % 3 == 2) {
+                    static const int odd[4] = {3, 4, 0, 7};  // B, D, forbidden, reserved
+                    hdr_type = odd[(g / 3 + (int)k) & 3];    // coded as P with the last real P header's f_code
+                } else {
+                    f_code = 1 + (int)((k + (uint32_t)f) % 3 == 0);
+                    full_pel = (k + (uint32_t)f) % 5 == 0;
+                }
+            }
             if ((f % gop) == 0) {
                 sequence_header();
+                odd_units();
                 gop_header(f);
+                odd_units();
             }
             // the picture content moved by (+dxg,+dyg) in source coordinates, i.e. the matching
             // reference block lies at (+dxg,+dyg) relative to the current block
-            encode_picture(f % 1024, type, type == 2 ? dxg : 0, type == 2 ? dyg : 0);
+            encode_picture(f % 1024, type, hdr_type, type == 2 ? dxg : 0, type == 2 ? dyg : 0);
             std::swap(cur, ref);
         }
         bw.align();

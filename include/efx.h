@@ -46,6 +46,12 @@ typedef enum efx_status {
 #define EFX_STREAM_BAD_VLC 8u         /* an invalid code ended a slice early */
 #define EFX_STREAM_MB_OVERRUN 16u     /* a slice ran past the last macroblock row */
 #define EFX_STREAM_COEF_OVERRUN 32u   /* a block ran past 64 coefficients (block dropped) */
+#define EFX_STREAM_SERIAL_HUNT 64u    /* bits the reference's marker hunt (player.cpp:1360-1363: skip zero bits, DISCARD 24 bits, \
+                                         take 8 as the marker) would misread: non-zero bits after a header it ignores (picture \
+                                         types other than I / P, player.cpp:710-717), a user_data / extension payload that is not \
+                                         made of harmless 4-byte groups (player.cpp:1328-1330), bytes ahead of the first start \
+                                         code.  The reference then acts on phantom markers; this decoder indexes byte-aligned \
+                                         start codes, so its output for the stream is NOT the reference's */
 
 typedef enum efx_format {
     EFX_FORMAT_ES = 0, /* raw ISO 11172-2 video elementary stream */

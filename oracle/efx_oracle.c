@@ -749,12 +749,14 @@ static int decode_block(dec_t* d, int blk, int intra)
             if (rl == -1) { /* escape: 6 bit run, 8 or 16 bit level (player.cpp:1092-1099) */
                 run = get_bits(d, 6);
                 v = get_bits(d, 8);
+                int form = v == 0 ? 1 : (v == 128 ? 2 : 0);
                 if (v == 0)
                     v = get_bits(d, 8);
                 else if (v == 128)
                     v = get_bits(d, 8) - 256;
                 else if (v > 128)
                     v -= 256;
+                TRACE(EFXO_T_ESCAPE, form, run, v, 0);
             } else {
                 run = rl >> 8;
                 v = rl & 0xFF;

@@ -2,7 +2,8 @@
 import numpy as np
 
 FRAME_BYTES = 101376
-SYN_FLAGS = [0, 1, 2, 4, 8, 16]   # generator flavours (espflix_amd.gen.FLAG_*)
+SYN_FLAGS = [0, 1, 2, 4, 8, 16, 64, 128]   # generator flavours (espflix_amd.gen.FLAG_*); 64: every escape form of
+                                           # player.cpp:1092-1099, 128: ignored picture types, user data / extension units
 SYN_IDS = [0, 1, 7]               # 7: full_pel_forward = 1, odd ids: forward_f_code = 2
 
 

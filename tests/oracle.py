@@ -54,6 +54,58 @@ def decode(data: np.ndarray, fmt: int, flush_last: bool = True, want_frames: boo
     return n, hashes[:n], pts[:n], (frames[:n] if want_frames else None)
 
 
+def trace_levels(data: np.ndarray, fmt: int) -> dict:
+    """Runs the oracle with its parse trace on (efxo_set_trace) and summarises the AC levels it decoded -- the
+    values of player.cpp:1087-1103 before dequantisation: min / max, how many lie outside -127..127 (only the 16-bit
+    escape forms reach those), coded zeros, -256, the pictures' coding types and the longest zero run."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    st = {"min": 0, "max": 0, "wide": 0, "zero": 0, "m256": 0, "coefs": 0, "max_run": 0, "pic_types": set(), "r_sizes": set(),
+          "full_pel": set(), "abandoned": 0, "bad": 0, "esc_forms": [0, 0, 0], "esc_small_long": 0, "esc_max_run": 0}
+    cur = {"intra": False, "last": -1}
+
+    def cb(_user, kind, a, b, c, e):
+        if kind == 0:      # slice: c = type | full_pel << 4 | r_size << 8 | decoded << 16
+            st["pic_types"].add(c & 15)
+            if (c & 15) != 1:
+                st["r_sizes"].add((c >> 8) & 0xFF)
+                st["full_pel"].add((c >> 4) & 1)
+        elif kind == 1:    # macroblock
+            cur["intra"] = bool(b & 1)
+        elif kind == 3:    # block end
+            cur["last"] = -1
+            if b == -1:
+                st["abandoned"] += 1
+            elif b == -2:
+                st["bad"] += 1
+        elif kind == 4:    # escape: a = form (0 "xx", 1 "00 xx", 2 "80 xx"), b = run, c = level
+            st["esc_forms"][a] += 1
+            st["esc_small_long"] += a != 0 and -127 <= c <= 127   # a level the short form could carry, sent the long way
+            st["esc_max_run"] = max(st["esc_max_run"], b)
+        elif kind == 2:    # coefficient: b = scan position, c = level
+            if cur["intra"] and b == 0 and cur["last"] < 0:
+                cur["last"] = 0
+                return     # intra DC value
+            st["coefs"] += 1
+            st["max_run"] = max(st["max_run"], b - cur["last"] - 1)
+            cur["last"] = b
+            st["min"] = min(st["min"], c)
+            st["max"] = max(st["max"], c)
+            st["wide"] += c > 127 or c < -127
+            st["zero"] += c == 0
+            st["m256"] += c == -256
+
+    FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
+    fn = FN(cb)
+    L = lib()
+    L.efxo_set_trace.argtypes = [FN, C.c_void_p]
+    L.efxo_set_trace(fn, None)
+    try:
+        L.efxo_decode(data.ctypes.data, data.size, fmt, 1, None, None, None, 0)
+    finally:
+        L.efxo_set_trace(FN(), None)
+    return st
+
+
 def ts_to_es(ts: np.ndarray) -> np.ndarray:
     ts = np.ascontiguousarray(ts, dtype=np.uint8)
     out = np.zeros(ts.size, dtype=np.uint8)

@@ -208,3 +208,58 @@ def test_heavily_damaged_streams_come_back(efx, ts_input):
     counts = np.array([dec.picture_count(i) for i in range(len(blobs))])
     assert counts.max() <= 16 and (status != 0).sum() > len(blobs) // 2
     dec.close()
+
+
+def test_bits_the_reference_marker_hunt_would_misread_are_flagged(efx):
+    """The reference hunts for markers bit by bit and discards 24 bits without comparing them with 00 00 01
+    (player.cpp:1360-1363): it passes an ignored picture header, user data or an extension only when what it walks
+    through is zero bits or harmless 4-byte groups (that is how generator flavour 128 writes them: decoded bit-exact,
+    status 0).  Anything else derails it onto phantom markers -- an extra flush_picture(), slices parsed from the
+    middle of a header: the oracle, a bit-serial restatement, follows it there; the HIP path indexes byte-aligned
+    start codes, cannot, and says so: EFX_STREAM_SERIAL_HUNT."""
+    from espflix_amd import gen
+    b = gen.Batch(0, 8, 12, 12, gen.FLAG_ODD_HEADERS)
+    clean = [b.es(k) for k in range(8)]
+    assert all(st == 0 for _, st, _ in run(efx, clean))
+
+    es = clean[0].tobytes()
+    user = es.index(b"\x00\x00\x01\xb2")
+    user_end = es.index(b"\x00\x00\x01", user + 4)
+    ext = es.index(b"\x00\x00\x01\xb5")
+    # a picture header of an ignored type: 13 bits, then zero padding up to the next start code
+    odd = next(o for o in _picture_headers(es) if ((es[o + 5] >> 3) & 7) not in (1, 2))
+    real_b_header = bytearray(es)
+    real_b_header[odd + 5] |= 0x07            # vbv_delay as a B picture carries it: the hunt reads 24 bits of it as a start code
+    variants = {
+        "user data of 4 n + 1 bytes": es[:user + 4] + b"Z" + es[user + 4:],
+        "user data whose fourth byte is a slice code": es[:user + 7] + b"\x03" + es[user + 8:],
+        "extension with a payload": es[:ext + 4] + b"\x12\x34" + es[ext + 4:],
+        "B header with its real fields": bytes(real_b_header),
+        "bytes ahead of the first start code": b"\x55\xAA\x01" + es,
+    }
+    harmless = {
+        "zero bytes ahead of the first start code": b"\x00" * 7 + es,
+        "zero stuffing after user data": es[:user_end] + b"\x00" * 5 + es[user_end:],
+    }
+    names = list(variants) + list(harmless)
+    res = run(efx, [np.frombuffer(v, dtype=np.uint8) for v in list(variants.values()) + list(harmless.values())])
+    for name, (n, st, hashes) in zip(names, res):
+        if name in variants:
+            assert st & efx.STREAM_SERIAL_HUNT, name
+        else:
+            assert st == 0, name
+            _, h, _, _ = oracle.decode(np.frombuffer(harmless[name], dtype=np.uint8), 0)
+            assert hashes == [int(x) for x in h], name
+    # and the flag is not cosmetic: on the derailed streams the reference (its restatement) really decodes something else
+    _, h0, _, _ = oracle.decode(clean[0], 0)
+    n1, h1, _, _ = oracle.decode(np.frombuffer(variants["B header with its real fields"], dtype=np.uint8), 0)
+    assert n1 != len(h0) or [int(x) for x in h1] != [int(x) for x in h0]
+
+
+def _picture_headers(es: bytes):
+    at = -1
+    while True:
+        at = es.find(b"\x00\x00\x01\x00", at + 1)
+        if at < 0:
+            return
+        yield at

@@ -49,6 +49,34 @@ def test_synthetic_streams(flags, golden):
         assert hx(h2) == g["hashes"]
 
 
+def test_fixture_coverage_escape_levels_and_header_quirks():
+    """What the two quirk flavours are FOR, checked on the oracle's parse trace (so that a change of the generator
+    cannot quietly empty the fixture): flavour 64 reaches every form of the escape level of player.cpp:1092-1099 --
+    "xx", "00 xx" (128..255, also small levels and 0 the long way) and "80 xx" (-256..-129, also -128..-1) -- and zero
+    runs beyond 31; flavour 128 carries B / D / forbidden / reserved picture types whose slices decode with the P
+    books (player.cpp:710-717,1292) under f_code and full_pel values that change from one real P header to the next."""
+    b = gen.Batch(0, 8, 12, 12, gen.FLAG_HUGE_LEVELS)
+    for k in common.SYN_IDS:
+        t = oracle.trace_levels(b.es(k), 0)
+        assert t["max"] == 255 and t["min"] == -256 and t["m256"] > 0 and t["zero"] > 0 and t["wide"] > 300
+        assert min(t["esc_forms"]) > 1000 and t["esc_small_long"] > 1000 and t["esc_max_run"] == 63
+        assert t["abandoned"] == 0 and t["bad"] == 0
+    # the other flavours and both clips stay inside -127..127: without flavour 64 the 16-bit forms are never decoded
+    assert oracle.trace_levels(gen.Batch(0, 1, 12, 12, 0).es(0), 0)["esc_forms"][1:] == [0, 0]
+    b = gen.Batch(0, 8, 12, 12, gen.FLAG_ODD_HEADERS)
+    types, r_sizes, full = set(), set(), set()
+    for k in range(8):
+        es = b.es(k)
+        t = oracle.trace_levels(es, 0)
+        types |= t["pic_types"]
+        r_sizes |= t["r_sizes"]
+        full |= t["full_pel"]
+        assert t["bad"] == 0
+        raw = es.tobytes()
+        assert raw.count(b"\x00\x00\x01\xb2") > 0 and raw.count(b"\x00\x00\x01\xb5") > 0
+    assert types == {0, 1, 2, 3, 4, 7} and r_sizes == {0, 1} and full == {0, 1}
+
+
 def test_composite_fields(golden):
     _, _, _, frames = oracle.decode(gen.Batch(0, 1, 12, 12, 0).ts(0), 1, want_frames=True)
     inputs = {"lcg": common.lcg_frames(), "random": common.random_frames(7),
