@@ -202,39 +202,40 @@ __global__ __launch_bounds__(64 * kIndexWaves) void k_index(
     __syncthreads();
 
     // ---- 2. lane-parallel header pre-parse -------------------------------------------------
-    // bit 31 of a unit's info: the reference's marker hunt does not get from this unit to the next one (hunt_arrives)
-    constexpr uint32_t kHuntLost = 1u << 31;
+    // sh_misc[1]: index of the first unit from which the reference's marker hunt does not get to the next one
+    // (hunt_arrives; 0 also stands for whatever precedes the first start code)
     if (tid == 0)
-        sh_misc[1] = n_units && !hunt_arrives(base, 0, u_off[0]);  // whatever precedes the first start code
+        sh_misc[1] = (n_units && !hunt_arrives(base, 0, u_off[0])) ? 0u : ~0u;
+    __syncthreads();
     for (uint32_t i = tid; i < n_units; i += 64 * kIndexWaves) {
         const uint32_t off = u_off[i];
         const uint8_t* p = base + off;
         const uint32_t code = p[-1];  // the start code value
-        uint32_t info = code;
-        uint32_t consumed = ~0u;  // bits of the unit the reference reads before it resumes its marker hunt (slices: k_parse)
+        u_info[i] = code;  // (stored at once and overwritten below: with the value kept in a register until the end of
+                           // the loop body hipcc 7.2 left it undefined for codes B4..B7 -- stale infos, phantom slices)
+        // bits of the unit the reference reads before it resumes its marker hunt: user data, extension (player.cpp:1328-1330),
+        // unknown codes and slice rows beyond the picture (player.cpp:1255-1258) nothing; a slice in the picture: k_parse's
+        // business
+        uint32_t consumed = code >= 0x0E ? 0u : ~0u;
         if (code == 0x00) {  // picture: temporal_reference 10, type 3, vbv_delay 16, [full_pel 1, f_code 3]
             uint32_t type = load_bits(p, 10, 3);
             uint32_t fp = load_bits(p, 29, 1), fc = load_bits(p, 30, 3);
-            info = code | (type << 8) | (fp << 11) | (fc << 12);
+            u_info[i] = code | (type << 8) | (fp << 11) | (fc << 12);
             consumed = type == 1 ? 29 : (type == 2 ? 33 : 13);  // player.cpp:704-724
         } else if (code == 0xB3) {  // sequence: 12+12+4+4+18+12 bits, then the two load flags
             uint32_t wdt = load_bits(p, 0, 12), hgt = load_bits(p, 12, 12);
             uint32_t li = load_bits(p, 62, 1);
             uint32_t ln = load_bits(p, li ? 63 + 512 : 63, 1);
             uint32_t bad = (wdt != EFX_FRAME_WIDTH || hgt != EFX_FRAME_HEIGHT);
-            info = code | (bad << 16) | (li << 17) | (ln << 18);
+            u_info[i] = code | (bad << 16) | (li << 17) | (ln << 18);
             consumed = 64 + 512 * (li + ln);  // player.cpp:658-678
         } else if (code == 0xB8)
             consumed = 32;  // player.cpp:680-690
-        else if (code >= 0x0E)
-            consumed = 0;  // user data, extension (player.cpp:1328-1330), unknown codes, slice rows beyond the picture
-                           // (player.cpp:1255-1258): nothing is read
         if (consumed != ~0u && code != 0xB7 && i + 1 < n_units) {
             // (a header longer than its unit -- truncated -- has the reference read into the next unit)
             if (off * 8 + consumed > (u_off[i + 1] - 4) * 8 || !hunt_arrives(base, off * 8 + consumed, u_off[i + 1]))
-                info |= kHuntLost;
+                atomicMin(&sh_misc[1], i);
         }
-        u_info[i] = info;
     }
     __syncthreads();
 
@@ -250,14 +251,13 @@ __global__ __launch_bounds__(64 * kIndexWaves) void k_index(
         uint32_t seq_flags = 0, seq_off = 0;
         uint16_t nsl = 0;
         bool dead = false;
-        if (sh_misc[1])
-            st |= EFX_STREAM_SERIAL_HUNT;
+        const uint32_t hunt_lost_at = sh_misc[1];
         for (uint32_t i = 0; i < n_units; i++) {
             uint32_t info = u_info[i], code = info & 0xFF;
+            if (i >= hunt_lost_at)
+                st |= EFX_STREAM_SERIAL_HUNT;
             if (code == 0xB7)  // sequence_end: the reference pauses here (player.cpp:1324-1327)
                 break;
-            if (info & kHuntLost)
-                st |= EFX_STREAM_SERIAL_HUNT;
             if (code == 0xB3) {
                 seq_flags = (info >> 17) & 3;
                 seq_off = u_off[i];

@@ -63,9 +63,15 @@ struct BitWriter {
     std::vector<uint8_t> buf;
     uint64_t acc = 0;
     int n = 0;
+    int zrun = 0;  // zero bits at the end of what has been written
     void put(uint32_t v, int len)
     {
-        acc = (acc << len) | (v & ((len >= 32) ? 0xFFFFFFFFu : ((1u << len) - 1)));
+        v &= (len >= 32) ? 0xFFFFFFFFu : ((1u << len) - 1);
+        if (v == 0)
+            zrun += len;
+        else
+            zrun = __builtin_ctz(v);
+        acc = (acc << len) | v;
         n += len;
         while (n >= 8) {
             buf.push_back((uint8_t)(acc >> (n - 8)));
@@ -457,7 +463,15 @@ struct Encoder {
                 const uint32_t r = rng.next();
                 const int lv = v == kCodedZero ? 0 : v;
                 const bool has_code = lv != 0 && std::abs(lv) <= 40 && run < 32 && (B.dct_len[run][std::abs(lv)] || (run == 0 && std::abs(lv) == 1));
-                if (!has_code || (r >> 30) == 0) {
+                // No start code may appear inside a slice: 23 zero bits and a one (the code books alone guarantee that;
+                // the long forms of small levels, which ISO 11172-2 forbids for this very reason, do not).  A code word
+                // whose leading zeros would stretch the zeros already written to 22 is sent as an escape (5 zeros).
+                int lz = 0;
+                if (has_code && !(run == 0 && std::abs(lv) == 1)) {
+                    const int len = B.dct_len[run][std::abs(lv)];
+                    lz = len - (32 - __builtin_clz((uint32_t)B.dct_code[run][std::abs(lv)]));
+                }
+                if (!has_code || (r >> 30) == 0 || bw.zrun + lz >= 22) {
                     bw.put(efx::kDctEscapeCode, efx::kDctEscapeLen);
                     bw.put(run, 6);
                     const bool can_short = lv != 0 && lv >= -127 && lv <= 127;
@@ -525,13 +539,24 @@ struct Encoder {
                 const uint32_t r = rng.next();
                 if (l <= -250 && (r >> 31))
                     l = -256;  // "80 00"
-                else if (l == 0 && (r >> 23) == 0)
-                    l = kCodedZero;  // "00 00", one position in 512
                 else if ((r >> 20) == 1)
                     l = (int)((r >> 8) & 0x1FF) - 256;  // a full-range level anywhere (also behind runs > 31), one in 4096
             }
             levels[n] = l;
             any |= l != 0;
+        }
+        if ((flags & FLAG_HUGE_LEVELS) && inject) {
+            // a coefficient coded with level 0 ("00 00": 16 zero bits) only behind the last one, where end_of_block ("10")
+            // follows: anything else could complete a start code
+            const uint32_t r = rng.next();
+            int last = intra ? 0 : -1;
+            for (int n = 0; n < 64; n++)
+                if (levels[n] && !(intra && n == 0))
+                    last = n;
+            if ((r >> 28) == 0 && last < 63) {
+                levels[last + 1 + (int)((r >> 8) % (uint32_t)(63 - last))] = kCodedZero;
+                any = true;
+            }
         }
         return any || intra;
     }
