@@ -76,7 +76,7 @@ class _Timing(C.Structure):
     _fields_ = [("index_ms", C.c_float), ("parse_ms", C.c_float), ("recon_ms", C.c_float), ("total_ms", C.c_float),
                 ("pictures", C.c_uint64), ("slices", C.c_uint64), ("coefficients", C.c_uint64), ("es_bytes", C.c_uint64),
                 ("demux_ms", C.c_float), ("timed_calls", C.c_uint32), ("ts_bytes", C.c_uint64), ("groups", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("parse_halves", C.c_uint16), ("mixed", C.c_uint16)]
 
 
 # every symbol include/efx.h declares: (name, restype, argtypes)
@@ -200,7 +200,9 @@ class Timing:
     demux_ms: float = 0.0
     ts_bytes: int = 0
     timed_calls: int = 0
-    groups: int = 1  # a call runs as this many groups of streams (stage times are sums over them)
+    groups: int = 1  # reconstruction groups of the newest call: one k_recon launch per group and picture index
+    parse_halves: int = 1  # parse halves of the newest call (side by side on the parse streams)
+    mixed: int = 0   # 1: the averaged calls did not all run with that structure
 
 
 class DeviceBuffer:
@@ -426,4 +428,4 @@ class Decoder:
         t = _Timing()
         _check(self._ctx, self._lib.efx_get_timing(self._ctx, C.byref(t)))
         return Timing(t.index_ms, t.parse_ms, t.recon_ms, t.total_ms, t.pictures, t.slices, t.coefficients, t.es_bytes,
-                      t.demux_ms, t.ts_bytes, t.timed_calls, max(1, t.groups))
+                      t.demux_ms, t.ts_bytes, t.timed_calls, max(1, t.groups), max(1, t.parse_halves), t.mixed)

@@ -9,6 +9,7 @@
 #include <thread>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -48,7 +49,11 @@ using namespace efx;
 #define EFX_SLOTS 3
 #endif
 constexpr int kParseStreams = EFX_PARSE_STREAMS;  // parse halves in flight at once (latency-bound kernels: two overlap well)
-constexpr int kMaxGroups = 16;      // an efx_decode call runs as up to this many groups of streams, one after the other
+constexpr int kMaxGroups = 16;      // an efx_decode call parses its streams in up to this many parse halves
+#ifndef EFX_RECON_MERGE
+#define EFX_RECON_MERGE 1
+#endif
+constexpr int kReconMerge = EFX_RECON_MERGE;  // parse halves whose streams are reconstructed by ONE launch per picture index
 #ifndef EFX_GROUP_STREAMS
 #define EFX_GROUP_STREAMS 512
 #endif
@@ -95,6 +100,10 @@ struct efx_ctx {
         hipEvent_t last_read[kParseStreams] = {};       // newest parse half that reads this buffer
         hipEvent_t ev_demux[2] = {nullptr, nullptr};
         bool demux_timed = false;
+        uint32_t* h_hint = nullptr;      // pinned: {slices, streams} of the first parse half of this batch's first decode
+        hipEvent_t hint_ready = nullptr;
+        bool hint_recorded = false;
+        int halves = 0;                  // parse halves its decodes run as, once decided (0: not yet)
     } up[kUploads];
     int cur_up = -1;  // batch the next efx_decode reads
     hipStream_t copy_stream = nullptr;
@@ -129,28 +138,32 @@ struct efx_ctx {
         int64_t* d_pts = nullptr;    // per (stream, picture): PTS latched at the picture header (TS input); then, per
                                      // stream, the newest PES PTS of the upload (k_index -> k_advance)
         int32_t* d_call_pos = nullptr;  // per stream: ring position of this call's first picture, first picture with a PTS
-        hipEvent_t parse_done = nullptr, recon_done = nullptr;
+        hipEvent_t parse_done[kReconMerge] = {}, recon_done = nullptr;
         int epoch = 0;
         int upload = 0;  // batch this call decoded
     } slot[kSlots];
     // stage timing: one event set per efx_decode call since efx_set_timing(1), so that a run of
     // back-to-back (overlapping) calls can be averaged afterwards without a host sync in between
     struct TimingEvents {
-        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // parse start, index end, parse end, recon end, recon start
+        // per parse half: parse start, index end, parse end (its parse stream); the first half of a reconstruction group
+        // also carries that group's recon end [3] and recon start [4] (context stream)
+        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     };
     std::vector<TimingEvents> timing_ring;  // kTimingRing x kMaxGroups sets, created by efx_set_timing
     uint64_t timed_calls = 0;               // calls recorded since timing was (re-)enabled
     struct Group {
         int slot, first, count;  // hand-over slot, streams [first, first + count)
+        int half0, halves;       // its parse halves (their counters: d_counters[half0 ...])
     };
-    Group groups[kMaxGroups];  // of the most recent efx_decode
+    Group groups[kMaxGroups];  // reconstruction groups of the most recent efx_decode
     int n_groups = 0;
     int last_upload = 0;       // batch the most recent efx_decode read
     int last_n_streams = 0;    // ... its stream count and format, as they were when the decode was queued (a later upload may
     bool last_ts_input = false;  // have recycled the Upload record by the time the results are fetched)
-    uint64_t subcalls = 0;     // groups launched so far: group k uses slot k % kSlots and parse stream k % kParseStreams
-    uint8_t timing_groups[kTimingRing] = {};
-    uint32_t* h_hint = nullptr;  // pinned: {slices, streams} of the first group of a recent call (copied back asynchronously)
+    uint64_t subcalls = 0;     // reconstruction groups launched so far: group k uses slot k % kSlots
+    uint64_t parse_calls = 0;  // parse halves launched so far: half k runs on parse stream k % kParseStreams
+    uint8_t timing_groups[kTimingRing] = {};    // parse halves of the timed call
+    uint16_t timing_leaders[kTimingRing] = {};  // bit h: half h is the first of its reconstruction group (carries ev[3], ev[4])
     hipStream_t parse_streams[kParseStreams] = {};
     VideoTables* d_video[2] = {nullptr, nullptr};  // [0] PAL, [1] NTSC
     VideoLineTemplates* d_video_lines[2] = {nullptr, nullptr};
@@ -282,6 +295,25 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess)
             return bail(EFX_ERR_DEVICE);
+        // development aid ("who takes what from whom"): EFX_EXP_PARSE_CUS=n confines the parse
+        // streams to n of the compute units (every 256/n-th one), EFX_EXP_RECON_REST=1 the reconstruction stream to the others
+        const char* exp_cus = getenv("EFX_EXP_PARSE_CUS");
+        int mask_n = exp_cus ? atoi(exp_cus) : 0;
+        hipDeviceProp_t prop;
+        if (mask_n > 0 && hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && mask_n < prop.multiProcessorCount) {
+            const int total = prop.multiProcessorCount, every = total / mask_n;
+            std::vector<uint32_t> pm((total + 31) / 32, 0), rm((total + 31) / 32, 0);
+            for (int c = 0; c < total; c++)
+                (c % every == 0 ? pm : rm)[c / 32] |= 1u << (c % 32);
+            for (auto& ps : ctx->parse_streams)
+                if (hipExtStreamCreateWithCUMask(&ps, (uint32_t)pm.size(), pm.data()) != hipSuccess)
+                    return bail(EFX_ERR_DEVICE);
+            if (getenv("EFX_EXP_RECON_REST") && ctx->own_stream) {
+                (void)hipStreamDestroy(ctx->stream);
+                if (hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)rm.size(), rm.data()) != hipSuccess)
+                    return bail(EFX_ERR_DEVICE);
+            }
+        } else
         for (auto& ps : ctx->parse_streams)
             if (hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, hi) != hipSuccess)
                 return bail(EFX_ERR_DEVICE);
@@ -308,9 +340,6 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
             e = r;
     };
     A(dalloc(&ctx->d_tables, 1));
-    A(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_hint), 2 * sizeof(uint32_t), hipHostMallocDefault));
-    if (ctx->h_hint)
-        ctx->h_hint[0] = ctx->h_hint[1] = 0;
     A(dalloc(&ctx->d_state, n));
     for (auto& u : ctx->up) {
         A(dalloc(&u.d_es, ctx->es_cap));
@@ -319,6 +348,10 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         A(hipHostMalloc(reinterpret_cast<void**>(&u.h_es), ctx->es_cap, hipHostMallocDefault));
         A(hipHostMalloc(reinterpret_cast<void**>(&u.h_meta), meta_bytes(n), hipHostMallocDefault));
         A(hipEventCreateWithFlags(&u.uploaded, hipEventDisableTiming));
+        A(hipEventCreateWithFlags(&u.hint_ready, hipEventDisableTiming));
+        A(hipHostMalloc(reinterpret_cast<void**>(&u.h_hint), 2 * sizeof(uint32_t), hipHostMallocDefault));
+        if (u.h_hint)
+            u.h_hint[0] = u.h_hint[1] = 0;
         for (auto& ev : u.last_read)
             A(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         if (e == hipSuccess)
@@ -333,7 +366,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         A(dalloc(&sl.d_pics, n * P));
         A(dalloc(&sl.d_slices_tmp, n * P * kMaxSlicesPerPicture));
         A(dalloc(&sl.d_qtab, n * P * 64));
-        A(dalloc(&sl.d_slice_base, n * P + 1));
+        A(dalloc(&sl.d_slice_base, n * P + kMaxGroups));  // (one list per parse half, each with an end entry)
         A(dalloc(&sl.d_descs, n * P * kMaxSlicesPerPicture));
         A(dalloc(&sl.d_call_pos, 2 * n));
     }
@@ -369,7 +402,8 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     A(hipMemset(ctx->d_frames, 0, n * D * kFrameBytes));
     for (auto& sl : ctx->slot) {
         A(hipMemset(sl.d_mbrecs, 0, n * P * kMbCount * sizeof(MbRec)));
-        A(hipEventCreateWithFlags(&sl.parse_done, hipEventDisableTiming));
+        for (auto& ev : sl.parse_done)
+            A(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         A(hipEventCreateWithFlags(&sl.recon_done, hipEventDisableTiming));
     }
     if (e != hipSuccess)
@@ -412,6 +446,10 @@ void efx_destroy(efx_ctx* ctx)
             (void)hipHostFree(u.h_es);
         if (u.h_meta)
             (void)hipHostFree(u.h_meta);
+        if (u.h_hint)
+            (void)hipHostFree(u.h_hint);
+        if (u.hint_ready)
+            (void)hipEventDestroy(u.hint_ready);
         hipEvent_t evs[] = {u.uploaded, u.ev_demux[0], u.ev_demux[1]};
         for (auto ev : evs)
             if (ev)
@@ -426,8 +464,9 @@ void efx_destroy(efx_ctx* ctx)
         for (void* b : sb)
             if (b)
                 (void)hipFree(b);
-        if (sl.parse_done)
-            (void)hipEventDestroy(sl.parse_done);
+        for (auto ev : sl.parse_done)
+            if (ev)
+                (void)hipEventDestroy(ev);
         if (sl.recon_done)
             (void)hipEventDestroy(sl.recon_done);
     }
@@ -438,8 +477,6 @@ void efx_destroy(efx_ctx* ctx)
         (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream && ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
-    if (ctx->h_hint)
-        (void)hipHostFree(ctx->h_hint);
     delete ctx;
 }
 
@@ -522,6 +559,10 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
             EFX_HIP(hipEventSynchronize(ev));
     }
     u.valid = false;
+    if (u.hint_recorded)
+        EFX_HIP(hipEventSynchronize(u.hint_ready));  // (the pinned word is about to describe another batch)
+    u.hint_recorded = false;
+    u.halves = 0;
     hipStream_t st = ctx->copy_stream;
     uint8_t* d_dst = is_ts ? ctx->d_ts : u.d_es;
     // small per-stream arrays, pinned: stream_off | perm | ts_len | pkt_base
@@ -718,79 +759,112 @@ int efx_decode_from(efx_ctx* ctx, int first_picture)
         return fail(ctx, EFX_ERR_STATE, "efx_decode: no streams uploaded");
     efx_ctx::Upload& u = ctx->up[ctx->cur_up];
     const int n_all = u.n_streams, P = ctx->cfg.max_pictures, D = ctx->cfg.ring_depth;
+    // Parse halves of this call.  The first decode of an upload runs as the previous upload did (nothing is known about
+    // the new batch yet); it leaves the batch's slice count in a pinned word, and from the second decode of the same
+    // upload on the split is decided from that and stays: the launch structure of a run of calls does not depend on timing.
     int G = 1;
-    if (group_count(n_all) > 1 && ctx->h_hint) {
-        const uint32_t hint_slices = ctx->h_hint[0], hint_streams = ctx->h_hint[1];
-        if (hint_slices && hint_streams && (double)u.es_used * hint_streams / n_all / hint_slices < kGroupMaxSliceBytes)
-            G = group_count(n_all);
+    if (u.halves)
+        G = u.halves;
+    else if (group_count(n_all) > 1) {
+        const efx_ctx::Upload& prev = ctx->up[(ctx->cur_up + kUploads - 1) % kUploads];
+        const efx_ctx::Upload* src = u.hint_recorded ? &u : (prev.hint_recorded ? &prev : nullptr);
+        if (src) {
+            EFX_HIP(hipEventSynchronize(src->hint_ready));  // (index stage of an earlier call: long done)
+            const uint32_t hint_slices = src->h_hint[0], hint_streams = src->h_hint[1];
+            if (hint_slices && hint_streams && (double)u.es_used * hint_streams / n_all / hint_slices < kGroupMaxSliceBytes)
+                G = group_count(n_all);
+            if (src == &u)
+                u.halves = G;
+        }
     }
     hipStream_t sr = ctx->stream;
     int timing_slot = -1;
     if (ctx->timing && !ctx->timing_ring.empty()) {
         timing_slot = (int)(ctx->timed_calls++ % kTimingRing);
         ctx->timing_groups[timing_slot] = (uint8_t)G;
+        ctx->timing_leaders[timing_slot] = 0;
     }
-    ctx->n_groups = G;
     ctx->last_upload = ctx->cur_up;
     ctx->last_n_streams = u.n_streams;
     ctx->last_ts_input = u.ts_input;
-    for (int g = 0; g < G; g++) {
-        const int s0 = group_first(n_all, G, g), n = group_first(n_all, G, g + 1) - s0;
-        const int pi = (int)(ctx->subcalls % kParseStreams);
-        hipStream_t sp = ctx->parse_streams[pi];
+    // G parse halves; kReconMerge consecutive halves form one reconstruction group: they parse side by side on the parse
+    // streams into disjoint stream ranges of ONE hand-over slot, and one k_recon launch per picture index covers them all
+    // (a launch is a barrier: the fewer and fatter the launches, the smaller the share of their draining tails)
+    const int R = (G + kReconMerge - 1) / kReconMerge;
+    ctx->n_groups = R;
+    for (int r = 0; r < R; r++) {
+        const int h0 = r * kReconMerge, h1 = std::min(G, h0 + kReconMerge);
+        const int rs0 = group_first(n_all, G, h0), rn = group_first(n_all, G, h1) - rs0;
         const int slot = (int)(ctx->subcalls++ % kSlots);
-        ctx->groups[g] = {slot, s0, n};
+        ctx->groups[r] = {slot, rs0, rn, h0, h1 - h0};
         efx_ctx::Slot& sl = ctx->slot[slot];
         sl.upload = ctx->cur_up;
-        DecodeCounters* counters = sl.d_counters + g;
-
-        // ---- parse half (parse stream): index -> slice list -> VLC parse ---------------------------------------
-        EFX_HIP(hipStreamWaitEvent(sp, u.uploaded, 0));     // the batch is in HBM (H2D and k_demux on the copy stream)
-        EFX_HIP(hipStreamWaitEvent(sp, sl.recon_done, 0));  // the group kSlots back has released this slot
         // macroblock records carry the epoch that wrote them; recycle the tag space by clearing
-        if (++sl.epoch > 255) {
-            EFX_HIP(hipMemsetAsync(sl.d_mbrecs, 0, (size_t)ctx->cfg.max_streams * P * kMbCount * sizeof(MbRec), sp));
+        const bool wrap = ++sl.epoch > 255;
+        if (wrap)
             sl.epoch = 1;
-        }
-        efx_ctx::TimingEvents* te = timing_slot >= 0 ? &ctx->timing_ring[(size_t)timing_slot * kMaxGroups + g] : nullptr;
-        if (te && !te->ev[0])
-            for (auto& ev : te->ev)
-                EFX_HIP(hipEventCreate(&ev));
-        if (te)
-            EFX_HIP(hipEventRecord(te->ev[0], sp));
-        hipLaunchKernelGGL(k_index, dim3(n), dim3(64 * kIndexWaves), 0, sp, u.d_es, u.d_stream_off, P, sl.d_pics, sl.d_slices_tmp, sl.d_pic_count,
-                           sl.d_status, sl.d_qtab, ctx->d_tables->scan, u.d_pes, u.d_pkt_base, u.d_pes_count,
-                           u.ts_input ? sl.d_pts : nullptr, u.ts_input ? sl.d_pts + (size_t)ctx->cfg.max_streams * P : nullptr,
-                           first_picture, s0);
-        hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, sl.d_pics, sl.d_pic_count, n, P, u.d_stream_perm + s0,
-                           sl.d_slice_base, counters);
-        hipLaunchKernelGGL(k_slice_emit, dim3((n * P * kMaxSlicesPerPicture + 255) / 256), dim3(256), 0, sp, sl.d_pics,
-                           sl.d_slices_tmp, sl.d_pic_count, u.d_stream_off, sl.d_slice_base, n, P, u.d_stream_perm + s0, sl.d_descs);
-        if (g == 0 && ctx->h_hint)
-            EFX_HIP(hipMemcpyAsync(ctx->h_hint, counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, sp));
-        if (te)
-            EFX_HIP(hipEventRecord(te->ev[1], sp));
-        const int max_slices = n * P * kMaxSlicesPerPicture;
-        hipLaunchKernelGGL(k_parse, dim3((max_slices + 255) / 256), dim3(256), 0, sp, u.d_es, sl.d_descs, counters, ctx->d_tables,
-                           sl.d_mbrecs, sl.d_coefs, sl.d_status, P, sl.epoch);
-        if (te)
-            EFX_HIP(hipEventRecord(te->ev[2], sp));
-        EFX_HIP(hipEventRecord(sl.parse_done, sp));
-        EFX_HIP(hipEventRecord(u.last_read[pi], sp));  // the bitstream buffer is free for the upload after next
+        efx_ctx::TimingEvents* te0 = nullptr;
+        for (int g = h0; g < h1; g++) {
+            const int s0 = group_first(n_all, G, g), n = group_first(n_all, G, g + 1) - s0;
+            const int pi = (int)(ctx->parse_calls++ % kParseStreams);
+            hipStream_t sp = ctx->parse_streams[pi];
+            DecodeCounters* counters = sl.d_counters + g;
+            uint32_t* slice_base = sl.d_slice_base + (size_t)s0 * P + g;               // this half's own lists
+            SliceDesc* descs = sl.d_descs + (size_t)s0 * P * kMaxSlicesPerPicture;
 
-        // ---- reconstruction half (context stream): one launch per picture index ------------------------------
-        EFX_HIP(hipStreamWaitEvent(sr, sl.parse_done, 0));
-        if (te)
-            EFX_HIP(hipEventRecord(te->ev[4], sr));
+            // ---- parse half (a parse stream): index -> slice list -> VLC parse -----------------------------------
+            EFX_HIP(hipStreamWaitEvent(sp, u.uploaded, 0));     // the batch is in HBM (H2D and k_demux on the copy stream)
+            EFX_HIP(hipStreamWaitEvent(sp, sl.recon_done, 0));  // the group kSlots back has released this slot
+            if (wrap)
+                EFX_HIP(hipMemsetAsync(sl.d_mbrecs + (size_t)s0 * P * kMbCount, 0, (size_t)n * P * kMbCount * sizeof(MbRec), sp));
+            efx_ctx::TimingEvents* te = timing_slot >= 0 ? &ctx->timing_ring[(size_t)timing_slot * kMaxGroups + g] : nullptr;
+            if (te && !te->ev[0])
+                for (auto& ev : te->ev)
+                    EFX_HIP(hipEventCreate(&ev));
+            if (g == h0)
+                te0 = te;
+            if (te)
+                EFX_HIP(hipEventRecord(te->ev[0], sp));
+            hipLaunchKernelGGL(k_index, dim3(n), dim3(64 * kIndexWaves), 0, sp, u.d_es, u.d_stream_off, P, sl.d_pics, sl.d_slices_tmp,
+                               sl.d_pic_count, sl.d_status, sl.d_qtab, ctx->d_tables->scan, u.d_pes, u.d_pkt_base, u.d_pes_count,
+                               u.ts_input ? sl.d_pts : nullptr, u.ts_input ? sl.d_pts + (size_t)ctx->cfg.max_streams * P : nullptr,
+                               first_picture, s0);
+            hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, sl.d_pics, sl.d_pic_count, n, P, u.d_stream_perm + s0,
+                               slice_base, counters);
+            hipLaunchKernelGGL(k_slice_emit, dim3((n * P * kMaxSlicesPerPicture + 255) / 256), dim3(256), 0, sp, sl.d_pics,
+                               sl.d_slices_tmp, sl.d_pic_count, u.d_stream_off, slice_base, n, P, u.d_stream_perm + s0, descs);
+            if (g == 0 && u.h_hint) {
+                EFX_HIP(hipMemcpyAsync(u.h_hint, counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, sp));
+                EFX_HIP(hipEventRecord(u.hint_ready, sp));
+                u.hint_recorded = true;
+            }
+            if (te)
+                EFX_HIP(hipEventRecord(te->ev[1], sp));
+            const int max_slices = n * P * kMaxSlicesPerPicture;
+            hipLaunchKernelGGL(k_parse, dim3((max_slices / kParseLanes * 64 + 255) / 256), dim3(256), 0, sp, u.d_es, descs, counters,
+                               ctx->d_tables, sl.d_mbrecs, sl.d_coefs, sl.d_status, P, sl.epoch);
+            if (te)
+                EFX_HIP(hipEventRecord(te->ev[2], sp));
+            EFX_HIP(hipEventRecord(sl.parse_done[g - h0], sp));
+            EFX_HIP(hipEventRecord(u.last_read[pi], sp));  // the bitstream buffer is free for the upload after next
+        }
+
+        // ---- reconstruction of the group (context stream): one launch per picture index --------------------------
+        for (int g = h0; g < h1; g++)
+            EFX_HIP(hipStreamWaitEvent(sr, sl.parse_done[g - h0], 0));
+        if (te0) {
+            EFX_HIP(hipEventRecord(te0->ev[4], sr));
+            ctx->timing_leaders[timing_slot] |= (uint16_t)(1u << h0);
+        }
         // ring positions of this call's pictures; the reconstruction stream orders the calls
-        hipLaunchKernelGGL(k_advance, dim3((n + 255) / 256), dim3(256), 0, sr, ctx->d_state, sl.d_pic_count,
-                           u.ts_input ? sl.d_pts : nullptr, u.ts_input ? sl.d_pts + (size_t)ctx->cfg.max_streams * P : nullptr, s0, n,
+        hipLaunchKernelGGL(k_advance, dim3((rn + 255) / 256), dim3(256), 0, sr, ctx->d_state, sl.d_pic_count,
+                           u.ts_input ? sl.d_pts : nullptr, u.ts_input ? sl.d_pts + (size_t)ctx->cfg.max_streams * P : nullptr, rs0, rn,
                            P, sl.d_call_pos);
         for (int p = 0; p < P; p++)
-            hipLaunchKernelGGL(k_recon, dim3(n, (kMbCount * 6 + 63) / 64), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs,
-                               ctx->d_tables->scan, sl.d_qtab, ctx->d_frames, P, D, p, sl.d_call_pos, sl.epoch, s0);
-        if (te)
-            EFX_HIP(hipEventRecord(te->ev[3], sr));
+            hipLaunchKernelGGL(k_recon, dim3(rn, (kMbCount * 6 + 63) / 64), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs,
+                               ctx->d_tables->scan, sl.d_qtab, ctx->d_frames, P, D, p, sl.d_call_pos, sl.epoch, rs0);
+        if (te0)
+            EFX_HIP(hipEventRecord(te0->ev[3], sr));
         EFX_HIP(hipEventRecord(sl.recon_done, sr));
     }
     EFX_HIP(hipGetLastError());
@@ -840,11 +914,13 @@ static int fetch_results(efx_ctx* ctx)
         EFX_HIP(hipMemcpy(ctx->h_call_pos.data() + 2 * f, sl.d_call_pos + 2 * f, 2 * c * sizeof(int32_t), hipMemcpyDeviceToHost));
         if (ts_input)
             EFX_HIP(hipMemcpy(ctx->h_pts.data() + f * P, sl.d_pts + f * P, c * P * sizeof(int64_t), hipMemcpyDeviceToHost));
-        DecodeCounters dc;
-        EFX_HIP(hipMemcpy(&dc, sl.d_counters + g, sizeof(dc), hipMemcpyDeviceToHost));
-        ctx->h_counters.total_slices += dc.total_slices;
-        ctx->h_counters.coefficients += dc.coefficients;
-        ctx->h_counters.macroblocks += dc.macroblocks;
+        for (int h = gr.half0; h < gr.half0 + gr.halves; h++) {
+            DecodeCounters dc;
+            EFX_HIP(hipMemcpy(&dc, sl.d_counters + h, sizeof(dc), hipMemcpyDeviceToHost));
+            ctx->h_counters.total_slices += dc.total_slices;
+            ctx->h_counters.coefficients += dc.coefficients;
+            ctx->h_counters.macroblocks += dc.macroblocks;
+        }
     }
     ctx->results_valid = true;
     return EFX_OK;
@@ -1289,20 +1365,30 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out)
         // a call's stage time = the sum over its groups of streams (they run one after the other on their stream)
         const size_t call = (size_t)((ctx->timed_calls - 1 - k) % kTimingRing);
         const int G = ctx->timing_groups[call];
+        const uint32_t leaders = ctx->timing_leaders[call];
+        int last_leader = 0, n_leaders = 0;
         for (int g = 0; g < G; g++) {
             const efx_ctx::TimingEvents& te = ctx->timing_ring[call * kMaxGroups + g];
             float a = 0, b = 0, c = 0;
             EFX_HIP(hipEventElapsedTime(&a, te.ev[0], te.ev[1]));
             EFX_HIP(hipEventElapsedTime(&b, te.ev[1], te.ev[2]));
-            EFX_HIP(hipEventElapsedTime(&c, te.ev[4], te.ev[3]));
+            if (leaders >> g & 1) {
+                EFX_HIP(hipEventElapsedTime(&c, te.ev[4], te.ev[3]));
+                last_leader = g;
+                n_leaders++;
+            }
             t.index_ms += a / n_timed;
             t.parse_ms += b / n_timed;
             t.recon_ms += c / n_timed;
         }
         float d = 0;
-        EFX_HIP(hipEventElapsedTime(&d, ctx->timing_ring[call * kMaxGroups].ev[0], ctx->timing_ring[call * kMaxGroups + G - 1].ev[3]));
+        EFX_HIP(hipEventElapsedTime(&d, ctx->timing_ring[call * kMaxGroups].ev[0], ctx->timing_ring[call * kMaxGroups + last_leader].ev[3]));
         t.total_ms += d / n_timed;
-        t.groups = (uint32_t)G;
+        if (k == 0) {  // the launch structure of the newest call
+            t.groups = (uint32_t)n_leaders;
+            t.parse_halves = (uint32_t)G;
+        } else if (t.groups != (uint32_t)n_leaders || t.parse_halves != (uint32_t)G)
+            t.mixed = 1;
     }
     t.timed_calls = (uint32_t)n_timed;
     for (int i = 0; i < ctx->n_streams; i++)

@@ -18,6 +18,10 @@ namespace efx {
 constexpr int kMbW = 22, kMbH = 12, kMbCount = 264;
 constexpr int kStride = 528, kStripBytes = 8448, kFrameBytes = 101376;
 constexpr int kMaxSlicesPerPicture = 16;   // slice start codes kept per picture
+#ifndef EFX_PARSE_LANES
+#define EFX_PARSE_LANES 64
+#endif
+constexpr int kParseLanes = EFX_PARSE_LANES;  // slices per k_parse wave (one lane each)
 constexpr int kIndexWaves = 4;             // waves of a k_index workgroup (one workgroup per stream)
 constexpr int kMaxUnitsPerStream = 4096;   // start codes indexed per stream per decode
 constexpr int kCoefsPerEsByte = 3;         // a coefficient costs >= 3 bits (2 + EOB for singletons)

@@ -235,14 +235,30 @@ __device__ inline DctSymbol decode_symbol(uint32_t win, uint32_t ent)
 
 }  // namespace
 
+#ifdef EFX_DEBUG_WAVES
+// development aid (tools/dbg/wave_times.py): per wave of the last k_parse launch, {start, end} of s_memrealtime
+// (100 MHz), picture index | type << 8 | hardware id << 16
+__device__ unsigned long long g_parse_dbg[4 * 16384];
+extern "C" int efx_debug_parse_waves(unsigned long long* dst, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_parse_dbg), n * sizeof(unsigned long long));
+}
+#endif
+
 __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, const SliceDesc* __restrict__ descs,
                                                DecodeCounters* __restrict__ counters,
                                                const ParseTables* __restrict__ gtab, MbRec* __restrict__ mbrecs,
                                                uint32_t* __restrict__ coefs, uint32_t* __restrict__ status,
                                                int max_pictures, int epoch)
 {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool mine = gid < counters->total_slices;
+    // kParseLanes slices per wave: the wave's time is the union of its lanes' control flow (every macroblock, block and
+    // symbol trip is paid by all of them), so fewer slices per wave shorten it -- at the price of more waves
+    const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gid = (gthread >> 6) * kParseLanes + (threadIdx.x & 63);
+    const bool mine = (threadIdx.x & 63) < kParseLanes && gid < counters->total_slices;
+#ifdef EFX_DEBUG_WAVES
+    const unsigned long long dbg_t0 = wall_clock64();
+#endif
     SliceDesc d = {};
     if (mine)
         d = descs[gid];
@@ -250,7 +266,10 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
         return;  // no slice in the whole block: leave before staging tables
     // This kernel is a few thousand long, latency-bound waves and runs next to the (many, short)
     // reconstruction waves of the previous decode call: ask the SIMD arbiter to favour it.
-    __builtin_amdgcn_s_setprio(3);
+#ifndef EFX_PARSE_PRIO
+#define EFX_PARSE_PRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(EFX_PARSE_PRIO);
     __shared__ SharedTables sh;
     {
         // stage the look-up tables: sizeof(ParseTables) is a multiple of 4
@@ -510,6 +529,20 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
             break;
         }
     }
+#ifdef EFX_DEBUG_WAVES
+    {
+        // (the last lane of the wave to get here leaves the wave's end time)
+        const uint32_t w = gthread >> 6;
+        if (w < 16384) {
+            uint32_t hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            g_parse_dbg[4 * w] = dbg_t0;
+            atomicMax(&g_parse_dbg[4 * w + 1], wall_clock64());
+            g_parse_dbg[4 * w + 2] = pic | ((d.pic_code_flags >> 16) & 3) << 8 | ((unsigned long long)hw << 16);
+            g_parse_dbg[4 * w + 3] = n_mbs;
+        }
+    }
+#endif
     if (st)
         atomicOr(&status[d.stream], st);
     atomicAdd(&counters->coefficients, (unsigned long long)n_coefs);

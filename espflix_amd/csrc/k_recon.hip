@@ -132,7 +132,10 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     // What else a lane needs to know about another lane's block (first entry, quantiser) is fetched from that lane's
     // registers (ds_bpermute).  Measured: this layout at 16 / 18 / 19 waves per CU 8.07 / 8.16 / 7.85 M frames/s
     // (19 with the search through ds_bpermute as well), the previous one (9.7 KB, 16 waves) 7.78.
-    __shared__ uint32_t lds[64 * kLaneDwords + 32 + 16];
+#ifndef EFX_RECON_LDS_PAD
+#define EFX_RECON_LDS_PAD 0
+#endif
+    __shared__ uint32_t lds[64 * kLaneDwords + 32 + 16 + EFX_RECON_LDS_PAD];  // (pad: occupancy experiments)
     int16_t* const cfh = reinterpret_cast<int16_t*>(lds);
     uint16_t* const s_pre = reinterpret_cast<uint16_t*>(lds + 64 * kLaneDwords);  // entries before the block in the wave
     uint8_t* const s_zd = reinterpret_cast<uint8_t*>(lds + 64 * kLaneDwords + 32);  // bit 7: an entry sits at scan position 0;

@@ -269,9 +269,12 @@ typedef struct efx_timing {
     float demux_ms;    /* k_demux of the last EFX_FORMAT_TS upload (0 for ES input or timing off at upload) */
     uint32_t timed_calls; /* efx_decode calls averaged in the stage times */
     uint64_t ts_bytes; /* transport-stream bytes of the last upload */
-    uint32_t groups;   /* a call runs as this many groups of streams, one after the other (each one k_index ... k_parse
-                          and one k_recon launch per picture index); the stage times above are sums over them */
-    uint32_t reserved;
+    uint32_t groups;   /* reconstruction groups of the newest call: one k_recon launch per group and picture index; the
+                          stage times above are sums over them */
+    uint16_t parse_halves; /* parse halves (k_index ... k_parse over a range of streams) of the newest call: they run side
+                              by side on the parse streams and feed the reconstruction groups */
+    uint16_t mixed;    /* 1: the averaged calls did not all run with the newest call's structure (the first decodes of an
+                          upload run as the previous upload did): per-launch figures derived from the means are off */
 } efx_timing;
 /* Enable HIP-event timing of the decode stages (events recorded on the kernels' own streams);
  * enabling (again) starts a new averaging window. */
