@@ -63,24 +63,41 @@ def log(msg):
     sys.stderr.flush()
 
 
-def pmc_traffic(kernel, S, P):
+def kernel_sources_digest() -> str:
+    """SHA-1 over the kernel sources (espflix_amd/csrc): what a PMC summary was measured on, and what this run executes."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "espflix_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:12]
+
+
+def pmc_traffic(kernel, S, P, key="kernels"):
     """(HBM bytes per launch of `kernel`, provenance) from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE, separate runs, gfx950 correction applied by
     tools/summarize_profiles.py).  PMC counters cannot be collected from inside this process, so
-    the figure is the one measured on this exact workload (1024 streams x GOP 12), None otherwise."""
-    for name in ("r2_pmc_summary.json", "r1_pmc_summary.json"):
+    the figure is the one measured on this exact workload (1024 streams x GOP 12), None otherwise.
+    The summary records the digest of the kernel sources it was measured on (tools/collect_profiles.sh); when the
+    sources have changed since, the provenance says so and a warning goes to stderr."""
+    for name in ("r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if (S, P) != (1024, 12) or not os.path.exists(path):
             continue
         with open(path) as f:
-            v = json.load(f)["kernels"].get(kernel, {}).get("hbm_traffic_bytes")
-        sha = None
-        try:
-            sha = subprocess.run(["git", "log", "-1", "--format=%h", "--", path], cwd=ROOT, capture_output=True, text=True,
-                                 timeout=10).stdout.strip() or None
-        except (OSError, subprocess.SubprocessError):
-            pass
-        return v, {"file": "profiles/" + name, "commit": sha, "note": "separate rocprofv3 --pmc passes of this command, not this run"}
+            doc = json.load(f)
+        v = doc.get(key, {}).get(kernel, {}).get("hbm_traffic_bytes")
+        if v is None:
+            continue
+        measured_on, now = doc.get("kernel_sources_digest"), kernel_sources_digest()
+        stale = measured_on != now
+        if stale:
+            log(f"warning: {name} was measured on kernel sources {measured_on}, this run executes {now}: roofline.traffic of "
+                f"{kernel} may be out of date (re-run tools/collect_profiles.sh)")
+        return v, {"file": "profiles/" + name, "kernel_sources_digest": measured_on, "this_run": now, "stale": stale,
+                   "note": "separate rocprofv3 --pmc passes of this command, not this run"}
     return None, None
 
 
@@ -169,6 +186,231 @@ def _port_decode(ts):
     import oracle
     n, _, _, _ = oracle.decode(ts, 1, flush_last=True, max_frames=64)
     return n
+
+
+def _bench_line(err: str) -> dict:
+    line = [l for l in err.splitlines() if l.startswith("BENCH")]
+    return dict(x.split("=") for x in line[0].split()[1:]) if line else {}
+
+
+def cpu_baseline_o3(batch, n_streams: int, n_pictures: int, budget_streams: int, seconds: float):
+    """SURVEY 8d's second CPU line: the same unmodified reference sources at -O3 with AVX2 (oracle/Makefile: the binary
+    is built away from this host, so x86-64-v3 instead of -march=native; skipped when the host lacks AVX2)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "efx_ref_decode_o3")
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        flags = ""
+    if not os.path.exists(ref) or not all(f" {x}" in flags for x in ("avx2", "bmi2", "fma")):
+        return None
+    cores, n = usable_cores(), min(n_streams, budget_streams)
+    with tempfile.TemporaryDirectory() as td:
+        lst = os.path.join(td, "list.txt")
+        with open(lst, "w") as f:
+            for i in range(n):
+                path = os.path.join(td, f"{i}.ts")
+                batch.ts(i).tofile(path)
+                f.write(path + "\n")
+        repeat = max(1, int(seconds * cores * 3000 / (n * n_pictures)))
+        try:
+            p = subprocess.run([ref, "bench", str(cores), lst, str(repeat)], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL,
+                               text=True, timeout=150)
+        except subprocess.TimeoutExpired:
+            return None
+    kv = _bench_line(p.stderr)
+    if not kv:
+        return None
+    return {"value": int(kv["pictures"]) / float(kv["seconds"]), "unit": "frames/s", "cores": int(kv["workers"]), "kind": "reference",
+            "build": "-O3 -march=x86-64-v3 (AVX2): the reference sources unmodified, oracle/Makefile",
+            "sample": f"first {n} of the {n_streams} streams x {n_pictures} pictures, {kv['workers']} worker processes, each replays its "
+                      f"share {kv['repeat']}x ({kv['pictures']} pictures in {float(kv['seconds']):.2f} s, {kv['failed']} plays failed)"}
+
+
+def _event_ms(torch, stream, fn, reps):
+    """Mean duration of fn() in ms over `reps` back-to-back calls, measured with HIP events ON the stream the kernels
+    are launched on (the decoder context was created on this torch stream)."""
+    with torch.cuda.stream(stream):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for i in range(reps):
+            fn(i)
+        e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def run_video_out(job, args, S):
+    """BASELINE configs[3] and the SURVEY 8f rows in the driver-timed line: composite fields (NTSC, PAL), the PDM
+    modulator, TS demux and SBC decode over a batch of S streams -- each leg first checked against the goldens the
+    unmodified reference produced (tests/golden/golden.json), then timed with HIP events on the kernels' own stream;
+    next to them the reference's own video_isr() / write_pcm_16() timed on this box's host cores."""
+    import torch
+    import espflix_amd as efx
+    from espflix_amd import gen
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import common  # shared deterministic inputs of the golden vectors (no oracle involved)
+    with open(os.path.join(GOLDEN_DIR, "golden.json")) as f:
+        golden = json.load(f)
+    fnv = lambda a: f"{gen.fnv1a64(a):016x}"
+    stream = torch.cuda.Stream()
+    mk = lambda n, p, d, **kw: efx.Decoder(max_streams=n, max_pictures=p, ring_depth=d, device=torch.cuda.current_device(),
+                                           hip_stream=stream.cuda_stream, **kw)
+    out = {"streams": S, "timing": "HIP events on the stream the kernels run on, mean over back-to-back launches"}
+
+    # ---- composite fields -----------------------------------------------------------------------------------------
+    dec = mk(S, 2, 2)
+    lcg = common.lcg_frames()
+    dec.upload_frame(0, 0, lcg[:FRAME_BYTES])
+    for ntsc in (True, False):
+        vp = efx.video_params(ntsc)
+        n = vp["line_width"] * vp["line_count"]
+        one = dec.alloc(n * 2)
+        got = []
+        for fc in range(3):
+            dec.composite_fields(one, 0, 1, 0, ntsc, fc)
+            dec.sync()
+            got.append(fnv(one.download(np.uint16, n)))
+        one.free()
+        if got != golden["composite"]["lcg:" + ("ntsc" if ntsc else "pal")]:
+            raise SystemExit("parity gate (video_out): composite fields differ from the reference's video_isr()")
+    b = gen.Batch(0, S, 2, 12, 0, max(1, usable_cores()))
+    dec.upload(b.all_es(), 0)
+    dec.decode()
+    slot = dec.picture_slot(1)
+    out["composite"] = {}
+    for ntsc in (True, False):
+        std = "ntsc" if ntsc else "pal"
+        vp = efx.video_params(ntsc)
+        n = vp["line_width"] * vp["line_count"]
+        dst = dec.alloc(S * n * 2)
+        for i in range(3):
+            dec.composite_fields(dst, 0, S, slot, ntsc, i)
+        dec.sync()
+        ms = _event_ms(torch, stream, lambda i: dec.composite_fields(dst, 0, S, slot, ntsc, i), 50)
+        alg = S * (FRAME_BYTES + n * 2)  # SURVEY 8d: the frame read once + every sample of the field written
+        traffic, src = pmc_traffic("efx::k_composite:" + std, 1024, 12, key="video_kernels") if S == 1024 else (None, None)
+        out["composite"][std] = {"fields_per_s": S / ms * 1e3, "ms_per_launch": ms,
+                                 "roofline": {"bound": "hbm", "achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": alg / ms / 1e6 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                                              "algorithmic_bytes_per_launch": alg}}
+        dst.free()
+    dec.close()
+
+    # ---- PDM: golden check, then stream-seconds per second at S and at stream counts that fill the chip ----------------
+    dec = mk(1, 1, 2)
+    pcm = common.pdm_pcm(0, 40)
+    d_pcm, d_state, d_out = dec.alloc(pcm.nbytes), dec.alloc(12), dec.alloc(pcm.size * 4)
+    d_pcm.upload(pcm)
+    d_state.upload(np.zeros(3, dtype=np.int32))
+    dec.pdm(1, d_pcm, pcm.size, d_state, d_out)
+    dec.sync()
+    if fnv(d_out.download(np.uint16, 2 * pcm.size)) != golden["pdm"]["sine220"]:
+        raise SystemExit("parity gate (video_out): PDM words differ from the reference's pdm_second_order()")
+    for bfr in (d_pcm, d_state, d_out):
+        bfr.free()
+    out["pdm"] = {"what": "stream-seconds of 48 kHz audio modulated per second (32 delta-sigma steps per sample, one lane per stream: "
+                          "the recurrence is serial, so the rate grows with the stream count until every SIMD holds waves)", "by_streams": {}}
+    for n_streams, samples in ((S, 48000), (16 * S, 9600), (64 * S, 4800), (256 * S, 2400)):
+        d_pcm, d_state, d_out = dec.alloc(n_streams * samples * 2), dec.alloc(n_streams * 12), dec.alloc(n_streams * samples * 4)
+        one = np.round(8000 * np.sin(2 * np.pi * 220 * np.arange(samples) / 48000)).astype(np.int16)
+        d_pcm.upload(np.tile(one, n_streams))
+        d_state.upload(np.zeros(n_streams * 3, dtype=np.int32))
+        dec.pdm(n_streams, d_pcm, samples, d_state, d_out)
+        dec.sync()
+        ms = _event_ms(torch, stream, lambda i: dec.pdm(n_streams, d_pcm, samples, d_state, d_out), 3)
+        alg = n_streams * samples * 6
+        out["pdm"]["by_streams"][str(n_streams)] = {"samples_per_stream": samples, "ms_per_launch": ms,
+                                                    "stream_seconds_per_s": n_streams * samples / 48000 / ms * 1e3,
+                                                    "achieved_GBs": alg / ms / 1e6, "frac": alg / ms / 1e6 / HBM_PEAK_GBS}
+        for bfr in (d_pcm, d_state, d_out):
+            bfr.free()
+    dec.close()
+
+    # ---- TS demux on the device (SURVEY 8f-1) ---------------------------------------------------------------------------
+    b8 = gen.Batch(0, 8, 12, 12, 0)
+    dec = mk(8, 12, 2)
+    dec.upload([b8.ts(k) for k in range(8)], 1)
+    for k in common.SYN_IDS:
+        if fnv(np.frombuffer(dec.es(k), dtype=np.uint8)) != golden["synthetic"][f"0:{k}"]["es_fnv"]:
+            raise SystemExit("parity gate (video_out): demultiplexed elementary stream differs")
+    dec.close()
+    bS = gen.Batch(0, S, 12, 12, 0, max(1, usable_cores()))
+    ts = [bS.ts(k) for k in range(S)]
+    es_bytes = sum(bS.es(k).size for k in range(S))
+    dec = mk(S, 12, 2, max_stream_bytes=sum(x.size for x in ts) + 4096)
+    dec.set_timing(True)
+    best = None
+    for _ in range(5):
+        dec.upload(ts, 1)
+        dec.decode()
+        t = dec.timing()
+        best = t.demux_ms if best is None else min(best, t.demux_ms)
+    alg = t.ts_bytes + es_bytes
+    out["demux"] = {"ms_per_launch": best, "ts_bytes": int(t.ts_bytes), "es_bytes": int(es_bytes), "ts_GB_per_s": t.ts_bytes / best / 1e6,
+                    "roofline": {"bound": "hbm", "achieved": alg / best / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": alg / best / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": int(alg)}}
+    dec.close()
+
+    # ---- SBC audio decode (SURVEY 8f-3) ---------------------------------------------------------------------------------
+    name, kw, nfr, _ = common.SBC_CASES[1]  # (a case without the probe call: the golden is the whole PCM)
+    gfb = common.sbc_frame_bytes(kw["blocks"], 1, kw["bitpool"])
+    fr = common.sbc_frames(common.seed_of(name), nfr, **kw)
+    dec = mk(1, 1, 2)
+    d_fr, d_st, d_pcm, d_cnt = dec.alloc(fr.size + 16), dec.alloc(efx.sbc_state_bytes()), dec.alloc(nfr * 256 * 2), dec.alloc(4)
+    d_fr.upload(fr)
+    d_st.upload(np.zeros(efx.sbc_state_bytes(), dtype=np.uint8))
+    dec.sbc_decode(1, d_fr, (fr.size + 15) & ~15, gfb, nfr, d_st, d_pcm, nfr * 256, None, d_cnt)
+    dec.sync()
+    cnt = int(d_cnt.download(np.uint32, 1)[0])
+    if fnv(d_pcm.download(np.int16, nfr * 256)[:cnt]) != golden["sbc"][name]:
+        raise SystemExit("parity gate (video_out): SBC PCM differs from the reference's sbc_decoder()")
+    for bfr in (d_fr, d_st, d_pcm, d_cnt):
+        bfr.free()
+    name, kw, _, _ = common.SBC_CASES[0]  # the service's own audio format: 48 kHz mono, 16 blocks, bitpool 28
+    fb = common.sbc_frame_bytes(kw["blocks"], 1, kw["bitpool"])
+    frames = 375  # one second of 48 kHz mono audio
+    one = common.sbc_frames(1, frames, **kw)
+    d_fr, d_st, d_pcm = dec.alloc(S * frames * fb), dec.alloc(S * efx.sbc_state_bytes()), dec.alloc(S * frames * 128 * 2)
+    d_fr.upload(np.tile(one, S))
+    d_st.upload(np.zeros(S * efx.sbc_state_bytes(), dtype=np.uint8))
+    dec.sbc_decode(S, d_fr, frames * fb, fb, frames, d_st, d_pcm, frames * 128)
+    dec.sync()
+    ms = _event_ms(torch, stream, lambda i: dec.sbc_decode(S, d_fr, frames * fb, fb, frames, d_st, d_pcm, frames * 128), 5)
+    alg = S * frames * (fb + 256)
+    out["sbc"] = {"ms_per_launch": ms, "stream_seconds_per_s": S / ms * 1e3, "frames_per_stream": frames,
+                  "roofline": {"bound": "hbm", "achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": alg / ms / 1e6 / HBM_PEAK_GBS,
+                               "note": "frames of a stream are serial (filter memory): one wave per stream"}}
+    dec.close()
+
+    # ---- the reference's own video-out on this box's host cores --------------------------------------------------------------
+    cores = usable_cores()
+    cpu = {}
+    rv, rp = os.path.join(ROOT, "oracle", "_ref", "efx_ref_video"), os.path.join(ROOT, "oracle", "_ref", "efx_ref_pdm")
+    if os.path.exists(rv) and os.path.exists(rp) and not args.no_cpu_baseline:
+        with tempfile.TemporaryDirectory() as td:
+            fpath, ppath = os.path.join(td, "frames.bin"), os.path.join(td, "pcm.bin")
+            lcg.tofile(fpath)
+            common.pdm_pcm(0, 375).tofile(ppath)
+            for ntsc in (1, 0):
+                p = subprocess.run([rv, "bench", fpath, str(ntsc), "40000", str(cores)], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL,
+                                   text=True, timeout=120)
+                kv = _bench_line(p.stderr)
+                if kv:
+                    cpu["composite_" + ("ntsc" if ntsc else "pal")] = {
+                        "value": int(kv["fields"]) / float(kv["seconds"]), "unit": "fields/s", "cores": int(kv["workers"]), "kind": "reference",
+                        "sample": f"video_isr() (src/video.cpp, unmodified, -O2) over {kv['fields']} fields of the LCG frame, "
+                                  f"{kv['workers']} worker processes, {float(kv['seconds']):.2f} s"}
+            p = subprocess.run([rp, "bench", ppath, "800", str(cores)], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True,
+                               timeout=120)
+            kv = _bench_line(p.stderr)
+            if kv:
+                cpu["pdm"] = {"value": int(kv["samples"]) / 48000 / float(kv["seconds"]), "unit": "stream-seconds/s", "cores": int(kv["workers"]),
+                              "kind": "reference",
+                              "sample": f"write_pcm_16() / pdm_second_order() (espflix.ino:73-145, text lifted at build time, -O2) over "
+                                        f"{kv['samples']} samples, {kv['workers']} worker processes, {float(kv['seconds']):.2f} s"}
+    out["cpu_baseline_video"] = cpu or None
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -271,7 +513,10 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
     t = dec.timing()
     stage_ms = np.array([t.index_ms, t.parse_ms, t.recon_ms])
     timed_calls = t.timed_calls
-    groups = max(1, int(getattr(t, "groups", 1)))  # a call runs as this many groups of streams, one launch set each
+    groups = max(1, int(getattr(t, "groups", 1)))  # reconstruction groups: one k_recon launch per group and picture index
+    halves = max(1, int(getattr(t, "parse_halves", groups)))  # parse halves: one k_index ... k_parse sequence each
+    if getattr(t, "mixed", 0):
+        log("warning: the timed calls did not all run with the same launch structure: per-launch figures are approximate")
 
     # the double buffer now holds pictures P-2 and P-1 of every stream: compare them with the reference again
     assert t.pictures == S * P, (t.pictures, S * P)
@@ -334,7 +579,7 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
     with np.errstate(over="ignore"):
         csum = int(np.bitwise_xor.reduce(chains * edist.GOLDEN)) if chains.size else 0
     return {"workload": workload, "S": S, "P": P, "es_bytes": es_bytes, "n_i": n_i, "n_p": n_p, "elapsed": elapsed,
-            "stage_ms": stage_ms, "serial_ms": serial_ms, "timed_calls": timed_calls, "groups": groups, "n_coefs": int(n_coefs),
+            "stage_ms": stage_ms, "serial_ms": serial_ms, "timed_calls": timed_calls, "groups": groups, "halves": halves, "n_coefs": int(n_coefs),
             "gen_seconds": t_gen, "batch0": batches[0][1], "ingest": ingest, "job_pictures": totals[0], "job_es_bytes": totals[1],
             "checksum": csum, "streams_checked": int(chains.size), "first_id": int(ids[0]), "last_id": int(ids[-1])}
 
@@ -424,9 +669,15 @@ def run(job, args):
                                        **stage_report(ow, min(args.steps, 10))}
         others["vmedia_x%d" % S] = run_clip(job, args, "vmedia", S, max(2, min(args.steps, 5)))
 
-    cpu = None
+    video_out = None
+    if world == 1 and job.device == "cuda" and not args.no_video_out:
+        video_out = run_video_out(job, args, S)
+
+    cpu = cpu_o3 = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(r["batch0"], S, P, 1024, args.cpu_baseline_seconds)
+        if job.device == "cuda":
+            cpu_o3 = cpu_baseline_o3(r["batch0"], S, P, 1024, args.cpu_baseline_seconds)
     job.barrier()
 
     if rank != 0:
@@ -471,9 +722,10 @@ def run(job, args):
                              "time, measured after the timed region",
                      "serial_stage_ms": dict(zip(names, [float(x) for x in serial_ms])),
                      "serial_frac": alg / (serial_ms[2] / 1e3) / 1e9 / HBM_PEAK_GBS,
-                     "k_parse": {"algorithmic_bytes_per_launch": parse_bytes / G, "avg_launch_ms": float(stage_ms[1]) / G,
+                     "k_parse": {"algorithmic_bytes_per_launch": parse_bytes / r["halves"], "avg_launch_ms": float(stage_ms[1]) / r["halves"],
+                                 "launches_per_step": r["halves"],
                                  "achieved": parse_bytes / (stage_ms[1] / 1e3) / 1e9,
-                                 "serial_launch_ms": float(serial_ms[1]) / G, "traffic": ptraffic,
+                                 "serial_launch_ms": float(serial_ms[1]) / r["halves"], "traffic": ptraffic,
                                  "bound": "serial symbol chains (VALU issue), not bandwidth"}},
         "parity_gate": {"reference": "tests/golden/bench_gop12.u64 (unmodified reference decoder, tests/golden/make_bench_golden.py)",
                         "streams_checked": r["streams_checked"], "pictures_checked_per_stream": P,
@@ -484,7 +736,9 @@ def run(job, args):
         "ingest": r["ingest"],
         "fixed_batch_8192": fixed,
         "other_workloads": others,
+        "video_out": video_out,
         "cpu_baseline": cpu,
+        "cpu_baseline_o3": cpu_o3,
     }
     return out
 
@@ -511,6 +765,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-fixed-batch", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-video-out", action="store_true", help="skip the composite / PDM / demux / SBC legs (N = 1 only anyway)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=5.0, help="wall-time target of the CPU baseline leg")
     ap.add_argument("--no-overlap", action="store_true", help="synchronise after every step (no cross-step pipelining)")
     ap.add_argument("--timed-only", action="store_true",

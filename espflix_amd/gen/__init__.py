@@ -40,10 +40,18 @@ def _load():
         L.efxgen_batch_es_copy.argtypes = [vp, C.c_int, vp, C.c_uint64]
         L.efxgen_batch_ts.restype = C.c_uint64
         L.efxgen_batch_ts.argtypes = [vp, C.c_int, vp, C.c_uint64]
+        L.efxgen_fnv1a64.restype = C.c_uint64
+        L.efxgen_fnv1a64.argtypes = [vp, C.c_uint64, C.c_uint64]
         L.efxgen_batch_offsets.restype = C.c_int
         L.efxgen_batch_offsets.argtypes = [vp, C.c_int, vp, C.c_int]
         _lib = L
     return _lib
+
+
+def fnv1a64(buf, h: int = 0xCBF29CE484222325) -> int:
+    """FNV-1a-64 of a contiguous array's bytes (the hash of the committed golden vectors)."""
+    a = np.ascontiguousarray(buf)
+    return int(_load().efxgen_fnv1a64(a.ctypes.data, a.nbytes, h))
 
 
 class Batch:

@@ -978,6 +978,17 @@ void* efxgen_batch_create(uint32_t first_id, int n_streams, int n_pictures, int 
 
 void efxgen_batch_destroy(void* h) { delete (Batch*)h; }
 
+// FNV-1a-64 of a byte range (basis cbf29ce484222325, prime 100000001b3), for callers that check bulk
+// output against the committed golden hashes without a byte loop in Python
+uint64_t efxgen_fnv1a64(const uint8_t* p, uint64_t n, uint64_t h)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        h ^= p[i];
+        h *= 0x100000001b3ull;
+    }
+    return h;
+}
+
 uint64_t efxgen_batch_es_size(void* h, int i)
 {
     Batch* b = (Batch*)h;

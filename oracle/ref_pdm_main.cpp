@@ -12,19 +12,29 @@
 //   each call hands to i2s_write.  State (_i0,_i1,_i2) persists across calls as in the sketch.
 //   "silence_every N": every N-th call passes s==0 (PDM silence 0xAAAA, espflix.ino:139-140).
 //   "beep_at K": calls beep() before call K (5 sine bursts, espflix.ino:119-133).
+// Usage: efx_ref_pdm bench <pcm_s16le.bin> <repeat> <workers>
+//   CPU baseline of bench.py's video_out leg: `workers` processes, each feeds the PCM `repeat` times to
+//   write_pcm_16(s,128,1) (output discarded); stderr: BENCH samples=.. seconds=.. workers=..
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
 #include <vector>
+#include <sys/time.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #define PLOG(_x)
 #define portMAX_DELAY 0
 typedef int i2s_port_t;
 static FILE* g_o = 0;
+static volatile unsigned g_sink = 0;
 static int i2s_write(i2s_port_t, const void* src, size_t n, size_t* written, int)
 {
-    fwrite(src, 1, n, g_o);
+    if (g_o)
+        fwrite(src, 1, n, g_o);
+    else
+        g_sink += ((const volatile uint16_t*)src)[n / 2 - 1];  // bench: the words are produced, not kept
     *written = n;
     return 0;
 }
@@ -33,6 +43,35 @@ static int i2s_write(i2s_port_t, const void* src, size_t n, size_t* written, int
 
 int main(int argc, char** argv)
 {
+    if (argc == 5 && !strcmp(argv[1], "bench")) {
+        FILE* f = fopen(argv[2], "rb");
+        if (!f) return 2;
+        std::vector<int16_t> pcm;
+        int16_t buf[128];
+        while (fread(buf, 2, 128, f) == 128) pcm.insert(pcm.end(), buf, buf + 128);
+        fclose(f);
+        const int repeat = atoi(argv[3]);
+        int workers = atoi(argv[4]);
+        if (workers < 1) workers = 1;
+        const int calls = (int)(pcm.size() / 128);
+        struct timeval t0, t1;
+        gettimeofday(&t0, 0);
+        for (int w = 0; w < workers; w++)
+            if (fork() == 0) {
+                for (int r = 0; r < repeat; r++)
+                    for (int c = 0; c < calls; c++)
+                        write_pcm_16(&pcm[c * 128], 128, 1);
+                _exit(0);
+            }
+        for (int w = 0; w < workers; w++) {
+            int st;
+            wait(&st);
+        }
+        gettimeofday(&t1, 0);
+        fprintf(stderr, "BENCH samples=%ld seconds=%.6f workers=%d\n", (long)calls * 128 * repeat * workers,
+                (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec), workers);
+        return 0;
+    }
     if (argc < 3) return 2;
     int silence_every = 0, beep_at = -1;
     for (int i = 3; i + 1 < argc; i += 2) {

@@ -19,6 +19,9 @@
 //        _animate_index is 0); _video_composite (src/video.cpp:841) = the 1280 overlay bytes,
 //        _video_composite_blend / _video_composite_progress as given (the ISR decrements the
 //        blend once per field itself).
+//   efx_ref_video bench <frames.bin> <ntsc:1|0> <nfields> <workers>
+//        CPU baseline of bench.py's video_out leg: `workers` processes, each runs video_isr() for nfields fields
+//        of the two frames (lines kept in memory, nothing written); stderr: BENCH fields=.. seconds=.. workers=..
 //   efx_ref_video params <ntsc:1|0> <out.bin>
 //        dumps int32 {line_width,line_count,hsync,hsync_long,hsync_short,burst_start,
 //        burst_width,active_start} followed by _color_tab[768] (u32) and dither4x4[8] (u32).
@@ -28,6 +31,9 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <sys/time.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "video.h"      // reference header
 #include "streamer.h"
@@ -61,6 +67,41 @@ int main(int argc, char** argv)
         fwrite(_color_tab, 4, 768, f);
         fwrite(dither4x4, 4, 8, f);
         fclose(f);
+        return 0;
+    }
+    if (cmd == "bench" && argc == 6) {
+        static Frame fb[2];
+        fb[0].init();
+        fb[1].init();
+        FILE* f = fopen(argv[2], "rb");
+        if (!f) return 2;
+        for (int k = 0; k < 2; k++)
+            for (int s = 0; s < FB_SLICES; s++)
+                if (fread(fb[k]._slices[s], 1, FB_STRIDE * FB_SLICE_HEIGHT, f) != FB_STRIDE * FB_SLICE_HEIGHT) return 2;
+        fclose(f);
+        video_init(atoi(argv[3]));
+        const int nfields = atoi(argv[4]);
+        int workers = atoi(argv[5]);
+        if (workers < 1) workers = 1;
+        _frames = fb;
+        _current_frame = 0;
+        struct timeval t0, t1;
+        gettimeofday(&t0, 0);
+        for (int w = 0; w < workers; w++)
+            if (fork() == 0) {
+                std::vector<uint16_t> a(_line_width, 0), b(_line_width, 0);
+                for (int fld = 0; fld < nfields; fld++)
+                    for (int l = 0; l < _line_count; l++)
+                        video_isr((l & 1) ? &b[0] : &a[0]);
+                _exit(0);
+            }
+        for (int w = 0; w < workers; w++) {
+            int st;
+            wait(&st);
+        }
+        gettimeofday(&t1, 0);
+        fprintf(stderr, "BENCH fields=%ld seconds=%.6f workers=%d\n", (long)nfields * workers,
+                (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec), workers);
         return 0;
     }
     if ((cmd == "field" && argc == 6) || (cmd == "fieldx" && argc == 11)) {

@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("tag")
 ap.add_argument("--stats", nargs="*", default=[])
 ap.add_argument("--pmc", nargs="*", default=[])
+ap.add_argument("--video-pmc", nargs="*", default=[], help="PMC passes of tools/bench_video.py (k_composite NTSC / PAL, k_pdm ...)")
 ap.add_argument("--note", default="")
 a = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,7 +57,46 @@ for k, cs in summary.items():
         cs["hbm_write_bytes"] = cs["WRITE_SIZE"] * 1024.0
     if "hbm_read_bytes" in cs and "hbm_write_bytes" in cs:
         cs["hbm_traffic_bytes"] = cs["hbm_read_bytes"] + cs["hbm_write_bytes"]
-if summary:
-    json.dump({"note": a.note, "kernels": summary}, open(os.path.join(out, f"{a.tag}_pmc_summary.json"), "w"), indent=1,
-              sort_keys=True)
-    print(json.dumps(summary, indent=1, sort_keys=True))
+# video-out kernels (tools/bench_video.py): one entry per (kernel, grid size) -- k_composite runs with one grid for NTSC
+# (17 blocks of 16 lines per stream) and a larger one for PAL (20)
+video = collections.defaultdict(dict)
+for d in a.video_pmc:
+    rows = collections.defaultdict(list)
+    for f in os.listdir(d):
+        if not f.endswith("counter_collection.csv"):
+            continue
+        for r in csv.DictReader(open(os.path.join(d, f))):
+            k = r["Kernel_Name"].split("(")[0]
+            if k.startswith("efx::"):
+                rows[(k, int(r["Grid_Size"]))].append((r["Counter_Name"], float(r["Counter_Value"])))
+    comp = sorted(g for (k, g) in rows if k == "efx::k_composite")
+    big = [g for g in comp if len(rows[("efx::k_composite", g)]) >= 10]  # (the one-stream gate launches are not the timed ones)
+    for (k, g), rs in rows.items():
+        name = k
+        if k == "efx::k_composite":
+            if g not in big[-2:]:
+                continue
+            name = k + (":ntsc" if g == big[-2] else ":pal")
+        elif len(rs) < 2 and k != "efx::k_pdm":
+            continue
+        cs = collections.defaultdict(list)
+        for c, v in rs:
+            cs[c].append(v)
+        video[name]["grid_size"] = g
+        for c, v in cs.items():
+            video[name][c] = sum(v) / len(v)
+            video[name]["dispatches_" + c] = len(v)
+for k, cs in video.items():
+    if "FETCH_SIZE" in cs:
+        cs["hbm_read_bytes"] = 2.0 * cs["FETCH_SIZE"] * 1024.0
+    if "WRITE_SIZE" in cs:
+        cs["hbm_write_bytes"] = cs["WRITE_SIZE"] * 1024.0
+    if "hbm_read_bytes" in cs and "hbm_write_bytes" in cs:
+        cs["hbm_traffic_bytes"] = cs["hbm_read_bytes"] + cs["hbm_write_bytes"]
+
+if summary or video:
+    sys.path.insert(0, root)
+    import bench  # (kernel_sources_digest: what the counters were measured on; bench.py warns when the sources move on)
+    json.dump({"note": a.note, "kernel_sources_digest": bench.kernel_sources_digest(), "kernels": summary, "video_kernels": video},
+              open(os.path.join(out, f"{a.tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({"kernels": summary, "video_kernels": video}, indent=1, sort_keys=True))
