@@ -7,10 +7,10 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 CSRC     = espflix_amd/csrc
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
-OBJS     = $(CSRC)/efx_api.o $(CSRC)/k_demux.o $(CSRC)/k_index.o $(CSRC)/k_parse.o $(CSRC)/k_recon.o $(CSRC)/k_video.o $(CSRC)/k_sbc.o $(CSRC)/k_tsindex.o $(CSRC)/efx_tables.o
+OBJS     = $(CSRC)/efx_api.o $(CSRC)/k_demux.o $(CSRC)/k_index.o $(CSRC)/k_parse.o $(CSRC)/k_recon.o $(CSRC)/k_video.o $(CSRC)/k_sbc.o $(CSRC)/k_tsindex.o $(CSRC)/efx_tables.o $(CSRC)/efx_multi.o
 
-.PHONY: all lib gen oracle ref clean dropin
-all: lib gen oracle
+.PHONY: all lib gen oracle ref clean dropin scale
+all: lib gen oracle scale
 
 lib: espflix_amd/libefx.so
 gen: espflix_amd/gen/libefx_gen.so
@@ -18,6 +18,8 @@ gen: espflix_amd/gen/libefx_gen.so
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/efx_internal.h include/efx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/efx_tables.o: $(CSRC)/efx_tables.cpp $(CSRC)/efx_internal.h $(CSRC)/mpeg1_codebook.h
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+$(CSRC)/efx_multi.o: $(CSRC)/efx_multi.cpp include/efx.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
 espflix_amd/libefx.so: $(OBJS)
@@ -48,6 +50,12 @@ tests/_build/dropin_long/splash.h: tests/make_dropin_long.py espflix_amd/gen/lib
 	python3 tests/make_dropin_long.py tests/_build/dropin_long
 tests/_build/espflix_dropin_long: tests/_build/dropin_long/splash.h $(DROPIN_SRC)/espflix.cpp tests/dropin_main.cpp include/efx_player.hpp espflix_amd/libefx.so
 	g++ -Itests/_build/dropin_long $(DROPIN_FLAGS) tests/dropin_main.cpp $(DROPIN_SRC)/espflix.cpp $(DROPIN_SRC)/streamer.cpp $(DROPIN_LIBS) -o $@
+
+# the C++ scaling harness over the multi-device C-ABI (efx_multi_*), RCCL for the gather of the chain hashes
+scale: tools/efx_scale
+tools/efx_scale: tools/efx_scale.cpp include/efx.h espflix_amd/libefx.so espflix_amd/gen/libefx_gen.so
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude tools/efx_scale.cpp -Lespflix_amd -lefx -Lespflix_amd/gen -lefx_gen \
+	    -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN/../espflix_amd' -Wl,-rpath,'$$ORIGIN/../espflix_amd/gen' -Wl,-rpath,/opt/rocm/lib -o $@
 
 oracle:
 	$(MAKE) -C oracle port

@@ -117,6 +117,19 @@ _SYMBOLS = {
     "efx_pdm": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
     "efx_set_timing": (C.c_int, [_P, C.c_int]),
     "efx_get_timing": (C.c_int, [_P, C.POINTER(_Timing)]),
+    "efx_partition_first": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "efx_multi_create": (C.c_int, [C.POINTER(_Config), C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
+    "efx_multi_destroy": (None, [_P]),
+    "efx_multi_device_count": (C.c_int, [_P]),
+    "efx_multi_context": (_P, [_P, C.c_int]),
+    "efx_multi_last_error": (C.c_char_p, [_P]),
+    "efx_multi_upload_streams": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t), C.c_int]),
+    "efx_multi_locate": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "efx_multi_decode": (C.c_int, [_P]),
+    "efx_multi_sync": (C.c_int, [_P]),
+    "efx_multi_reset": (C.c_int, [_P]),
+    "efx_multi_results": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
+    "efx_multi_frame_hashes": (C.c_int, [_P, _P]),
     "efx_device_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "efx_device_free": (C.c_int, [_P, _P]),
     "efx_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -429,3 +442,71 @@ class Decoder:
         _check(self._ctx, self._lib.efx_get_timing(self._ctx, C.byref(t)))
         return Timing(t.index_ms, t.parse_ms, t.recon_ms, t.total_ms, t.pictures, t.slices, t.coefficients, t.es_bytes,
                       t.demux_ms, t.ts_bytes, t.timed_calls, max(1, t.groups), max(1, t.parse_halves), t.mixed)
+
+
+def partition_first(total: int, parts: int, part: int) -> int:
+    """First stream of part `part` when `total` streams are dealt to `parts` devices (efx_partition_first): stream k lives on
+    device floor(k * parts / total).  Host-only."""
+    return load_library().efx_partition_first(total, parts, part)
+
+
+class MultiDecoder:
+    """efx_multi: one context and one host thread per device of a node, streams dealt in contiguous blocks (no collective
+    on the data path).  max_streams is the per-device capacity."""
+
+    def __init__(self, devices, max_streams: int, max_pictures: int, ring_depth: int = 2, max_stream_bytes: int = 0):
+        self._lib = load_library()
+        self._m = _P()
+        cfg = _Config(0, max_streams, max_pictures, ring_depth, max_stream_bytes, None)
+        devs = (C.c_int * len(devices))(*devices)
+        st = self._lib.efx_multi_create(C.byref(cfg), devs, len(devices), C.byref(self._m))
+        if st != 0:
+            raise EfxError(st, self._lib.efx_status_string(st).decode())
+        self.ring_depth, self.n_streams = max(2, ring_depth), 0
+
+    def _check(self, st):
+        if st != 0:
+            raise EfxError(st, (self._lib.efx_multi_last_error(self._m) or b"").decode() or self._lib.efx_status_string(st).decode())
+
+    def upload(self, streams, fmt: int = FORMAT_ES):
+        arrs = [np.ascontiguousarray(s, dtype=np.uint8) for s in streams]
+        n = len(arrs)
+        ptrs = (_P * n)(*[a.ctypes.data for a in arrs])
+        lens = (C.c_size_t * n)(*[a.size for a in arrs])
+        self._check(self._lib.efx_multi_upload_streams(self._m, n, ptrs, lens, fmt))
+        self.n_streams = n
+
+    def decode(self, sync: bool = True):
+        self._check(self._lib.efx_multi_decode(self._m))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        self._check(self._lib.efx_multi_sync(self._m))
+
+    def locate(self, stream: int):
+        d, l = C.c_int(), C.c_int()
+        self._check(self._lib.efx_multi_locate(self._m, stream, C.byref(d), C.byref(l)))
+        return d.value, l.value
+
+    def results(self):
+        n = (C.c_int * self.n_streams)()
+        st = (C.c_uint32 * self.n_streams)()
+        self._check(self._lib.efx_multi_results(self._m, n, st))
+        return np.array(n[:]), np.array(st[:])
+
+    def frame_hashes(self) -> np.ndarray:
+        out = np.empty((self.n_streams, self.ring_depth), dtype=np.uint64)
+        self._check(self._lib.efx_multi_frame_hashes(self._m, out.ctypes.data))
+        return out
+
+    def close(self):
+        if self._m:
+            self._lib.efx_multi_destroy(self._m)
+            self._m = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

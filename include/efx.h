@@ -281,6 +281,38 @@ typedef struct efx_timing {
 int efx_set_timing(efx_ctx* ctx, int enable);
 int efx_get_timing(efx_ctx* ctx, efx_timing* out);
 
+/* -- several devices of one node ----------------------------------------------------------------- */
+/* The reference decodes one stream on one core; its batch form here shards by STREAM and nothing else (SURVEY.md 8e,
+ * BASELINE.json north_star): streams are independent, so stream k of a batch of n goes to device floor(k * R / n) of
+ * the R devices -- contiguous blocks -- and no collective touches the data path.  An efx_multi owns one efx_ctx and one
+ * host thread per device (a HIP context is bound to the thread that drives it); every call below fans out to the
+ * devices, each working on its own block, and returns when all of them have QUEUED (decode) or FINISHED (upload,
+ * sync, queries) their part.  The per-device contexts are the ordinary ones: efx_multi_context(m, r) hands out device
+ * r's for everything this section does not wrap (composite fields, PDM, timing ...), to be used from the caller's
+ * thread only while no efx_multi_* call is in flight.  What MpegDecoder::run() is to one stream
+ * (src/player.cpp:1355-1367) efx_multi_decode is to a node's worth of them. */
+typedef struct efx_multi efx_multi;
+/* first stream of part `part` when `total` streams are dealt to `parts` devices: ceil(part * total / parts); part ==
+ * parts gives total.  Pure function (no device needed): the partition the multi-device calls and bench.py use. */
+int efx_partition_first(int total, int parts, int part);
+/* cfg->max_streams is the PER-DEVICE capacity, cfg->device is ignored; devices[r] = HIP ordinal of device r. */
+int efx_multi_create(const efx_config* cfg, const int* devices, int n_devices, efx_multi** out);
+void efx_multi_destroy(efx_multi* m);
+int efx_multi_device_count(const efx_multi* m);
+efx_ctx* efx_multi_context(efx_multi* m, int r);
+const char* efx_multi_last_error(const efx_multi* m);
+/* efx_upload_streams for a batch of n_streams <= n_devices x max_streams streams, dealt as above */
+int efx_multi_upload_streams(efx_multi* m, int n_streams, const uint8_t* const* data, const size_t* len, int format);
+/* where stream k of the last upload lives: device index and its index in that device's batch */
+int efx_multi_locate(const efx_multi* m, int stream, int* device_index, int* local_stream);
+int efx_multi_decode(efx_multi* m);  /* efx_decode on every device; asynchronous */
+int efx_multi_sync(efx_multi* m);
+int efx_multi_reset(efx_multi* m);
+/* per stream of the last upload, in batch order: pictures decoded, status bits (either pointer may be NULL) */
+int efx_multi_results(efx_multi* m, int* n_pictures, uint32_t* status);
+/* efx_frame_hashes of every stream of the last upload, in batch order: out[n_streams][ring_depth] */
+int efx_multi_frame_hashes(efx_multi* m, uint64_t* out);
+
 /* raw device allocations for callers without their own allocator (bench, tests) */
 int efx_device_alloc(efx_ctx* ctx, size_t bytes, void** dptr);
 int efx_device_free(efx_ctx* ctx, void* dptr);

@@ -50,3 +50,21 @@ def test_no_cpu_fallback_without_gpu():
     with pytest.raises(efx.EfxError) as e:
         efx.Decoder(1, 1)
     assert e.value.status in (-2, -3)
+
+
+def test_stream_partition_is_the_one_of_the_scaling_job():
+    """efx_partition_first (the multi-device entry points' partition, host-only): stream k of n lives on device
+    floor(k * R / n) -- the blocks bench.py's ranks take (espflix_amd.dist.shard_fixed) -- every stream exactly once,
+    block sizes differing by at most one."""
+    from espflix_amd import dist
+    for total, parts in ((8192, 8), (8192, 3), (1000, 7), (5, 8), (1, 1), (0, 4), (1024, 2)):
+        firsts = [efx.partition_first(total, parts, r) for r in range(parts + 1)]
+        assert firsts[0] == 0 and firsts[-1] == total and firsts == sorted(firsts)
+        sizes = [b - a for a, b in zip(firsts, firsts[1:])]
+        assert max(sizes) - min(sizes) <= 1
+        for r in range(parts):
+            if total:
+                assert (firsts[r], firsts[r + 1]) == dist.shard_fixed(r, parts, total)
+            for k in range(firsts[r], firsts[r + 1]):
+                assert k * parts // total == r
+    assert efx.partition_first(10, 0, 0) == -1 and efx.partition_first(-1, 2, 0) == -1
