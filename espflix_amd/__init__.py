@@ -94,6 +94,7 @@ _SYMBOLS = {
     "efx_stream_state": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "efx_decode": (C.c_int, [_P]),
     "efx_decode_from": (C.c_int, [_P, C.c_int]),
+    "efx_decode_range": (C.c_int, [_P, C.c_int, C.c_int]),
     "efx_stream_picture_slot": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "efx_sync": (C.c_int, [_P]),
     "efx_picture_count": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
@@ -312,9 +313,13 @@ class Decoder:
         _check(self._ctx, self._lib.efx_erase_frames(self._ctx))
 
     # -- decode ---------------------------------------------------------------------------
-    def decode(self, sync: bool = True, first_picture: int = 0):
-        """efx_decode (first_picture = 0) / efx_decode_from: the decoder keeps going from call to call."""
-        _check(self._ctx, self._lib.efx_decode_from(self._ctx, first_picture))
+    def decode(self, sync: bool = True, first_picture: int = 0, n_pictures: int | None = None):
+        """efx_decode (first_picture = 0) / efx_decode_from / efx_decode_range (at most n_pictures pictures per stream):
+        the decoder keeps going from call to call."""
+        if n_pictures is None:
+            _check(self._ctx, self._lib.efx_decode_from(self._ctx, first_picture))
+        else:
+            _check(self._ctx, self._lib.efx_decode_range(self._ctx, first_picture, n_pictures))
         if sync:
             self.sync()
 

@@ -25,7 +25,7 @@ __global__ void k_demux_audio(const uint8_t*, const uint64_t*, const uint32_t*, 
 __global__ void k_ts_sequences(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, PesEntry*, IdxInfo*);
 __global__ void k_idx_bins(const PesEntry*, const uint32_t*, const IdxInfo*, uint32_t, uint32_t*, size_t);
 __global__ void k_index(const uint8_t*, const uint64_t*, int, PicInfo*, SliceTmp*, uint32_t*, uint32_t*, uint32_t*,
-                        const uint32_t*, const PesEntry*, const uint32_t*, const uint32_t*, int64_t*, int64_t*, int, int);
+                        const uint32_t*, const PesEntry*, const uint32_t*, const uint32_t*, int64_t*, int64_t*, int, int, int);
 __global__ void k_advance(StreamState*, const uint32_t*, int64_t*, const int64_t*, int, int, int, int32_t*);
 __global__ void k_slice_scan(const PicInfo*, const uint32_t*, int, int, const uint32_t*, uint32_t*, DecodeCounters*);
 __global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, const uint64_t*, const uint32_t*, int, int,
@@ -751,9 +751,11 @@ int efx_erase_frames(efx_ctx* ctx)
     return EFX_OK;
 }
 
-int efx_decode_from(efx_ctx* ctx, int first_picture)
+int efx_decode_from(efx_ctx* ctx, int first_picture) { return efx_decode_range(ctx, first_picture, ctx ? ctx->cfg.max_pictures : 0); }
+
+int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
 {
-    if (!ctx || first_picture < 0)
+    if (!ctx || first_picture < 0 || n_pictures < 1 || n_pictures > ctx->cfg.max_pictures)
         return EFX_ERR_ARG;
     if (ctx->cur_up < 0)
         return fail(ctx, EFX_ERR_STATE, "efx_decode: no streams uploaded");
@@ -828,7 +830,7 @@ int efx_decode_from(efx_ctx* ctx, int first_picture)
             hipLaunchKernelGGL(k_index, dim3(n), dim3(64 * kIndexWaves), 0, sp, u.d_es, u.d_stream_off, P, sl.d_pics, sl.d_slices_tmp,
                                sl.d_pic_count, sl.d_status, sl.d_qtab, ctx->d_tables->scan, u.d_pes, u.d_pkt_base, u.d_pes_count,
                                u.ts_input ? sl.d_pts : nullptr, u.ts_input ? sl.d_pts + (size_t)ctx->cfg.max_streams * P : nullptr,
-                               first_picture, s0);
+                               first_picture, s0, n_pictures);
             hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, sl.d_pics, sl.d_pic_count, n, P, u.d_stream_perm + s0,
                                slice_base, counters);
             hipLaunchKernelGGL(k_slice_emit, dim3((n * P * kMaxSlicesPerPicture + 255) / 256), dim3(256), 0, sp, sl.d_pics,
@@ -860,7 +862,7 @@ int efx_decode_from(efx_ctx* ctx, int first_picture)
         hipLaunchKernelGGL(k_advance, dim3((rn + 255) / 256), dim3(256), 0, sr, ctx->d_state, sl.d_pic_count,
                            u.ts_input ? sl.d_pts : nullptr, u.ts_input ? sl.d_pts + (size_t)ctx->cfg.max_streams * P : nullptr, rs0, rn,
                            P, sl.d_call_pos);
-        for (int p = 0; p < P; p++)
+        for (int p = 0; p < n_pictures; p++)
             hipLaunchKernelGGL(k_recon, dim3(rn, (kMbCount * 6 + 63) / 64), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs,
                                ctx->d_tables->scan, sl.d_qtab, ctx->d_frames, P, D, p, sl.d_call_pos, sl.epoch, rs0);
         if (te0)

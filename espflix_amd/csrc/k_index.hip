@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64 * kIndexWaves) void k_index(
     SliceTmp* __restrict__ slices_tmp, uint32_t* __restrict__ pic_count, uint32_t* __restrict__ status, uint32_t* __restrict__ qtab,
     const uint32_t* __restrict__ scan_tab, const PesEntry* __restrict__ pes, const uint32_t* __restrict__ pkt_base,
     const uint32_t* __restrict__ pes_count, int64_t* __restrict__ pts_out, int64_t* __restrict__ pts_newest, int first_picture,
-    int stream0)
+    int stream0, int pic_limit)
 {
     __shared__ uint32_t u_off[kMaxUnitsPerStream];
     __shared__ uint32_t u_info[kMaxUnitsPerStream];
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * kIndexWaves) void k_index(
             } else if (code == 0x00) {
                 if (pic >= 0)
                     mypics[pic].n_slices = nsl;
-                if (pic + 1 >= max_pictures) {
+                if (pic + 1 >= pic_limit) {  // (efx_decode_range: at most this many pictures per stream in this call)
                     st |= EFX_STREAM_TRUNCATED;
                     break;
                 }

@@ -133,6 +133,10 @@ int efx_decode(efx_ctx* ctx);
  * for their header state only): a stream with more than max_pictures pictures (EFX_STREAM_TRUNCATED)
  * is decoded by efx_decode_from(ctx, 0), (ctx, max_pictures), (ctx, 2 * max_pictures) ... */
 int efx_decode_from(efx_ctx* ctx, int first_picture);
+/* The same for at most n_pictures (1 ... max_pictures) pictures per stream: a caller that knows its batch holds few
+ * pictures (the streaming adapter decoding a real-time play picture by picture, efx_player.hpp) pays for that many
+ * reconstruction launches, not for max_pictures of them; streams with more are flagged EFX_STREAM_TRUNCATED as above. */
+int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures);
 int efx_sync(efx_ctx* ctx);
 
 /* number of pictures found in a stream by the last efx_decode (valid after efx_sync) */

@@ -26,8 +26,10 @@
 //   * STREAMING: Buffers are decoded while they arrive, in windows cut where a video PES starts with
 //     a sequence, group or picture start code (every picture of the reference's own files and of
 //     ffmpeg's muxer starts a PES): a window is decoded when a sequence header opens the next one,
-//     when it holds kWindowPictures pictures, or at the zero-length Buffer.  Pictures therefore arrive up
-//     to one window (one GOP) after the reference would have pushed them; a play may be of any length.
+//     when it holds kWindowPictures pictures, at the zero-length Buffer -- and whenever no further Buffer is
+//     waiting (the feeder is not ahead of the decoder: a real-time play), so that a picture is pushed when the
+//     PES of its successor has arrived, as the reference pushes it at its successor's header.  Only a feeder
+//     faster than the decoder makes pictures arrive in batches (up to one window late); a play may be of any length.
 //     The decoder state travels from window to window on the device (frame index, PTS latch, reference
 //     frame: efx.h, efx_decode), exactly as the reference's does from Buffer to Buffer.  A stream whose
 //     PES packets never start at a picture is decoded at its end (one window of at most
@@ -53,6 +55,7 @@
 #include <string.h>
 
 #include <condition_variable>
+#include <chrono>
 #include <mutex>
 #include <queue>
 #include <thread>
@@ -130,7 +133,7 @@ class MpegDecoder {
   protected:
     void pause();
     void feed(const uint8_t* packets, size_t bytes);  // transport packets of one Buffer
-    void decode_window(size_t bytes);                 // decode the first `bytes` of the window, keep the rest
+    void decode_window(size_t bytes, bool next_started = false);  // decode the first `bytes` of the window, keep the rest
     void seed_ring();
     Q _empty_q;
     Q _full_q;
@@ -284,6 +287,17 @@ MpegDecoder::MpegDecoder(Frame* fb0, Frame* fb1)
         fprintf(stderr, "MpegDecoder: efx_create failed (a gfx950 device is required)\n");
         abort();
     }
+    // one pass over an empty transport stream now: the transport-stream buffers, the code objects and the queues
+    // exist before the first picture arrives (the first window of a real-time play is not the slow one)
+    uint8_t null_packet[188];
+    memset(null_packet, 0xFF, sizeof(null_packet));
+    null_packet[0] = 0x47;
+    null_packet[1] = 0x1F;
+    null_packet[3] = 0x10;
+    const uint8_t* ptr = null_packet;
+    size_t len = sizeof(null_packet);
+    if (efx_upload_streams(_ctx, 1, &ptr, &len, EFX_FORMAT_TS) == EFX_OK && efx_decode(_ctx) == EFX_OK)
+        efx_sync(_ctx);
 }
 
 MpegDecoder::~MpegDecoder() { efx_destroy(_ctx); }
@@ -346,7 +360,7 @@ void MpegDecoder::seed_ring()
     }
 }
 
-void MpegDecoder::decode_window(size_t bytes)
+void MpegDecoder::decode_window(size_t bytes, bool next_started)
 {
     if (bytes > _win.size())
         bytes = _win.size();
@@ -364,9 +378,11 @@ void MpegDecoder::decode_window(size_t bytes)
         fprintf(stderr, "MpegDecoder: %s\n", efx_last_error(_ctx));
         len = 0;
     }
-    // passes of at most kMaxPictures pictures over the window (efx_decode_from)
+    // passes over the window: the first for as many pictures as picture-aligned PES packets were counted (a real-time
+    // play: one or two -- that many reconstruction launches, not kMaxPictures of them), more passes if more turn up
+    int budget = _win_pictures + 1 < (int)kMaxPictures ? _win_pictures + 1 : (int)kMaxPictures;
     for (int first = 0; len;) {
-        if (efx_decode_from(_ctx, first) != EFX_OK || efx_sync(_ctx) != EFX_OK) {
+        if (efx_decode_range(_ctx, first, budget) != EFX_OK || efx_sync(_ctx) != EFX_OK) {
             fprintf(stderr, "MpegDecoder: %s\n", efx_last_error(_ctx));
             break;
         }
@@ -392,10 +408,19 @@ void MpegDecoder::decode_window(size_t bytes)
         if (!(status & EFX_STREAM_TRUNCATED) || n <= 0)
             break;
         first += n;
+        budget = kMaxPictures;
     }
     _win.erase(_win.begin(), _win.begin() + (ptrdiff_t)bytes);
     _cut = 0;
     _win_pictures = 0;
+    // The window was cut where the PES of the NEXT picture starts: the reference, reaching that picture's header, pushes
+    // the one before it now (flush_picture, player.cpp:692-702) -- so does this.  (The PTS the next picture latches is set
+    // when it is decoded; the push itself only needs the one already latched.)
+    if (next_started && _have_last && _last_pts != -1) {
+        push_video(_fb[0], _fb_index & 1, _last_pts, 0);
+        _fb_index++;
+        _have_last = false;
+    }
 }
 
 namespace efx_player_detail {
@@ -437,14 +462,14 @@ void MpegDecoder::feed(const uint8_t* pk, size_t bytes)
                     // a picture (group, sequence) starts a PES here: everything before this packet is whole pictures
                     const size_t at = _win.size();
                     if (at && (es[3] == 0xB3 || _win_pictures >= kWindowPictures || at + 188 > (size_t)kWindowBytes)) {
-                        decode_window(at);
+                        decode_window(at, true);
                     } else if (at)
                         _cut = at;
                     _win_pictures++;
                 }
             }
             if (_win.size() + 188 > (size_t)kWindowBytes && _cut) {
-                decode_window(_cut);
+                decode_window(_cut, true);
             }
             _win.insert(_win.end(), d, d + 188);
         } else if ((pid == 0x101 || pid == 0x102) && has_payload) {
@@ -485,6 +510,17 @@ void MpegDecoder::run()  // player.cpp:1355-1367
         if (!eos)
             feed(b->data, b->len);
         _empty_q.push(b);
+        // Adaptive window: no Buffer is waiting, so the feeder is not ahead of the decoder (a real-time play): the whole
+        // pictures the window holds are decoded now and a picture is pushed as soon as the PES of its successor has
+        // arrived -- the reference's own latency.  While Buffers queue up (a feeder faster than the decoder) pictures are
+        // batched, up to kWindowPictures per pass over the GPU.
+        // (a feeder that is merely between two push_full calls refills the queue within microseconds: give it 300)
+        if (!eos && _cut && _full_q.empty()) {
+            for (int spin = 0; spin < 6 && _full_q.empty(); spin++)
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            if (_full_q.empty())
+                decode_window(_cut, true);
+        }
         if (eos) {  // zero-length Buffer: the decoder pads with a sequence_end code and pauses (player.cpp:469-473,1324-1327)
             decode_window(_win.size());
             pause();

@@ -4,8 +4,12 @@
 // src/espflix.cpp:723-737,1043-1068) -- compiled against include/efx_player.hpp.
 // Prints one line per pushed frame "F <idx> <pts> <fnv>", "U <bytes> <fnv>" for the audio bytes handed
 // to push_audio, then "V <fnv>" for one composite field of the last frame, "W" for a slide under the
-// overlay, "A <fnv>" for three write_pcm_16 calls and "B <fnv>" for beep() + six more.
+// overlay, "A <fnv>" for three write_pcm_16 calls and "B <fnv>" for beep() + six more.  The fifth field of an F line
+// is the number of Buffers the feeder had pushed when the frame arrived; `paced` as second argument makes the feeder
+// slower than the decoder (8 ms per Buffer = 1.5 Mbit/s), the situation of a real-time play.
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #include <unistd.h>
 
 #define EFX_PLAYER_IMPLEMENTATION
@@ -21,6 +25,7 @@ static uint64_t fnv(const uint8_t* p, size_t n, uint64_t h)
 }
 
 static int g_n = 0;
+static volatile int g_fed = 0;  // Buffers the feeder has pushed so far
 static Frame* g_frames = 0;
 static int g_front = 0;
 
@@ -30,7 +35,7 @@ void push_video(Frame* f, int front, int64_t pts, int mode)
     uint64_t h = 0xcbf29ce484222325ull;
     for (int s = 0; s < FB_SLICES; s++)
         h = fnv(f[front]._slices[s], FB_STRIDE * FB_SLICE_HEIGHT, h);
-    printf("F %d %lld %016llx\n", g_n++, (long long)pts, (unsigned long long)h);
+    printf("F %d %lld %016llx %d\n", g_n++, (long long)pts, (unsigned long long)h, g_fed);
     g_frames = f;
     g_front = front;
 }
@@ -67,9 +72,12 @@ int main(int argc, char** argv)
             continue;
         int n = (int)fread(b->data, 1, sizeof(b->data), f);
         b->len = n;
+        g_fed++;
         dec.push_full(b);
         if (!n)
             break;
+        if (argc > 2 && !strcmp(argv[2], "paced"))  // a feeder slower than the decoder: a real-time play
+            usleep(argc > 3 ? atoi(argv[3]) : 8000);  // (default: 1504 bytes at the service's 1.5 Mbit/s)
     }
     wait_events(DECODER_PAUSED);
     dec.flush_picture(1);  // as load_poster does: show the last picture too

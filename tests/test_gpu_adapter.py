@@ -101,3 +101,38 @@ def test_unaligned_pes_stream_is_decoded_at_its_end(tmp_path):
     n, h, pts, _ = oracle.decode(ts, 1, flush_last=True)
     assert [int(r[3], 16) for r in frames] == [int(x) for x in h]
     assert [int(r[2]) for r in frames] == [int(x) for x in pts]
+
+
+@pytest.mark.parametrize("clip", ["splash", "vmedia"])
+def test_paced_feeder_gets_the_reference_latency(tmp_path, clip, golden):
+    """A feeder slower than the decoder (a real-time play): the adaptive window decodes whenever no Buffer is waiting and
+    a picture is pushed when the PES of its successor has arrived -- the reference pushes it at its successor's header
+    (flush_picture, player.cpp:692-702).  Checked on the Buffer count at each push_video(n): no Buffer beyond the one
+    that holds the PES start of picture n + 1 has been handed over yet.  Frames and PTS stay exact."""
+    exe = build(tmp_path)
+    path = os.path.join(ROOT, "tests", "golden", clip + ".ts")
+    # the feeder's pace: the clip at its own 30 pictures per second, Buffer by Buffer
+    n_buffers = os.path.getsize(path) / 1504
+    usec = int(1e6 * len(golden["clips"][clip]["hashes"]) / 30 / n_buffers)
+    p = subprocess.run([exe, path, "paced", str(usec)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    frames = [l.split() for l in p.stdout.splitlines() if l.startswith("F ")]
+    g = golden["clips"][clip]
+    assert [r[3] for r in frames] == g["hashes"] and [int(r[2]) for r in frames] == g["pts"]
+    # Buffer (8 transport packets = 1504 bytes, streamer.h:142) that holds the PES start of every picture
+    ts = np.fromfile(path, dtype=np.uint8)
+    starts = []
+    for k in range(ts.size // 188):
+        pkt = ts[k * 188:(k + 1) * 188]
+        if pkt[0] == 0x47 and ((int(pkt[1]) << 8 | int(pkt[2])) & 0x1FFF) == 0x100 and pkt[1] & 0x40:
+            d = 4 + (1 + int(pkt[4]) if pkt[3] & 0x20 else 0)
+            es = d + 9 + int(pkt[d + 8])
+            if es + 4 <= 188 and bytes(pkt[es:es + 3]) == b"\x00\x00\x01" and pkt[es + 3] in (0x00, 0xB3, 0xB8):
+                starts.append(k * 188 // 1504)
+    assert len(starts) >= len(frames)
+    # picture n is pushed while the Buffer that holds the PES start of picture n + 1 is the newest one handed over
+    # (fed == its index + 1) -- in particular before the Buffer of picture n + 2's first byte is, unless that is the same one
+    # (picture 0 excepted: the first window of a play also seeds the device ring with the host's two Frames)
+    late = [n for n, r in enumerate(frames[:-1]) if 0 < n and n + 1 < len(starts) and int(r[4]) > starts[n + 1] + 1]
+    assert not late, (f"pictures pushed later than the reference would: {late[:10]}; "
+                      f"fed {[int(r[4]) for r in frames[:6]]}, picture starts in Buffers {starts[:8]}")

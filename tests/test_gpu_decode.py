@@ -256,6 +256,30 @@ def test_decode_from_walks_a_long_stream(efx):
     dec.close()
 
 
+def test_decode_range_picture_budget(efx):
+    """efx_decode_range: a call for at most n pictures per stream (fewer reconstruction launches) on a context sized for
+    more; the rest is flagged and picked up by the next call -- passes of 1, 3, 8 pictures give the reference's frames."""
+    from espflix_amd import gen
+    b = gen.Batch(60, 3, 12, 12, gen.FLAG_WIDE_SLICES)
+    es = b.all_es()
+    want = [oracle.decode(e, 0)[1] for e in es]
+    dec = efx.Decoder(3, 12, 13)
+    dec.upload(es, efx.FORMAT_ES)
+    first = 0
+    for n in (1, 3, 8):
+        dec.decode(first_picture=first, n_pictures=n)
+        h = dec.frame_hashes()
+        for k in range(3):
+            assert dec.picture_count(k) == n
+            assert bool(dec.stream_status(k) & efx.STREAM_TRUNCATED) == (first + n < 12)
+            for p in range(n):
+                assert int(h[k, dec.picture_slot(p, k)]) == int(want[k][first + p])
+        first += n
+    with pytest.raises(efx.EfxError):
+        dec.decode(n_pictures=13)
+    dec.close()
+
+
 def test_no_buffer_swap_before_the_first_pts(efx):
     """flush_picture() neither pushes nor swaps while no PES PTS has been latched (player.cpp:692-702): pictures
     ahead of the first PTS are decoded over each other; the oracle (pinned against the reference on the same
