@@ -68,9 +68,9 @@ struct SliceDesc {
     uint32_t es_len;   // bytes up to the next start code
     uint32_t stream;
     uint32_t pic_code_flags;  // pic | code << 8 | type << 16 | full_pel << 18 | r_size << 19 | custom_q << 22
-    uint32_t mb_limit;  // first macroblock of the next slice of the picture if that slice starts in a later row, else 264:
-                        // a (damaged) slice that runs on stops there -- the reference decodes on and the later slice
-                        // overwrites what it wrote (the slice later in the bitstream wins a macroblock)
+    uint32_t mb_limit;  // the slice stops here: the nearest first macroblock, in raster order, of any other slice of the
+                        // picture (264 if none; 0 for a slice superseded by a later one with the same start code) -- a
+                        // (damaged) slice that runs on never writes a macroblock another parse lane writes (k_slice_emit)
     uint32_t reserved;
 };
 

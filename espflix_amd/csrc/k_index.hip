@@ -482,13 +482,24 @@ __global__ __launch_bounds__(256) void k_slice_emit(const PicInfo* __restrict__ 
     d.stream = (uint32_t)s;
     d.pic_code_flags = (uint32_t)p | ((st.len_code & 0xFF) << 8) | ((uint32_t)pi.type << 16) | ((uint32_t)pi.full_pel << 18) |
                        ((uint32_t)pi.r_size << 19) | ((uint32_t)pi.custom_q << 22);
-    // a slice that runs on past the first macroblock of the next slice (damaged streams only) stops there
+    // A slice starts at column 0 of its row whatever its first address increment says (inc_mb, player.cpp:823-833,1277),
+    // so where every slice of the picture starts is known here.  A (damaged) slice that runs on stops at the nearest
+    // start, in raster order, of ANY other slice of the picture, and of several slices with the same start code only the
+    // last in the bitstream is parsed: every macroblock has exactly one writer among the parse lanes, whatever the
+    // damage.  (The reference, one serial decoder, lets whatever comes later in the bitstream overwrite: the same for a
+    // slice that runs on into a later slice's row, not for one that runs on into the row of a slice that came EARLIER
+    // in the bitstream -- slices out of raster order AND damaged -- a documented deviation)
     uint32_t limit = kMbCount;
-    if (k + 1 < (int)pi.n_slices) {
+    {
         const uint32_t code = st.len_code & 0xFF;
-        const uint32_t next = slices_tmp[(size_t)s * max_pictures * kMaxSlicesPerPicture + pi.first_slice + k + 1].len_code & 0xFF;
-        if (next > code && (next - 1) * kMbW < (uint32_t)kMbCount)
-            limit = (next - 1) * kMbW;
+        const SliceTmp* all = slices_tmp + (size_t)s * max_pictures * kMaxSlicesPerPicture + pi.first_slice;
+        for (int j = 0; j < (int)pi.n_slices; j++) {
+            const uint32_t other = all[j].len_code & 0xFF;
+            if (other > code && (other - 1) * kMbW < limit)
+                limit = (other - 1) * kMbW;
+            if (other == code && j > k)
+                limit = 0;  // superseded by a later slice with the same start code
+        }
     }
     d.mb_limit = limit;
     d.reserved = 0;

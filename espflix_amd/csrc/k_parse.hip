@@ -157,10 +157,11 @@ __device__ inline int decode_motion(BitReader& br, const uint16_t* tab, int pred
 }
 
 // DC size + differential of an intra block, player.cpp:1010-1068 (tables B-5a / B-5b): at most
-// 10 + 11 bits, all inside one window.  Updates the predictor, returns the DC value and the bits used.
-__device__ inline int decode_dc(uint32_t win, int blk, int& dc_y, int& dc_cr, int& dc_cb, uint32_t& used)
+// 10 + 11 bits, all inside one window.  Returns the DC value (= the new predictor) and the bits used.  (The three
+// predictors stay in registers: handed in by reference and picked by block number they became a scratch array.)
+__device__ inline int decode_dc(uint32_t win, int blk, int pred, uint32_t& used)
 {
-    int size, len, pred;
+    int size, len;
     if (blk < 4) {
         uint32_t pb = win >> 23;
         int ones = __clz((int)~(pb << 23));
@@ -174,7 +175,6 @@ __device__ inline int decode_dc(uint32_t win, int blk, int& dc_y, int& dc_cr, in
             size = ones + 2;
             len = ones + 1;
         }
-        pred = dc_y;
     } else {
         uint32_t pb = win >> 22;
         int ones = __clz((int)~(pb << 22));
@@ -185,7 +185,6 @@ __device__ inline int decode_dc(uint32_t win, int blk, int& dc_y, int& dc_cr, in
             size = ones + 1;
             len = size < 10 ? size : 10;
         }
-        pred = (blk == 4) ? dc_cr : dc_cb;
     }
     if (size) {
         int delta = (int)((win << len) >> (32 - size));
@@ -194,12 +193,6 @@ __device__ inline int decode_dc(uint32_t win, int blk, int& dc_y, int& dc_cr, in
             pred += delta;
         else
             pred += (int)((~0u << size) | (uint32_t)(delta + 1));
-        if (blk == 4)
-            dc_cr = pred;
-        else if (blk == 5)
-            dc_cb = pred;
-        else
-            dc_y = pred;
     }
     used = (uint32_t)len;
     return pred;
@@ -468,7 +461,10 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
             int pend_level, pend_n = 0, n;
             if (intra) {
                 uint32_t used;
-                pend_level = decode_dc(win, blk, dc_y, dc_cr, dc_cb, used);
+                pend_level = decode_dc(win, blk, blk < 4 ? dc_y : (blk == 4 ? dc_cr : dc_cb), used);
+                dc_y = blk < 4 ? pend_level : dc_y;
+                dc_cr = blk == 4 ? pend_level : dc_cr;
+                dc_cb = blk == 5 ? pend_level : dc_cb;
                 br.advance(used);
                 pend_valid = 1;
                 n = 1;
