@@ -256,6 +256,20 @@ def test_decode_from_walks_a_long_stream(efx):
     dec.close()
 
 
+@pytest.mark.parametrize("flags,n,pictures", [(64 | 128 | 4 | 2, 12, 24), (64 | 8 | 16, 16, 12), (128 | 8 | 4 | 2, 16, 24), (64 | 1, 8, 8)])
+def test_quirk_flavours_combined_fresh_ids(efx, flags, n, pictures):
+    """Escape-level forms / ignored picture types / user data combined with custom matrices, wide slices, long skips,
+    flat bright areas and I-only streams, on ids beyond the golden set (two GOPs where 24 pictures): HIP path = oracle
+    (which tests/test_oracle_vs_ref.py pins against the live reference on these flavours)."""
+    from espflix_amd import gen
+    b = gen.Batch(1000, n, pictures, 12, flags)
+    res = gpu_hashes(efx, b.all_es(), efx.FORMAT_ES, pictures)
+    for k in range(n):
+        cnt, h, _, _ = oracle.decode(b.es(k), 0)
+        assert res[k]["status"] == 0 and res[k]["n"] == cnt == pictures
+        assert res[k]["hashes"] == [int(x) for x in h]
+
+
 def test_decode_range_picture_budget(efx):
     """efx_decode_range: a call for at most n pictures per stream (fewer reconstruction launches) on a context sized for
     more; the rest is flagged and picked up by the next call -- passes of 1, 3, 8 pictures give the reference's frames."""
