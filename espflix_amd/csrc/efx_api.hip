@@ -31,7 +31,7 @@ __global__ void k_slice_scan(const PicInfo*, const uint32_t*, int, int, const ui
 __global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, const uint64_t*, const uint32_t*, int, int,
                              const uint32_t*, SliceDesc*);
 __global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const ParseTables*, MbRec*, uint32_t*, uint32_t*,
-                        int, int);
+                        int, int, int);
 __global__ void k_recon(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, const int32_t*, int, int);
 __global__ void k_frame_hash(const uint8_t*, int, uint64_t*);
 __global__ void k_fill(uint32_t*, uint32_t, size_t);
@@ -58,7 +58,7 @@ constexpr int kReconMerge = EFX_RECON_MERGE;  // parse halves whose streams are 
 #define EFX_GROUP_STREAMS 512
 #endif
 constexpr int kGroupStreams = EFX_GROUP_STREAMS;
-constexpr double kGroupMaxSliceBytes = 640;  // ... when the slices are short (see efx_decode_from)  // ... of about this many streams each (see efx_decode_from)
+constexpr double kGroupMaxSliceBytes = 640;  // a call is split into parse halves only when its slices are shorter than this on average (efx_decode_range)
 constexpr int kTimingRing = 64;   // efx_decode calls whose stage times efx_get_timing can average
 constexpr int kSlots = EFX_SLOTS;         // parse -> recon hand-over buffer sets (one being reconstructed + two being parsed)
 constexpr int kUploads = 2;       // bitstream buffers: one being decoded, one being filled
@@ -844,7 +844,7 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
                 EFX_HIP(hipEventRecord(te->ev[1], sp));
             const int max_slices = n * P * kMaxSlicesPerPicture;
             hipLaunchKernelGGL(k_parse, dim3((max_slices / kParseLanes * 64 + 255) / 256), dim3(256), 0, sp, u.d_es, descs, counters,
-                               ctx->d_tables, sl.d_mbrecs, sl.d_coefs, sl.d_status, P, sl.epoch);
+                               ctx->d_tables, sl.d_mbrecs, sl.d_coefs, sl.d_status, P, sl.epoch, G > 1 ? 1 : 0);
             if (te)
                 EFX_HIP(hipEventRecord(te->ev[2], sp));
             EFX_HIP(hipEventRecord(sl.parse_done[g - h0], sp));

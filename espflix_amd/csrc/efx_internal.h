@@ -99,7 +99,7 @@ struct ParseTables {
 };
 // dct entry: bits consumed (5 bits: code + sign; 2 for end_of_block; 20 for an escape with an 8-bit
 // level) | run << 5 (5 bits) | level << 10 (6 bits); level 0 = escape, level 63 = end_of_block;
-// 0 bits = invalid code
+// level 63 with 0 bits = invalid code
 
 struct DecodeCounters {
     uint32_t total_slices;

@@ -37,6 +37,12 @@ void build_parse_tables(ParseTables* t)
     // DCT coefficients.  dct_hi covers code words of <= 8 bits (index = their 8-bit prefix);
     // longer words all start with six zero bits and are resolved through dct_lo, indexed by
     // bits 6..15 of a 16-bit peek.
+    // (a bit pattern that is no code word: 0 bits consumed, level 63 -- the parser's "this block ends here" mark, which
+    // end_of_block carries with 2 bits)
+    for (auto& e : t->dct_hi)
+        e = (uint16_t)(63 << 10);
+    for (auto& e : t->dct_lo)
+        e = (uint16_t)(63 << 10);
     for (const DctCode& c : kDctCodes) {
         uint16_t e = (uint16_t)((c.len + 1) | (c.run << 5) | (c.level << 10));  // length incl. the sign bit
         if (c.len <= 8)

@@ -205,7 +205,7 @@ struct DctSymbol {
     uint32_t len;  // bits consumed
     uint32_t run;
     int level;     // signed
-    bool eob, bad;
+    bool stop;     // end_of_block ("10", table level 63) or an invalid code (table level 63, 0 bits): the block ends here
 };
 __device__ inline DctSymbol decode_symbol(uint32_t win, uint32_t ent)
 {
@@ -213,15 +213,18 @@ __device__ inline DctSymbol decode_symbol(uint32_t win, uint32_t ent)
     // the table carries the bits consumed (code + sign; 2 for end_of_block; 0 for an invalid code), so
     // the chain  entry -> length -> position  is one mask and one select long
     const uint32_t len_f = ent & 31, run_f = (ent >> 5) & 31, lev_f = ent >> 10;
-    y.bad = len_f == 0;           // invalid code
-    y.eob = lev_f == 63;          // "10": end_of_block
+    y.stop = lev_f == 63;
     const bool esc = lev_f == 0;  // escape: 6-bit run, 8- or 16-bit level (player.cpp:1092-1099)
     const int lvl_n = ((win << (len_f - 1)) >> 31) ? -(int)lev_f : (int)lev_f;  // sign = last bit of the code
-    const uint32_t lv8 = (win << 12) >> 24, ext = (win << 20) >> 24;
+    // the level byte as the int8 it is, or -- first byte 0x00 / 0x80 -- the next byte, minus 256 after 0x80:
+    // "ext - 2 * lv8" is that for both (lv8 = 0 or 128)
+    const int lv8 = (int)__builtin_amdgcn_ubfe(win, 12, 8), ext = (int)__builtin_amdgcn_ubfe(win, 4, 8);
     const bool two = (lv8 & 0x7F) == 0;
-    const int lvl_e = two ? (lv8 ? (int)ext - 256 : (int)ext) : (lv8 > 128 ? (int)lv8 - 256 : (int)lv8);
+    // (blended with masks: as a select hipcc turns it into a branch inside the symbol loop)
+    const int two_mask = (int)((uint32_t)((lv8 & 0x7F) - 1) >> 31) * -1;
+    const int lvl_e = ((ext - 2 * lv8) & two_mask) | (__builtin_amdgcn_sbfe((int)win, 12, 8) & ~two_mask);
     y.level = esc ? lvl_e : lvl_n;
-    y.run = esc ? (win << 6) >> 26 : run_f;
+    y.run = esc ? __builtin_amdgcn_ubfe(win, 20, 6) : run_f;
     y.len = (esc && two) ? 28u : len_f;
     return y;
 }
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                                                DecodeCounters* __restrict__ counters,
                                                const ParseTables* __restrict__ gtab, MbRec* __restrict__ mbrecs,
                                                uint32_t* __restrict__ coefs, uint32_t* __restrict__ status,
-                                               int max_pictures, int epoch)
+                                               int max_pictures, int epoch, int yield)
 {
     // kParseLanes slices per wave: the wave's time is the union of its lanes' control flow (every macroblock, block and
     // symbol trip is paid by all of them), so fewer slices per wave shorten it -- at the price of more waves
@@ -474,30 +477,38 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                 n = (int)pend_valid;
                 br.advance(pend_valid << 1);
             }
-            bool dropped = false;
-            uint32_t cont;
+            // The loop leaves nothing behind but its last table entry and position: why a lane stopped -- end_of_block, an
+            // invalid code, or a coefficient beyond position 63 (player.cpp:1106-1107: block abandoned) -- is read off
+            // them afterwards, so the trip carries one exit test and no flag bookkeeping.
+            uint32_t cont, ent;
+            int n_new;
             BitReader::Regs wr3;
             br.load_regs(wr3);
             do {
                 br.topup();
                 win = br.window(wr3);
                 const uint32_t pk = win >> 16;
-                const uint32_t ent = (pk >= 0x0400) ? sh.t.dct_hi[pk >> 8] : sh.t.dct_lo[pk & 0x3FF];
-                br.settle(wr3);
+                ent = (pk >= 0x0400) ? sh.t.dct_hi[pk >> 8] : sh.t.dct_lo[pk & 0x3FF];
                 coefs[min(coef_idx, coef_last)] = ((uint32_t)pend_level << 6) | (uint32_t)pend_n;
                 coef_idx += pend_valid;
                 const DctSymbol y = decode_symbol(win, ent);
+                br.settle(wr3);  // (behind the table look-up: one wait covers both LDS reads)
                 br.advance(wr3, y.len);
-                const int n_new = n + (int)y.run;
-                const bool drop = !y.eob && !y.bad && n_new >= 64;  // player.cpp:1106-1107: block abandoned
-                cont = !(y.eob || y.bad || drop);
+                n_new = n + (int)y.run;
+                cont = !y.stop && n_new < 64;
                 pend_valid = cont;
                 pend_n = n_new & 63;
                 pend_level = y.level;
                 n = n_new + 1;
-                bad |= y.bad;
-                dropped |= drop;
+                // When the reconstruction half is the critical path of the pipeline (short slices: the call runs as parse
+                // halves with time to spare, efx_decode_range) the parse waves hand issue slots to the k_recon waves they run
+                // beside: VALU issue is what the two kernels compete for, and a parse half that finishes
+                // early buys nothing.
+                if (yield)
+                    __builtin_amdgcn_s_sleep(2);
             } while (cont);
+            bad = (ent & 31) == 0;                       // invalid code
+            const bool dropped = !bad && (ent >> 10) != 63;  // stopped without an end_of_block: ran past position 63
             if (bad)
                 break;
             if (dropped) {
