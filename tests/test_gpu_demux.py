@@ -154,3 +154,55 @@ def test_pts_survive_pipelined_decodes(efx, golden):
             want = (got, h)
             assert got[0] == golden["synthetic"]["0:0"]["pts"]
         assert got == want[0] and np.array_equal(h, want[1])
+
+
+def test_pts_carry_with_uploads_running_ahead_of_the_reconstruction(efx):
+    """A transport stream cut into uploads where the PES that carries a picture's PTS arrives one upload BEFORE the
+    picture: every PES starts three bytes ahead of its picture's start code and its first transport packet carries just
+    those three bytes, and every upload ends with that packet.  upload k, decode k, upload k + 1, decode k + 1 ... are
+    queued back to back with a reconstruction stream that lags (a batch of long streams beside it): k_advance -- on the
+    reconstruction stream -- must take the carried PTS from what k_index left in the hand-over slot, not from the upload
+    buffers, which upload k + 2 is already overwriting (round-2 advisor finding).  Every picture carries the PTS the
+    reference latches, frames included."""
+    from espflix_amd import gen
+    n_pic = 10
+    es = gen.Batch(70, 1, n_pic, 12, 0).es(0).tobytes()
+    offs = common.picture_offsets(es)
+    starts = [0] + [o - 3 for o in offs[1:]] + [len(es)]
+    first, rest = [], []   # per PES: its first packet (header + 3 payload bytes), the packets after it
+    cc = 0
+    for i in range(n_pic):
+        chunk = es[starts[i]:starts[i + 1]]
+        first.append(common.ts_packet(0x100, common.pes_header(500000 + 3003 * i) + chunk[:3], pusi=True, cc=cc))
+        cc += 1
+        pk = b""
+        for o in range(3, len(chunk), 184):
+            pk += common.ts_packet(0x100, chunk[o:o + 184], cc=cc)
+            cc += 1
+        rest.append(pk)
+    ts = b"".join(f + r for f, r in zip(first, rest))
+    ref_n, ref_h, ref_pts, _ = oracle.decode(np.frombuffer(ts, dtype=np.uint8), 1, flush_last=True)
+    assert ref_n == n_pic and [int(x) for x in ref_pts] == [500000 + 3003 * i for i in range(n_pic)]
+    # upload k: the packets of PES k behind its first one + the first packet of PES k + 1 (upload 0 also opens the stream)
+    uploads = [np.frombuffer((first[0] if k == 0 else b"") + rest[k] + (first[k + 1] if k + 1 < n_pic else b""), dtype=np.uint8)
+               for k in range(n_pic)]
+    ballast = gen.Batch(71, 96, 12, 12, 0)   # keeps the GPU busy: the uploads run ahead of the reconstruction
+    big = efx.Decoder(96, 12, 2)
+    big.upload(ballast.all_es(), efx.FORMAT_ES)
+    for attempt in range(3):
+        dec = efx.Decoder(1, 12, 13, max_stream_bytes=len(ts) + 4096)
+        got = []
+        for k, up in enumerate(uploads):
+            for _ in range(3):
+                big.decode(sync=False)
+            dec.upload([up], efx.FORMAT_TS)
+            dec.decode(sync=False)
+            if k % 3 == 2 or k + 1 == len(uploads):   # results are read only every third decode: uploads k + 1, k + 2 are
+                assert dec.picture_count(0) == 1         # queued while decode k has not been reconstructed yet
+                h = dec.frame_hashes()
+                got.append((k, dec.picture_pts(0, 0), int(h[0, dec.picture_slot(0)])))
+        assert dec.stream_state(0)[2] == int(ref_pts[-1])
+        for k, pts, fh in got:
+            assert pts == int(ref_pts[k]) and fh == int(ref_h[k]), (attempt, k)
+        dec.close()
+    big.close()
