@@ -409,7 +409,9 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             v[0] = intra ? (dc_raw << 8) : v[0];
             v[0] = dc_only ? (v[0] & ~0xFF) : v[0];
         }
+#if !defined(EFX_ABL_NO_IDCT) && !defined(EFX_ABL_NO_COL)
         idct8(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
+#endif
         // one butterfly at a time (volatile asm statements keep their order): with all sixteen in
         // flight the temporaries push the kernel past 128 registers and an occupancy step
         asm volatile("" : "+v"(v[c]), "+v"(v[8 + c]), "+v"(v[16 + c]), "+v"(v[24 + c]), "+v"(v[32 + c]), "+v"(v[40 + c]),
@@ -421,7 +423,9 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         // (it is never multiplied), so the 128 is added there, once; the shift is left to the byte permutes below -- a
         // residual fits 16 bits, so bytes 1 and 2 of x + 128 ARE the shifted value
         v[r * 8] += 128;
+#ifndef EFX_ABL_NO_IDCT
         idct8(v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
+#endif
         asm volatile("" : "+v"(v[r * 8]), "+v"(v[r * 8 + 1]), "+v"(v[r * 8 + 2]), "+v"(v[r * 8 + 3]), "+v"(v[r * 8 + 4]),
                      "+v"(v[r * 8 + 5]), "+v"(v[r * 8 + 6]), "+v"(v[r * 8 + 7]));
     }
