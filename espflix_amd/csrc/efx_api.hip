@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 #include <thread>
 
 #include <cstdio>
@@ -67,6 +68,8 @@ struct efx_ctx {
     efx_config cfg{};
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool pooled_streams = false;  // the parse / copy (and, if own_stream, reconstruction) streams go back to the pool
+    unsigned stream_serial = 0;
     std::string err;
 
     size_t es_cap = 0;  // bytes of one ES buffer (including tails and guard)
@@ -182,6 +185,39 @@ struct efx_ctx {
 
 namespace {
 
+// The streams of a context -- reconstruction, parse, copy -- are kept when the context goes and handed to the next context
+// on the same device.  Where a stream's hardware queue sits on the command processor's pipes decides whether the parse
+// halves run BESIDE the reconstruction or take turns with it (efx_create), and the runtime deals recycled queues out in
+// whatever order they came back: the second context of a process decoded the same batch at 4.8 instead of 8.2 M
+// frames/s (tools/efx_scale, round 3).  With the set reused as a whole every later context runs where the first one ran.
+struct StreamSet {
+    hipStream_t recon = nullptr, parse[kParseStreams] = {}, copy = nullptr;
+    unsigned serial = 0;  // creation order: the oldest parked set of a device is handed out first (the first set a process
+                          // creates is the one whose queues were dealt in the order efx_create asks for)
+};
+unsigned g_set_serial = 0;
+std::mutex g_pool_guard;
+std::vector<std::pair<int, StreamSet>> g_stream_pool;  // (device, parked set)
+
+bool take_stream_set(int device, StreamSet* out)
+{
+    std::lock_guard<std::mutex> lk(g_pool_guard);
+    size_t best = g_stream_pool.size();
+    for (size_t i = 0; i < g_stream_pool.size(); i++)
+        if (g_stream_pool[i].first == device && (best == g_stream_pool.size() || g_stream_pool[i].second.serial < g_stream_pool[best].second.serial))
+            best = i;
+    if (best == g_stream_pool.size())
+        return false;
+    *out = g_stream_pool[best].second;
+    g_stream_pool.erase(g_stream_pool.begin() + (ptrdiff_t)best);
+    return true;
+}
+void park_stream_set(int device, const StreamSet& set)
+{
+    std::lock_guard<std::mutex> lk(g_pool_guard);
+    g_stream_pool.emplace_back(device, set);
+}
+
 // An efx_decode call may run as G groups of about kGroupStreams streams, one after the other: each group is a complete
 // parse half + reconstruction half with its own hand-over slot, so that the parse half of the next group (and of the
 // one after) runs beside the reconstruction of this one.  Streams are independent, so the result does not depend on
@@ -276,14 +312,28 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     };
     if (hipSetDevice(cfg->device) != hipSuccess)
         return bail(EFX_ERR_NO_DEVICE);
-    if (cfg->hip_stream)
+    StreamSet pooled;
+    const bool experiment = getenv("EFX_EXP_PARSE_CUS") != nullptr;
+    if (!cfg->hip_stream && !experiment && take_stream_set(cfg->device, &pooled)) {
+        // the stream set of an earlier context on this device: same queues, same places
+        ctx->stream = pooled.recon;
+        ctx->own_stream = true;
+        for (int i = 0; i < kParseStreams; i++)
+            ctx->parse_streams[i] = pooled.parse[i];
+        ctx->copy_stream = pooled.copy;
+        ctx->pooled_streams = true;
+        ctx->stream_serial = pooled.serial;
+    } else if (cfg->hip_stream)
         ctx->stream = (hipStream_t)cfg->hip_stream;
     else {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
             return bail(EFX_ERR_DEVICE);
         ctx->own_stream = true;
+        ctx->pooled_streams = !experiment;
+        std::lock_guard<std::mutex> lk(g_pool_guard);
+        ctx->stream_serial = ++g_set_serial;
     }
-    {
+    if (!ctx->parse_streams[0]) {
         // The parse kernel is a few thousand long-running waves: give it the higher priority so its workgroups are
         // placed as soon as the reconstruction kernels of the previous call free a slot.
         // The runtime creates a stream's hardware queue at its first launch, and queues are dealt onto the
@@ -470,13 +520,26 @@ void efx_destroy(efx_ctx* ctx)
         if (sl.recon_done)
             (void)hipEventDestroy(sl.recon_done);
     }
+    bool complete = ctx->own_stream && ctx->stream && ctx->copy_stream;
     for (auto ps : ctx->parse_streams)
-        if (ps)
-            (void)hipStreamDestroy(ps);
-    if (ctx->copy_stream)
-        (void)hipStreamDestroy(ctx->copy_stream);
-    if (ctx->own_stream && ctx->stream)
-        (void)hipStreamDestroy(ctx->stream);
+        complete = complete && ps;
+    if (ctx->pooled_streams && complete) {  // (all of them idle: synchronised above)
+        StreamSet set;
+        set.recon = ctx->stream;
+        for (int i = 0; i < kParseStreams; i++)
+            set.parse[i] = ctx->parse_streams[i];
+        set.copy = ctx->copy_stream;
+        set.serial = ctx->stream_serial;
+        park_stream_set(ctx->cfg.device, set);
+    } else {
+        for (auto ps : ctx->parse_streams)
+            if (ps)
+                (void)hipStreamDestroy(ps);
+        if (ctx->copy_stream)
+            (void)hipStreamDestroy(ctx->copy_stream);
+        if (ctx->own_stream && ctx->stream)
+            (void)hipStreamDestroy(ctx->stream);
+    }
     delete ctx;
 }
 
