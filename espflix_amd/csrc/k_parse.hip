@@ -45,9 +45,15 @@ struct BitReader {
     uint32_t pos;        // bit position relative to gp
     uint32_t wr;         // dwords copied global -> ring so far
 
+#ifdef EFX_DEBUG_WAVES
+    unsigned long long dbg_topup = 0;
+#endif
     __device__ inline void topup()
     {
         if (__any((int)(wr - (pos >> 5)) < kRingLow)) {
+#ifdef EFX_DEBUG_WAVES
+            const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
             const uint32_t n = kRingDwords - (wr - (pos >> 5));
             for (uint32_t base = 0; base < (uint32_t)kRingDwords; base += 8) {
                 if (!__any(base < n))
@@ -66,6 +72,9 @@ struct BitReader {
                 }
             }
             wr += n;
+#ifdef EFX_DEBUG_WAVES
+            dbg_topup += __builtin_readcyclecounter() - t0;
+#endif
         }
     }
     __device__ inline void init(const uint8_t* __restrict__ es, uint32_t off, uint32_t* ring_lane)
@@ -76,49 +85,37 @@ struct BitReader {
         pos = mis * 8;
         wr = 0;
         topup();
+        const uint32_t i = pos >> 5;
+        hi = ring[(i % kRingDwords) * 64];
+        lo = ring[((i + 1) % kRingDwords) * 64];
+        nx = ring[((i + 2) % kRingDwords) * 64];
+        pend = 0;
+        crossed = false;
     }
+    // The window lives in registers: dwords i, i + 1, i + 2 of the stream (i = pos >> 5), for EVERY element of the slice
+    // (round 2 kept it there inside the coefficient loop only; macroblock headers and block starts read the ring twice
+    // per element and were half of a P-slice wave's time, tools/dbg/wave_times.py).  So the chain  position -> window
+    // -> table -> length -> position  holds ONE LDS round trip, the table.  An element is at most 28 bits, so an advance
+    // crosses at most one dword boundary; the dword that then becomes i + 2 is requested at once (`pend`) and put in
+    // place by the NEXT advance, where its latency has long been covered by that element's table look-up.  The ring
+    // always holds dword i + 2 (top-ups keep eight dwords ahead).
+    uint32_t hi, lo, nx, pend;
+    bool crossed;
     // the next 32 bits of the stream, MSB first
     __device__ inline uint32_t window() const
     {
-        uint32_t i = pos >> 5;
-        uint32_t hi = ring[(i % kRingDwords) * 64];
-        uint32_t lo = ring[((i + 1) % kRingDwords) * 64];
         return (uint32_t)((((((uint64_t)hi) << 32) | lo) << (pos & 31)) >> 32);
     }
-    __device__ inline void advance(uint32_t n) { pos += n; }
-
-    // The coefficient loop keeps the window in registers: dwords i, i + 1, i + 2 of the stream (i = pos >> 5), so that
-    // the chain  position -> window -> table -> length -> position  holds ONE LDS round trip (the table) instead of
-    // two.  A symbol is at most 28 bits, so a trip crosses at most one dword boundary; the dword that then becomes
-    // i + 2 is requested at once and put in place at the top of the next trip, where its latency sits in the shadow of
-    // that trip's table look-up.
-    struct Regs {
-        uint32_t hi, lo, nx, pend;
-        bool crossed;
-    };
-    __device__ inline void load_regs(Regs& r) const
+    __device__ inline void advance(uint32_t n)  // n <= 32
     {
-        const uint32_t i = pos >> 5;
-        r.hi = ring[(i % kRingDwords) * 64];
-        r.lo = ring[((i + 1) % kRingDwords) * 64];
-        r.nx = ring[((i + 2) % kRingDwords) * 64];
-        r.pend = 0;
-        r.crossed = false;
-    }
-    __device__ inline uint32_t window(const Regs& r) const
-    {
-        return (uint32_t)((((((uint64_t)r.hi) << 32) | r.lo) << (pos & 31)) >> 32);
-    }
-    __device__ inline void settle(Regs& r) const { r.nx = r.crossed ? r.pend : r.nx; }
-    __device__ inline void advance(Regs& r, uint32_t n)
-    {
+        nx = crossed ? pend : nx;
         const uint32_t np = pos + n;
         const bool c = ((np ^ pos) >> 5) != 0;
         pos = np;
-        r.hi = c ? r.lo : r.hi;
-        r.lo = c ? r.nx : r.lo;
-        r.crossed = c;
-        r.pend = ring[(((np >> 5) + 2) % kRingDwords) * 64];
+        hi = c ? lo : hi;
+        lo = c ? nx : lo;
+        crossed = c;
+        pend = ring[(((np >> 5) + 2) % kRingDwords) * 64];
     }
 };
 
@@ -234,9 +231,15 @@ __device__ inline DctSymbol decode_symbol(uint32_t win, uint32_t ent)
 #ifdef EFX_DEBUG_WAVES
 // development aid (tools/dbg/wave_times.py): per wave of the last k_parse launch, {start, end} of s_memrealtime
 // (100 MHz), picture index | type << 8 | hardware id << 16
-__device__ unsigned long long g_parse_dbg[4 * 16384];
-extern "C" int efx_debug_parse_waves(unsigned long long* dst, size_t n)
+__device__ unsigned long long g_parse_dbg[8 * 16384];
+extern "C" int efx_debug_parse_waves(unsigned long long* dst, size_t n)  // dst == NULL: clear
 {
+    if (!dst) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_parse_dbg)) != hipSuccess)
+            return -1;
+        return (int)hipMemset(p, 0, sizeof(g_parse_dbg));
+    }
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_parse_dbg), n * sizeof(unsigned long long));
 }
 #endif
@@ -297,6 +300,9 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
 
     uint32_t st = 0;
     uint32_t n_coefs = 0, n_mbs = 0;
+#ifdef EFX_DEBUG_WAVES
+    unsigned long long dbg_loop = 0, dbg_hdr = 0, dbg_c0 = __builtin_readcyclecounter();
+#endif
 
     // slice header, player.cpp:1255-1263
     int mb_addr = (code - 1) * kMbW - 1;  // mb_y = code-2, mb_x = mb_width-1
@@ -315,6 +321,9 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
     }
 
     for (int mb = 0;; mb++) {
+#ifdef EFX_DEBUG_WAVES
+        const unsigned long long dbg_h0 = __builtin_readcyclecounter();
+#endif
         br.topup();
         uint32_t win = br.window();
         if ((win >> 9) == 0)  // slice_done(): 23 zero bits, player.cpp:1238-1249
@@ -452,6 +461,9 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
         // entry, or with "1s" = (0, +-1) when a non-intra block opens with a 1 bit (end_of_block
         // cannot come first); when it starts empty the first store lands on a slot that the next
         // real entry overwrites (coef_idx is not advanced).
+#ifdef EFX_DEBUG_WAVES
+        dbg_hdr += __builtin_readcyclecounter() - dbg_h0;
+#endif
         bool bad = false;
         uint32_t cnt_lo = 0, cnt_hi = 0;  // entries per block: blocks 0-3 / 4-5, one byte each
         for (int blk = 0; blk < 6; blk++) {
@@ -482,18 +494,18 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
             // them afterwards, so the trip carries one exit test and no flag bookkeeping.
             uint32_t cont, ent;
             int n_new;
-            BitReader::Regs wr3;
-            br.load_regs(wr3);
+#ifdef EFX_DEBUG_WAVES
+            const unsigned long long dbg_l0 = __builtin_readcyclecounter();
+#endif
             do {
                 br.topup();
-                win = br.window(wr3);
+                win = br.window();
                 const uint32_t pk = win >> 16;
                 ent = (pk >= 0x0400) ? sh.t.dct_hi[pk >> 8] : sh.t.dct_lo[pk & 0x3FF];
                 coefs[min(coef_idx, coef_last)] = ((uint32_t)pend_level << 6) | (uint32_t)pend_n;
                 coef_idx += pend_valid;
                 const DctSymbol y = decode_symbol(win, ent);
-                br.settle(wr3);  // (behind the table look-up: one wait covers both LDS reads)
-                br.advance(wr3, y.len);
+                br.advance(y.len);  // (behind the table look-up: one wait covers both LDS reads)
                 n_new = n + (int)y.run;
                 cont = !y.stop && n_new < 64;
                 pend_valid = cont;
@@ -507,6 +519,9 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
                 if (yield)
                     __builtin_amdgcn_s_sleep(2);
             } while (cont);
+#ifdef EFX_DEBUG_WAVES
+            dbg_loop += __builtin_readcyclecounter() - dbg_l0;
+#endif
             bad = (ent & 31) == 0;                       // invalid code
             const bool dropped = !bad && (ent >> 10) != 63;  // stopped without an end_of_block: ran past position 63
             if (bad)
@@ -543,10 +558,16 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t* __restrict__ es, c
         if (w < 16384) {
             uint32_t hw;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-            g_parse_dbg[4 * w] = dbg_t0;
-            atomicMax(&g_parse_dbg[4 * w + 1], wall_clock64());
-            g_parse_dbg[4 * w + 2] = pic | ((d.pic_code_flags >> 16) & 3) << 8 | ((unsigned long long)hw << 16);
-            g_parse_dbg[4 * w + 3] = n_mbs;
+            // per wave: start, end, picture | type << 8 | hw id << 16, then the maxima over its lanes of the cycles spent in
+            // the symbol loops / in macroblock headers / in ring refills / in all (a lane whose block is not coded sits a
+            // symbol loop out: the lane that took part in every one has the wave's figure)
+            g_parse_dbg[8 * w] = dbg_t0;
+            atomicMax(&g_parse_dbg[8 * w + 1], wall_clock64());
+            g_parse_dbg[8 * w + 2] = pic | ((d.pic_code_flags >> 16) & 3) << 8 | ((unsigned long long)hw << 16);
+            atomicMax(&g_parse_dbg[8 * w + 3], dbg_loop);
+            atomicMax(&g_parse_dbg[8 * w + 4], dbg_hdr);
+            atomicMax(&g_parse_dbg[8 * w + 5], br.dbg_topup);
+            atomicMax(&g_parse_dbg[8 * w + 6], __builtin_readcyclecounter() - dbg_c0);
         }
     }
 #endif
