@@ -17,6 +17,7 @@ FLAG_LONG_SKIPS = 8
 FLAG_FLAT_BRIGHT = 16
 FLAG_RATE_1500K = 32   # mean picture ~6.25 kB (1.5 Mbit/s at 30 Hz, the service's profile)
 FLAG_HUGE_LEVELS = 64  # AC levels up to +-255 / -256, every escape form of player.cpp:1092-1099, coded zeros, runs > 31
+FLAG_SLICE_EXTRA = 256  # 0-3 extra_bit_slice = 1 + information bytes in every slice header (player.cpp:1261-1262)
 FLAG_ODD_HEADERS = 128  # B / D / reserved picture types on P-coded pictures, user_data / extension units, varying f_code
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -48,6 +48,9 @@ enum : uint32_t {
                              // reference's bit-serial marker hunt (player.cpp:1360-1363) walks through is shaped so that
                              // the hunt arrives at the next real start code: zero bits only after an ignored header,
                              // user data in 4-byte groups whose last byte is a harmless marker value
+    FLAG_SLICE_EXTRA = 256,  // slice headers carry 0-3 extra_bit_slice = 1 + extra_information_slice bytes before the
+                             // closing 0 bit (player.cpp:1261-1262: `while (get_bit()) get_bits(8);`), on I and P pictures;
+                             // the bytes have their top bit set, so they cannot take part in a start code
 };
 constexpr int kCodedZero = 1 << 20;  // levels[]: a coefficient coded with level 0 (escape "00 00"): decoded, not skipped
 
@@ -657,6 +660,14 @@ struct Encoder {
                 odd_units();
             bw.start_code(row0 + 1);
             bw.put(qscale, 5);
+            if (flags & FLAG_SLICE_EXTRA) {
+                // extra_information_slice: ISO 11172-2 reserves it, the reference skips it a byte at a time
+                const uint32_t r = rng.next();
+                for (int e = (int)(r >> 30); e > 0; e--) {
+                    bw.put(1, 1);  // extra_bit_slice
+                    bw.put(0x80 | ((r >> (7 * e)) & 0x7F), 8);
+                }
+            }
             bw.put(0, 1);  // extra_bit_slice
             int dc_pred[3] = {128, 128, 128};
             int pmv_h = 0, pmv_v = 0;  // in coded units (full pels when full_pel)

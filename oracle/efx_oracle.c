@@ -865,8 +865,15 @@ static void decode_slice(dec_t* d, int code)
         return;
     reset_predictors(d);
     d->qscale = get_bits(d, 5);
-    while (get_bits(d, 1))
-        get_bits(d, 8);
+    {
+        int extra = 0, last = 0; /* extra_bit_slice / extra_information_slice, player.cpp:1261-1262 */
+        while (get_bits(d, 1)) {
+            last = (int)get_bits(d, 8);
+            extra++;
+        }
+        if (extra)
+            TRACE(EFXO_T_SLICE_EXTRA, extra, last, d->pic_type, 0);
+    }
 
     for (int mb = 0;; mb++) {
         if (peek_bits(d, 23) == 0) /* slice_done, player.cpp:1238-1249 */

@@ -2,8 +2,9 @@
 import numpy as np
 
 FRAME_BYTES = 101376
-SYN_FLAGS = [0, 1, 2, 4, 8, 16, 64, 128]   # generator flavours (espflix_amd.gen.FLAG_*); 64: every escape form of
-                                           # player.cpp:1092-1099, 128: ignored picture types, user data / extension units
+SYN_FLAGS = [0, 1, 2, 4, 8, 16, 64, 128, 256, 260]   # generator flavours (espflix_amd.gen.FLAG_*); 64: every escape form of
+                                           # player.cpp:1092-1099, 128: ignored picture types, user data / extension units,
+                                           # 256 / 260: extra_information_slice (player.cpp:1261-1262) in 12- / 5-slice pictures
 SYN_IDS = [0, 1, 7]               # 7: full_pel_forward = 1, odd ids: forward_f_code = 2
 
 

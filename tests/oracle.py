@@ -60,11 +60,13 @@ def trace_levels(data: np.ndarray, fmt: int) -> dict:
     escape forms reach those), coded zeros, -256, the pictures' coding types and the longest zero run."""
     data = np.ascontiguousarray(data, dtype=np.uint8)
     st = {"min": 0, "max": 0, "wide": 0, "zero": 0, "m256": 0, "coefs": 0, "max_run": 0, "pic_types": set(), "r_sizes": set(),
-          "full_pel": set(), "abandoned": 0, "bad": 0, "esc_forms": [0, 0, 0], "esc_small_long": 0, "esc_max_run": 0}
+          "full_pel": set(), "abandoned": 0, "bad": 0, "esc_forms": [0, 0, 0], "esc_small_long": 0, "esc_max_run": 0,
+          "slices": 0, "slice_extra": {}}  # slice_extra: (picture type, extra_information_slice bytes) -> slices
     cur = {"intra": False, "last": -1}
 
     def cb(_user, kind, a, b, c, e):
         if kind == 0:      # slice: c = type | full_pel << 4 | r_size << 8 | decoded << 16
+            st["slices"] += 1
             st["pic_types"].add(c & 15)
             if (c & 15) != 1:
                 st["r_sizes"].add((c >> 8) & 0xFF)
@@ -81,6 +83,8 @@ def trace_levels(data: np.ndarray, fmt: int) -> dict:
             st["esc_forms"][a] += 1
             st["esc_small_long"] += a != 0 and -127 <= c <= 127   # a level the short form could carry, sent the long way
             st["esc_max_run"] = max(st["esc_max_run"], b)
+        elif kind == 5:    # slice header with extra_information_slice: a = bytes, c = picture type
+            st["slice_extra"][(c, a)] = st["slice_extra"].get((c, a), 0) + 1
         elif kind == 2:    # coefficient: b = scan position, c = level
             if cur["intra"] and b == 0 and cur["last"] < 0:
                 cur["last"] = 0

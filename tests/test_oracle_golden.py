@@ -49,7 +49,7 @@ def test_synthetic_streams(flags, golden):
         assert hx(h2) == g["hashes"]
 
 
-def test_fixture_coverage_escape_levels_and_header_quirks():
+def test_fixture_coverage_escape_levels_and_header_quirks(clips):
     """What the two quirk flavours are FOR, checked on the oracle's parse trace (so that a change of the generator
     cannot quietly empty the fixture): flavour 64 reaches every form of the escape level of player.cpp:1092-1099 --
     "xx", "00 xx" (128..255, also small levels and 0 the long way) and "80 xx" (-256..-129, also -128..-1) -- and zero
@@ -78,6 +78,19 @@ def test_fixture_coverage_escape_levels_and_header_quirks():
         raw = es.tobytes()
         assert raw.count(b"\x00\x00\x01\xb2") > 0 and raw.count(b"\x00\x00\x01\xb5") > 0
     assert types == {0, 1, 2, 3, 4, 7} and r_sizes == {0, 1} and full == {0, 1}
+    # flavour 256: extra_bit_slice = 1 + information bytes (player.cpp:1261-1262) -- one, two and three of them, in I and
+    # in P pictures, in the 12-slice and in the 5-slice shape; no other fixture (nor either clip) has the bit set
+    for fl, per_pic in ((gen.FLAG_SLICE_EXTRA, 12), (gen.FLAG_SLICE_EXTRA | gen.FLAG_WIDE_SLICES, 5)):
+        seen = {}
+        for k in common.SYN_IDS:
+            t = oracle.trace_levels(gen.Batch(0, 8, 12, 12, fl).es(k), 0)
+            assert t["bad"] == 0 and t["slices"] == 12 * per_pic
+            for key, n in t["slice_extra"].items():
+                seen[key] = seen.get(key, 0) + n
+        assert {(1, 1), (1, 2), (1, 3), (2, 1), (2, 2), (2, 3)} <= set(seen) and sum(seen.values()) > 12 * per_pic
+    assert oracle.trace_levels(gen.Batch(0, 1, 12, 12, 0).es(0), 0)["slice_extra"] == {}
+    for clip in ("splash", "vmedia"):
+        assert oracle.trace_levels(clips[clip], 1)["slice_extra"] == {}
 
 
 def test_composite_fields(golden):
