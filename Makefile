@@ -10,7 +10,8 @@ HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall
 OBJS     = $(CSRC)/efx_api.o $(CSRC)/k_demux.o $(CSRC)/k_index.o $(CSRC)/k_parse.o $(CSRC)/k_recon.o $(CSRC)/k_video.o $(CSRC)/k_sbc.o $(CSRC)/k_tsindex.o $(CSRC)/efx_tables.o $(CSRC)/efx_multi.o
 
 .PHONY: all lib gen oracle ref clean dropin scale
-all: lib gen oracle scale
+# (`scale` links librccl: built by __graft_entry__.build() and by `make scale`, not by a plain `make`)
+all: lib gen oracle
 
 lib: espflix_amd/libefx.so
 gen: espflix_amd/gen/libefx_gen.so

@@ -34,6 +34,7 @@ STREAM_BAD_VLC = 8
 STREAM_MB_OVERRUN = 16
 STREAM_COEF_OVERRUN = 32
 STREAM_SERIAL_HUNT = 64   # the reference would misread bits between two start codes (its marker hunt is bit-serial): see efx.h
+STREAM_SLICE_ORDER = 128  # slice start codes of a picture not strictly rising in bitstream order: see efx.h
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EFX_LIB") or os.path.join(_HERE, "libefx.so")  # EFX_LIB: development builds

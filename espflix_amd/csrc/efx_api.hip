@@ -30,7 +30,7 @@ __global__ void k_index(const uint8_t*, const uint64_t*, int, PicInfo*, SliceTmp
 __global__ void k_advance(StreamState*, const uint32_t*, int64_t*, const int64_t*, int, int, int, int32_t*);
 __global__ void k_slice_scan(const PicInfo*, const uint32_t*, int, int, const uint32_t*, uint32_t*, DecodeCounters*);
 __global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, const uint64_t*, const uint32_t*, int, int,
-                             const uint32_t*, SliceDesc*);
+                             const uint32_t*, SliceDesc*, uint32_t*);
 __global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const ParseTables*, MbRec*, uint32_t*, uint32_t*,
                         int, int, int);
 __global__ void k_recon(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, const int32_t*, int, int);
@@ -141,7 +141,7 @@ struct efx_ctx {
         int64_t* d_pts = nullptr;    // per (stream, picture): PTS latched at the picture header (TS input); then, per
                                      // stream, the newest PES PTS of the upload (k_index -> k_advance)
         int32_t* d_call_pos = nullptr;  // per stream: ring position of this call's first picture, first picture with a PTS
-        hipEvent_t parse_done[kReconMerge] = {}, recon_done = nullptr;
+        hipEvent_t parse_done[kReconMerge] = {}, recon_done = nullptr, wrap_cleared = nullptr;
         int epoch = 0;
         int upload = 0;  // batch this call decoded
     } slot[kSlots];
@@ -160,6 +160,7 @@ struct efx_ctx {
     };
     Group groups[kMaxGroups];  // reconstruction groups of the most recent efx_decode
     int n_groups = 0;
+    int last_halves = 0;       // parse halves of the most recent efx_decode (the default while an upload's slice count is on its way)
     int last_upload = 0;       // batch the most recent efx_decode read
     int last_n_streams = 0;    // ... its stream count and format, as they were when the decode was queued (a later upload may
     bool last_ts_input = false;  // have recycled the Upload record by the time the results are fetched)
@@ -237,6 +238,10 @@ int group_first(int n_streams, int groups, int g)
     return g >= groups ? n_streams : (int)(((int64_t)n_streams * g / groups) & ~7);
 }
 
+// A context's device is made current on every entry: efx_multi_context() hands per-device contexts to the caller's own
+// thread (composite, PDM, timing, raw allocation), whose current device is whatever it was.
+void bind_device(efx_ctx* c);
+
 int fail(efx_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
 {
     if (c) {
@@ -272,6 +277,12 @@ int sync_all(efx_ctx* ctx)
 }
 
 size_t meta_bytes(size_t n) { return (n + 1) * sizeof(uint64_t) + 3 * n * sizeof(uint32_t); }
+
+void bind_device(efx_ctx* c)
+{
+    if (c)
+        (void)hipSetDevice(c->cfg.device);
+}
 
 }  // namespace
 
@@ -455,6 +466,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         for (auto& ev : sl.parse_done)
             A(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         A(hipEventCreateWithFlags(&sl.recon_done, hipEventDisableTiming));
+        A(hipEventCreateWithFlags(&sl.wrap_cleared, hipEventDisableTiming));
     }
     if (e != hipSuccess)
         return bail(EFX_ERR_DEVICE);
@@ -468,6 +480,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
 
 void efx_destroy(efx_ctx* ctx)
 {
+    bind_device(ctx);
     if (!ctx)
         return;
     if (ctx->copy_stream)
@@ -519,6 +532,8 @@ void efx_destroy(efx_ctx* ctx)
                 (void)hipEventDestroy(ev);
         if (sl.recon_done)
             (void)hipEventDestroy(sl.recon_done);
+        if (sl.wrap_cleared)
+            (void)hipEventDestroy(sl.wrap_cleared);
     }
     bool complete = ctx->own_stream && ctx->stream && ctx->copy_stream;
     for (auto ps : ctx->parse_streams)
@@ -580,6 +595,7 @@ static int ensure_ts_buffers(efx_ctx* ctx)
 
 int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, const size_t* len, int format)
 {
+    bind_device(ctx);
     if (!ctx || !data || !len || n_streams <= 0 || (format != EFX_FORMAT_ES && format != EFX_FORMAT_TS))
         return fail(ctx, EFX_ERR_ARG, "efx_upload_streams: bad argument");
     if (n_streams > ctx->cfg.max_streams)
@@ -735,6 +751,7 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
 
 int efx_download_es(efx_ctx* ctx, int stream, uint8_t* dst, size_t cap, size_t* es_len)
 {
+    bind_device(ctx);
     if (!ctx || !es_len || ctx->cur_up < 0 || stream < 0 || stream >= ctx->up[ctx->cur_up].n_streams || (!dst && cap))
         return ctx && ctx->cur_up < 0 ? fail(ctx, EFX_ERR_STATE, "efx_download_es: no streams uploaded") : EFX_ERR_ARG;
     efx_ctx::Upload& u = ctx->up[ctx->cur_up];
@@ -755,6 +772,7 @@ int efx_download_es(efx_ctx* ctx, int stream, uint8_t* dst, size_t cap, size_t* 
 
 int efx_reset(efx_ctx* ctx)
 {
+    bind_device(ctx);
     if (!ctx)
         return EFX_ERR_ARG;
     const size_t n = (size_t)ctx->cfg.max_streams;
@@ -773,6 +791,7 @@ int efx_reset(efx_ctx* ctx)
 
 int efx_play_reset(efx_ctx* ctx)
 {
+    bind_device(ctx);
     if (!ctx)
         return EFX_ERR_ARG;
     int r = sync_all(ctx);
@@ -789,6 +808,7 @@ int efx_play_reset(efx_ctx* ctx)
 
 int efx_stream_state(efx_ctx* ctx, int stream, uint32_t* frame_index, int* pts_seen, int64_t* newest_pts)
 {
+    bind_device(ctx);
     if (!ctx || stream < 0 || stream >= ctx->cfg.max_streams)
         return EFX_ERR_ARG;
     int r = sync_all(ctx);
@@ -807,6 +827,7 @@ int efx_stream_state(efx_ctx* ctx, int stream, uint32_t* frame_index, int* pts_s
 
 int efx_erase_frames(efx_ctx* ctx)
 {
+    bind_device(ctx);
     if (!ctx)
         return EFX_ERR_ARG;
     size_t bytes = (size_t)ctx->cfg.max_streams * ctx->cfg.ring_depth * kFrameBytes;
@@ -818,6 +839,7 @@ int efx_decode_from(efx_ctx* ctx, int first_picture) { return efx_decode_range(c
 
 int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
 {
+    bind_device(ctx);
     if (!ctx || first_picture < 0 || n_pictures < 1 || n_pictures > ctx->cfg.max_pictures)
         return EFX_ERR_ARG;
     if (ctx->cur_up < 0)
@@ -833,14 +855,21 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
     else if (group_count(n_all) > 1) {
         const efx_ctx::Upload& prev = ctx->up[(ctx->cur_up + kUploads - 1) % kUploads];
         const efx_ctx::Upload* src = u.hint_recorded ? &u : (prev.hint_recorded ? &prev : nullptr);
+        // (never waited for: the call stays asynchronous.  While this upload's own count is still on its way the
+        // previous upload's decides; the split is fixed once the upload's own count has arrived)
+        if (src == &u && hipEventQuery(u.hint_ready) != hipSuccess)
+            src = prev.hint_recorded && hipEventQuery(prev.hint_ready) == hipSuccess ? &prev : nullptr;
+        else if (src && hipEventQuery(src->hint_ready) != hipSuccess)
+            src = nullptr;
+        (void)hipGetLastError();  // (hipErrorNotReady is not an error)
         if (src) {
-            EFX_HIP(hipEventSynchronize(src->hint_ready));  // (index stage of an earlier call: long done)
             const uint32_t hint_slices = src->h_hint[0], hint_streams = src->h_hint[1];
             if (hint_slices && hint_streams && (double)u.es_used * hint_streams / n_all / hint_slices < kGroupMaxSliceBytes)
                 G = group_count(n_all);
             if (src == &u)
                 u.halves = G;
-        }
+        } else if (ctx->last_halves > 0 && ctx->last_halves <= group_count(n_all))
+            G = ctx->last_halves;
     }
     hipStream_t sr = ctx->stream;
     int timing_slot = -1;
@@ -849,6 +878,7 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
         ctx->timing_groups[timing_slot] = (uint8_t)G;
         ctx->timing_leaders[timing_slot] = 0;
     }
+    ctx->last_halves = G;
     ctx->last_upload = ctx->cur_up;
     ctx->last_n_streams = u.n_streams;
     ctx->last_ts_input = u.ts_input;
@@ -880,8 +910,13 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
             // ---- parse half (a parse stream): index -> slice list -> VLC parse -----------------------------------
             EFX_HIP(hipStreamWaitEvent(sp, u.uploaded, 0));     // the batch is in HBM (H2D and k_demux on the copy stream)
             EFX_HIP(hipStreamWaitEvent(sp, sl.recon_done, 0));  // the group kSlots back has released this slot
-            if (wrap)
-                EFX_HIP(hipMemsetAsync(sl.d_mbrecs + (size_t)s0 * P * kMbCount, 0, (size_t)n * P * kMbCount * sizeof(MbRec), sp));
+            // (the WHOLE slot: its stream ranges belong to other halves in other calls, and a record the current parse
+            // does not write must never match a tag of the previous 255-cycle)
+            if (wrap && g == h0) {
+                EFX_HIP(hipMemsetAsync(sl.d_mbrecs, 0, (size_t)ctx->cfg.max_streams * P * kMbCount * sizeof(MbRec), sp));
+                EFX_HIP(hipEventRecord(sl.wrap_cleared, sp));
+            } else if (wrap)
+                EFX_HIP(hipStreamWaitEvent(sp, sl.wrap_cleared, 0));
             efx_ctx::TimingEvents* te = timing_slot >= 0 ? &ctx->timing_ring[(size_t)timing_slot * kMaxGroups + g] : nullptr;
             if (te && !te->ev[0])
                 for (auto& ev : te->ev)
@@ -897,7 +932,7 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
             hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, sp, sl.d_pics, sl.d_pic_count, n, P, u.d_stream_perm + s0,
                                slice_base, counters);
             hipLaunchKernelGGL(k_slice_emit, dim3((n * P * kMaxSlicesPerPicture + 255) / 256), dim3(256), 0, sp, sl.d_pics,
-                               sl.d_slices_tmp, sl.d_pic_count, u.d_stream_off, slice_base, n, P, u.d_stream_perm + s0, descs);
+                               sl.d_slices_tmp, sl.d_pic_count, u.d_stream_off, slice_base, n, P, u.d_stream_perm + s0, descs, sl.d_status);
             if (g == 0 && u.h_hint) {
                 EFX_HIP(hipMemcpyAsync(u.h_hint, counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, sp));
                 EFX_HIP(hipEventRecord(u.hint_ready, sp));
@@ -906,7 +941,8 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
             if (te)
                 EFX_HIP(hipEventRecord(te->ev[1], sp));
             const int max_slices = n * P * kMaxSlicesPerPicture;
-            hipLaunchKernelGGL(k_parse, dim3((max_slices / kParseLanes * 64 + 255) / 256), dim3(256), 0, sp, u.d_es, descs, counters,
+            const int parse_waves = (max_slices + kParseLanes - 1) / kParseLanes;  // (rounded UP: one lane per slice slot)
+            hipLaunchKernelGGL(k_parse, dim3((parse_waves * 64 + 255) / 256), dim3(256), 0, sp, u.d_es, descs, counters,
                                ctx->d_tables, sl.d_mbrecs, sl.d_coefs, sl.d_status, P, sl.epoch, G > 1 ? 1 : 0);
             if (te)
                 EFX_HIP(hipEventRecord(te->ev[2], sp));
@@ -942,6 +978,7 @@ int efx_decode(efx_ctx* ctx) { return efx_decode_from(ctx, 0); }
 
 int efx_sync(efx_ctx* ctx)
 {
+    bind_device(ctx);
     if (!ctx)
         return EFX_ERR_ARG;
     return sync_all(ctx);
@@ -993,6 +1030,7 @@ static int fetch_results(efx_ctx* ctx)
 
 int efx_picture_count(efx_ctx* ctx, int stream, int* n_pictures)
 {
+    bind_device(ctx);
     if (!ctx || !n_pictures || stream < 0)
         return EFX_ERR_ARG;
     int r = fetch_results(ctx);
@@ -1006,6 +1044,7 @@ int efx_picture_count(efx_ctx* ctx, int stream, int* n_pictures)
 
 int efx_stream_status(efx_ctx* ctx, int stream, uint32_t* bits)
 {
+    bind_device(ctx);
     if (!ctx || !bits || stream < 0)
         return EFX_ERR_ARG;
     int r = fetch_results(ctx);
@@ -1019,6 +1058,7 @@ int efx_stream_status(efx_ctx* ctx, int stream, uint32_t* bits)
 
 int efx_picture_pts(efx_ctx* ctx, int stream, int picture, int64_t* pts)
 {
+    bind_device(ctx);
     if (!ctx || !pts || stream < 0 || picture < 0)
         return EFX_ERR_ARG;
     int r = fetch_results(ctx);
@@ -1036,6 +1076,7 @@ int efx_picture_pts(efx_ctx* ctx, int stream, int picture, int64_t* pts)
 
 int efx_stream_picture_slot(efx_ctx* ctx, int stream, int picture, int* slot)
 {
+    bind_device(ctx);
     if (!ctx || !slot || stream < 0 || picture < 0)
         return EFX_ERR_ARG;
     int r = fetch_results(ctx);
@@ -1051,6 +1092,7 @@ int efx_stream_picture_slot(efx_ctx* ctx, int stream, int picture, int* slot)
 
 int efx_picture_slot(efx_ctx* ctx, int picture)
 {
+    bind_device(ctx);
     int slot = 0;
     int r = efx_stream_picture_slot(ctx, 0, picture, &slot);
     return r ? r : slot;
@@ -1058,6 +1100,7 @@ int efx_picture_slot(efx_ctx* ctx, int picture)
 
 int efx_frame_device_ptr(efx_ctx* ctx, int stream, int slot, void** dptr)
 {
+    bind_device(ctx);
     if (!ctx || !dptr || stream < 0 || stream >= ctx->cfg.max_streams || slot < 0 || slot >= ctx->cfg.ring_depth)
         return EFX_ERR_ARG;
     *dptr = ctx->d_frames + ((size_t)stream * ctx->cfg.ring_depth + slot) * kFrameBytes;
@@ -1066,6 +1109,7 @@ int efx_frame_device_ptr(efx_ctx* ctx, int stream, int slot, void** dptr)
 
 int efx_download_frame(efx_ctx* ctx, int stream, int slot, uint8_t* dst)
 {
+    bind_device(ctx);
     void* p;
     int r = efx_frame_device_ptr(ctx, stream, slot, &p);
     if (r || !dst)
@@ -1077,6 +1121,7 @@ int efx_download_frame(efx_ctx* ctx, int stream, int slot, uint8_t* dst)
 
 int efx_upload_frame(efx_ctx* ctx, int stream, int slot, const uint8_t* src)
 {
+    bind_device(ctx);
     void* p;
     int r = efx_frame_device_ptr(ctx, stream, slot, &p);
     if (r || !src)
@@ -1088,6 +1133,7 @@ int efx_upload_frame(efx_ctx* ctx, int stream, int slot, const uint8_t* src)
 
 int efx_frame_hashes(efx_ctx* ctx, int first_stream, int n, uint64_t* out)
 {
+    bind_device(ctx);
     if (!ctx || !out || first_stream < 0 || n <= 0 || first_stream + n > ctx->cfg.max_streams)
         return EFX_ERR_ARG;
     const int D = ctx->cfg.ring_depth;
@@ -1119,6 +1165,7 @@ int efx_video_get_params(int ntsc, efx_video_params* out)
 
 int efx_composite_fields_ex(efx_ctx* ctx, const efx_field_opts* o, uint16_t* dst_device)
 {
+    bind_device(ctx);
     if (!ctx || !o || !dst_device || o->first_stream < 0 || o->n_streams <= 0 ||
         o->first_stream + o->n_streams > ctx->cfg.max_streams || o->slot < 0 || o->slot >= ctx->cfg.ring_depth)
         return EFX_ERR_ARG;
@@ -1156,6 +1203,7 @@ int efx_composite_fields_ex(efx_ctx* ctx, const efx_field_opts* o, uint16_t* dst
 int efx_composite_fields(efx_ctx* ctx, int first_stream, int n_streams, int slot, int ntsc, int frame_counter,
                          uint16_t* dst_device)
 {
+    bind_device(ctx);
     efx_field_opts o{};
     o.first_stream = first_stream;
     o.n_streams = n_streams;
@@ -1167,6 +1215,7 @@ int efx_composite_fields(efx_ctx* ctx, int first_stream, int n_streams, int slot
 
 int efx_pdm(efx_ctx* ctx, int n_streams, const int16_t* pcm_device, int n_samples, int32_t* state_device, uint16_t* dst_device)
 {
+    bind_device(ctx);
     if (!ctx || !pcm_device || !state_device || !dst_device || n_streams <= 0 || n_samples <= 0)
         return EFX_ERR_ARG;
     hipLaunchKernelGGL(k_pdm, dim3((n_streams + 63) / 64), dim3(64), 0, ctx->stream, pcm_device, n_streams, n_samples,
@@ -1181,6 +1230,7 @@ int efx_pdm(efx_ctx* ctx, int n_streams, const int16_t* pcm_device, int n_sample
 int efx_demux_audio(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, const size_t* len, uint8_t* audio_device,
                     size_t stride, uint32_t* audio_len_device)
 {
+    bind_device(ctx);
     if (!ctx || !ts || !len || !audio_device || !audio_len_device || n_streams <= 0)
         return fail(ctx, EFX_ERR_ARG, "efx_demux_audio: bad argument");
     if (n_streams > ctx->cfg.max_streams)
@@ -1238,6 +1288,7 @@ int efx_demux_audio(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, const
 int efx_index_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, const size_t* len, const uint32_t* trick_speed,
                       uint32_t bin_size, efx_idx_rec* recs, uint32_t* samples, size_t samples_cap)
 {
+    bind_device(ctx);
     if (!ctx || !ts || !len || !recs || !samples || n_streams <= 0 || bin_size == 0 || samples_cap == 0)
         return fail(ctx, EFX_ERR_ARG, "efx_index_streams: bad argument");
     if (n_streams > ctx->cfg.max_streams)
@@ -1393,6 +1444,7 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
                    int n_frames, void* state_device, int16_t* pcm_device, size_t pcm_stride, uint32_t* ret_device,
                    uint32_t* pcm_count_device, int flags)
 {
+    bind_device(ctx);
     if (!ctx || !frames_device || !state_device || !pcm_device || n_streams <= 0 || n_frames < 0 || frame_bytes <= 0 ||
         (size_t)frame_bytes * (size_t)n_frames > 0x7FFFFFFFu || ((uintptr_t)state_device & 3))
         return EFX_ERR_ARG;
@@ -1405,6 +1457,7 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
 
 int efx_set_timing(efx_ctx* ctx, int enable)
 {
+    bind_device(ctx);
     if (!ctx)
         return EFX_ERR_ARG;
     if (enable && ctx->timing_ring.empty()) {
@@ -1417,6 +1470,7 @@ int efx_set_timing(efx_ctx* ctx, int enable)
 
 int efx_get_timing(efx_ctx* ctx, efx_timing* out)
 {
+    bind_device(ctx);
     if (!ctx || !out)
         return EFX_ERR_ARG;
     int r = fetch_results(ctx);
@@ -1474,6 +1528,7 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out)
 
 int efx_device_alloc(efx_ctx* ctx, size_t bytes, void** dptr)
 {
+    bind_device(ctx);
     if (!ctx || !dptr)
         return EFX_ERR_ARG;
     EFX_HIP(hipMalloc(dptr, bytes));
@@ -1482,6 +1537,7 @@ int efx_device_alloc(efx_ctx* ctx, size_t bytes, void** dptr)
 
 int efx_device_free(efx_ctx* ctx, void* dptr)
 {
+    bind_device(ctx);
     if (!ctx)
         return EFX_ERR_ARG;
     EFX_HIP(hipFree(dptr));
@@ -1490,6 +1546,7 @@ int efx_device_free(efx_ctx* ctx, void* dptr)
 
 int efx_memcpy_h2d(efx_ctx* ctx, void* dst_device, const void* src, size_t bytes)
 {
+    bind_device(ctx);
     if (!ctx || !dst_device || !src)
         return EFX_ERR_ARG;
     EFX_HIP(hipStreamSynchronize(ctx->stream));
@@ -1499,6 +1556,7 @@ int efx_memcpy_h2d(efx_ctx* ctx, void* dst_device, const void* src, size_t bytes
 
 int efx_memcpy_d2h(efx_ctx* ctx, void* dst, const void* src_device, size_t bytes)
 {
+    bind_device(ctx);
     if (!ctx || !dst || !src_device)
         return EFX_ERR_ARG;
     EFX_HIP(hipStreamSynchronize(ctx->stream));

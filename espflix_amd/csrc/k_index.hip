@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void k_slice_emit(const PicInfo* __restrict__ 
                                                     const uint64_t* __restrict__ stream_off,
                                                     const uint32_t* __restrict__ slice_base, int n_streams,
                                                     int max_pictures, const uint32_t* __restrict__ stream_perm,
-                                                    SliceDesc* __restrict__ descs)
+                                                    SliceDesc* __restrict__ descs, uint32_t* __restrict__ status)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     int k = t % kMaxSlicesPerPicture, i = t / kMaxSlicesPerPicture;
@@ -490,6 +490,7 @@ __global__ __launch_bounds__(256) void k_slice_emit(const PicInfo* __restrict__ 
     // slice that runs on into a later slice's row, not for one that runs on into the row of a slice that came EARLIER
     // in the bitstream -- slices out of raster order AND damaged -- a documented deviation)
     uint32_t limit = kMbCount;
+    bool out_of_order = false;
     {
         const uint32_t code = st.len_code & 0xFF;
         const SliceTmp* all = slices_tmp + (size_t)s * max_pictures * kMaxSlicesPerPicture + pi.first_slice;
@@ -499,8 +500,11 @@ __global__ __launch_bounds__(256) void k_slice_emit(const PicInfo* __restrict__ 
                 limit = (other - 1) * kMbW;
             if (other == code && j > k)
                 limit = 0;  // superseded by a later slice with the same start code
+            out_of_order |= j < k && other >= code;
         }
     }
+    if (out_of_order)
+        atomicOr(&status[s], EFX_STREAM_SLICE_ORDER);  // (rare: damaged or unusual streams only)
     d.mb_limit = limit;
     d.reserved = 0;
     descs[slice_base[i] + k] = d;

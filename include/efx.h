@@ -8,8 +8,11 @@
  * push_video, video_isr, write_pcm_16) on top of this header for batch = 1.
  *
  * Conventions: plain pointers and sizes only; every function returns 0 (EFX_OK) or a negative
- * efx_status; nothing throws; one context per host thread (thread-compatible, no global state).
- * All work is queued on the context's HIP stream; efx_sync() waits for it.
+ * efx_status; nothing throws; one context per host thread (thread-compatible).  Process-global state: none that a
+ * caller can observe -- one mutex-guarded pool of parked HIP streams per device, so that a context created after
+ * another was destroyed runs on the same hardware queues (streams are never destroyed).
+ * Every entry point makes its context's device current for the calling thread (hipSetDevice) and leaves it so.
+ * All work is queued on the context's HIP streams; efx_sync() waits for it.
  */
 #ifndef EFX_H
 #define EFX_H
@@ -52,6 +55,7 @@ typedef enum efx_status {
                                          made of harmless 4-byte groups (player.cpp:1328-1330), bytes ahead of the first start \
                                          code.  The reference then acts on phantom markers; this decoder indexes byte-aligned \
                                          start codes, so its output for the stream is NOT the reference's */
+#define EFX_STREAM_SLICE_ORDER 128u   /* a picture's slice start codes do not rise strictly in bitstream order (a row coded twice,                                          rows out of raster order).  Every slice is parsed by its own lane and stops where any other                                          slice of the picture starts; of slices with the same code only the last is parsed.  The                                          reference, one serial decoder, lets whatever comes LATER in the bitstream overwrite: the                                          same frames when every such slice is complete, not when one of them is also damaged or                                          short -- the parity claim does not cover a stream with this bit */
 
 typedef enum efx_format {
     EFX_FORMAT_ES = 0, /* raw ISO 11172-2 video elementary stream */

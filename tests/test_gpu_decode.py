@@ -256,7 +256,8 @@ def test_decode_from_walks_a_long_stream(efx):
     dec.close()
 
 
-@pytest.mark.parametrize("flags,n,pictures", [(64 | 128 | 4 | 2, 12, 24), (64 | 8 | 16, 16, 12), (128 | 8 | 4 | 2, 16, 24), (64 | 1, 8, 8)])
+@pytest.mark.parametrize("flags,n,pictures", [(64 | 128 | 4 | 2, 12, 24), (64 | 8 | 16, 16, 12), (128 | 8 | 4 | 2, 16, 24), (64 | 1, 8, 8),
+                                              (256 | 64 | 8, 16, 12), (256 | 4 | 2 | 128, 12, 24)])
 def test_quirk_flavours_combined_fresh_ids(efx, flags, n, pictures):
     """Escape-level forms / ignored picture types / user data combined with custom matrices, wide slices, long skips,
     flat bright areas and I-only streams, on ids beyond the golden set (two GOPs where 24 pictures): HIP path = oracle

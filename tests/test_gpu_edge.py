@@ -263,3 +263,61 @@ def _picture_headers(es: bytes):
         if at < 0:
             return
         yield at
+
+
+@pytest.mark.parametrize("n,pictures", [(1, 1), (1, 2), (2, 1), (1, 3), (1, 17), (3, 5)])
+def test_tiny_batches_get_a_parse_lane_per_slice_slot(efx, n, pictures):
+    """n x pictures x 16 slice slots not a multiple of 64: the k_parse grid is rounded UP (a truncating division left
+    the last slots -- all of them below four pictures -- without a lane, and k_recon with stale records)."""
+    from espflix_amd import gen
+    b = gen.Batch(20, n, pictures, 12, 0)
+    streams = b.all_es()
+    dec = efx.Decoder(n, pictures, 2)
+    for _ in range(2):
+        dec.upload(streams, efx.FORMAT_ES)
+        dec.decode()
+        h = dec.frame_hashes()
+        for i, es in enumerate(streams):
+            cnt, oh, _, _ = oracle.decode(es, 0, True)
+            assert dec.picture_count(i) == cnt == pictures and dec.stream_status(i) == 0
+            assert int(h[i, dec.picture_slot(pictures - 1, i)]) == int(oh[-1]), (i, pictures)
+            if pictures > 1:
+                assert int(h[i, dec.picture_slot(pictures - 2, i)]) == int(oh[-2]), (i, pictures)
+    dec.close()
+
+
+def _units(es: np.ndarray):
+    """Byte ranges of the start-code units of an elementary stream: [(start code value, first byte, end byte)]."""
+    raw = es.tobytes()
+    at, pos = [], raw.find(b"\x00\x00\x01")
+    while pos >= 0:
+        at.append(pos)
+        pos = raw.find(b"\x00\x00\x01", pos + 3)
+    return [(raw[p + 3], p, at[i + 1] if i + 1 < len(at) else len(raw)) for i, p in enumerate(at)]
+
+
+def test_slices_out_of_raster_order_are_flagged(efx):
+    """Complete slices in another order, or a row coded twice, decode to the same frames here and in the reference (which
+    lets the later slice overwrite); the streams are flagged EFX_STREAM_SLICE_ORDER all the same, because the two decoders
+    part ways as soon as such a slice is also damaged (include/efx.h).  A stream in raster order is not flagged."""
+    from espflix_amd import gen
+    es = gen.Batch(3, 1, 4, 12, 0).es(0)
+    raw = es.tobytes()
+    units = _units(es)
+    pic = [i for i, (c, _, _) in enumerate(units) if c == 0x00][2]      # third picture (a P picture)
+    sl = [i for i in range(pic + 1, len(units)) if 1 <= units[i][0] <= 0xAF][:12]
+    assert [units[i][0] for i in sl] == list(range(1, 13))
+    def rebuild(order):
+        out = raw[:units[sl[0]][1]]
+        for i in order:
+            out += raw[units[i][1]:units[i][2]]
+        return np.frombuffer(out + raw[units[sl[-1]][2]:], dtype=np.uint8)
+    swapped = rebuild(sl[:4] + [sl[5], sl[4]] + sl[6:])                 # rows 5 and 6 change places
+    twice = rebuild(sl[:8] + [sl[7]] + sl[8:])                          # row 8 coded twice
+    res = run(efx, [es, swapped, twice], 4)
+    want = [int(x) for x in oracle.decode(es, 0, True)[1]]
+    for (n, st, h), name, flagged in zip(res, ("raster", "swapped", "twice"), (False, True, True)):
+        assert n == 4 and h == want, name
+        assert bool(st & efx.STREAM_SLICE_ORDER) == flagged and (st & ~efx.STREAM_SLICE_ORDER) == 0, (name, st)
+    for s2 in (swapped, twice):
+        assert [int(x) for x in oracle.decode(s2, 0, True)[1]] == want

@@ -20,7 +20,7 @@ def test_clips_frame_by_frame(clip, clips):
     assert np.array_equal(frames, rframes)
 
 
-@pytest.mark.parametrize("flags", [0, 2, 4, 8, 16, 2 | 4 | 16, 64, 128, 64 | 128 | 4 | 2])
+@pytest.mark.parametrize("flags", [0, 2, 4, 8, 16, 2 | 4 | 16, 64, 128, 64 | 128 | 4 | 2, 256, 256 | 4 | 8 | 64])
 def test_fresh_synthetic_streams(flags):
     """Stream ids beyond the committed golden set."""
     b = gen.Batch(100, 6, 24, 12, flags)   # two GOPs: sequence header repeated mid-stream
