@@ -16,9 +16,9 @@ all: lib gen oracle
 lib: espflix_amd/libefx.so
 gen: espflix_amd/gen/libefx_gen.so
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/efx_internal.h include/efx.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/efx_internal.h $(CSRC)/parse_tm.h $(CSRC)/efx_probe.h include/efx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(CSRC)/efx_tables.o: $(CSRC)/efx_tables.cpp $(CSRC)/efx_internal.h $(CSRC)/mpeg1_codebook.h
+$(CSRC)/efx_tables.o: $(CSRC)/efx_tables.cpp $(CSRC)/efx_internal.h $(CSRC)/parse_tm.h $(CSRC)/mpeg1_codebook.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 $(CSRC)/efx_multi.o: $(CSRC)/efx_multi.cpp include/efx.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@

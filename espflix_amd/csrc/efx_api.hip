@@ -17,6 +17,7 @@
 
 #include "efx.h"
 #include "efx_internal.h"
+#include "parse_tm.h"
 
 namespace efx {
 // kernels (k_demux.hip, k_index.hip, k_parse.hip, k_recon.hip, k_video.hip)
@@ -31,8 +32,8 @@ __global__ void k_advance(StreamState*, const uint32_t*, int64_t*, const int64_t
 __global__ void k_slice_scan(const PicInfo*, const uint32_t*, int, int, const uint32_t*, uint32_t*, DecodeCounters*);
 __global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, const uint64_t*, const uint32_t*, int, int,
                              const uint32_t*, SliceDesc*, uint32_t*);
-__global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const ParseTables*, MbRec*, uint32_t*, uint32_t*,
-                        int, int, int);
+__global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const TmTables*, MbRec*, TmU4*, uint32_t*, uint32_t*,
+                        int, int);
 __global__ void k_recon(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, const int32_t*, int, int);
 __global__ void k_frame_hash(const uint8_t*, int, uint64_t*);
 __global__ void k_fill(uint32_t*, uint32_t, size_t);
@@ -76,6 +77,7 @@ struct efx_ctx {
     bool decoded = false, results_valid = false;
 
     ParseTables* d_tables = nullptr;
+    TmTables* d_tm_tables = nullptr;  // the token machine's tables (parse_tm.h)
     uint8_t* d_frames = nullptr;
     StreamState* d_state = nullptr;  // per stream: ring position, "a PTS has been seen", newest PES PTS (k_advance)
 
@@ -131,6 +133,7 @@ struct efx_ctx {
         uint32_t* d_status = nullptr;
         DecodeCounters* d_counters = nullptr;  // kMaxGroups of them: one per group of a call
         MbRec* d_mbrecs = nullptr;
+        TmU4* d_raw = nullptr;       // k_parse's own scratch: raw macroblock records, pass 1 -> pass 2 (same shape as d_mbrecs)
         uint32_t* d_coefs = nullptr;
         // index / slice-list scratch of this call (per slot: two parse halves run concurrently)
         PicInfo* d_pics = nullptr;
@@ -401,6 +404,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
             e = r;
     };
     A(dalloc(&ctx->d_tables, 1));
+    A(dalloc(&ctx->d_tm_tables, 1));
     A(dalloc(&ctx->d_state, n));
     for (auto& u : ctx->up) {
         A(dalloc(&u.d_es, ctx->es_cap));
@@ -423,6 +427,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         A(dalloc(&sl.d_status, n));
         A(dalloc(&sl.d_counters, kMaxGroups));
         A(dalloc(&sl.d_mbrecs, n * P * kMbCount));
+        A(dalloc(&sl.d_raw, n * P * kMbCount));
         A(dalloc(&sl.d_coefs, ctx->es_cap * kCoefsPerEsByte));
         A(dalloc(&sl.d_pics, n * P));
         A(dalloc(&sl.d_slices_tmp, n * P * kMaxSlicesPerPicture));
@@ -445,6 +450,13 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     ParseTables* pt = new ParseTables;
     build_parse_tables(pt);
     A(hipMemcpy(ctx->d_tables, pt, sizeof(ParseTables), hipMemcpyHostToDevice));
+    {
+        TmTables* tt = new TmTables;
+        build_tm_tables(tt);
+        hipError_t e_tm = hipMemcpy(ctx->d_tm_tables, tt, sizeof(TmTables), hipMemcpyHostToDevice);
+        delete tt;
+        A(e_tm);
+    }
     delete pt;
     for (int ntsc = 0; ntsc < 2; ntsc++) {
         VideoTables vt;
@@ -490,7 +502,7 @@ void efx_destroy(efx_ctx* ctx)
             (void)hipStreamSynchronize(ps);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
-    void* bufs[] = {ctx->d_tables, ctx->d_state, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0],
+    void* bufs[] = {ctx->d_tables, ctx->d_tm_tables, ctx->d_state, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0],
                     ctx->d_video_lines[1], ctx->d_hash, ctx->d_ts, ctx->d_sbc_tables, ctx->d_idx_info, ctx->d_ts_off, ctx->d_idx_len,
                     ctx->d_idx_base, ctx->d_idx_seq};
     for (auto& te : ctx->timing_ring)
@@ -522,7 +534,7 @@ void efx_destroy(efx_ctx* ctx)
                 (void)hipEventDestroy(ev);
     }
     for (auto& sl : ctx->slot) {
-        void* sb[] = {sl.d_pic_count, sl.d_status, sl.d_counters, sl.d_mbrecs, sl.d_coefs, sl.d_pts, sl.d_call_pos,
+        void* sb[] = {sl.d_pic_count, sl.d_status, sl.d_counters, sl.d_mbrecs, sl.d_raw, sl.d_coefs, sl.d_pts, sl.d_call_pos,
                       sl.d_pics,      sl.d_slices_tmp, sl.d_qtab, sl.d_slice_base, sl.d_descs};
         for (void* b : sb)
             if (b)
@@ -942,8 +954,8 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
                 EFX_HIP(hipEventRecord(te->ev[1], sp));
             const int max_slices = n * P * kMaxSlicesPerPicture;
             const int parse_waves = (max_slices + kParseLanes - 1) / kParseLanes;  // (rounded UP: one lane per slice slot)
-            hipLaunchKernelGGL(k_parse, dim3((parse_waves * 64 + 255) / 256), dim3(256), 0, sp, u.d_es, descs, counters,
-                               ctx->d_tables, sl.d_mbrecs, sl.d_coefs, sl.d_status, P, sl.epoch, G > 1 ? 1 : 0);
+            hipLaunchKernelGGL(k_parse, dim3((parse_waves + kParseWaves - 1) / kParseWaves), dim3(64 * kParseWaves), 0, sp, u.d_es,
+                               descs, counters, ctx->d_tm_tables, sl.d_mbrecs, sl.d_raw, sl.d_coefs, sl.d_status, P, sl.epoch);
             if (te)
                 EFX_HIP(hipEventRecord(te->ev[2], sp));
             EFX_HIP(hipEventRecord(sl.parse_done[g - h0], sp));

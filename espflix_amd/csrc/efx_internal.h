@@ -22,9 +22,15 @@ constexpr int kMaxSlicesPerPicture = 16;   // slice start codes kept per picture
 #define EFX_PARSE_LANES 64
 #endif
 constexpr int kParseLanes = EFX_PARSE_LANES;  // slices per k_parse wave (one lane each)
+#ifndef EFX_PARSE_WAVES
+#define EFX_PARSE_WAVES 4
+#endif
+constexpr int kParseWaves = EFX_PARSE_WAVES;  // waves of a k_parse workgroup (they share one copy of the tables in LDS)
 constexpr int kIndexWaves = 4;             // waves of a k_index workgroup (one workgroup per stream)
 constexpr int kMaxUnitsPerStream = 4096;   // start codes indexed per stream per decode
-constexpr int kCoefsPerEsByte = 3;         // a coefficient costs >= 3 bits (2 + EOB for singletons)
+constexpr int kCoefsPerEsByte = 4;         // stream words a slice can need per byte: < 3 (a run/level costs >= 3 bits, a motion
+                                           // code's word >= 3 with its share of the macroblock header); 4 keeps every slice's region
+                                           // 16-byte aligned for k_parse's staged 16-byte stores
 constexpr int kEsTailBytes = 9;            // 00 | 00 00 01 B7 | 00 00 01 B7   (player.cpp:456,472)
 constexpr int kEsGuardBytes = 512;         // zero guard after the last stream (parse lanes read 128 B ahead)
 

@@ -242,3 +242,174 @@ void build_sbc_tables(SbcTables* t)
 }
 
 }  // namespace efx
+
+// ---- the token machine's tables (parse_tm.h) -----------------------------------------------------------------------------
+#include "parse_tm.h"
+
+namespace efx {
+
+namespace {
+
+struct TmBuilder {
+    TmTables* t;
+    // entry: code bits, raw bits, value, run / header value, flags, hacc shift of this token, next state word
+    static TmE make(int len, int xb, int v10, int r6, uint32_t flags, int hsh, uint32_t next)
+    {
+        TmE e;
+        e.x = (uint32_t)len | ((uint32_t)(v10 & 0x3FF) << 6) | ((uint32_t)xb << 16) | ((uint32_t)r6 << 20) | flags;
+        e.y = next | ((uint32_t)hsh << 6);
+        return e;
+    }
+    // every index of the `peek`-bit table at `base` whose top `len` bits equal `code`
+    void fill(int base, int peek, uint32_t code, int len, TmE e)
+    {
+        const int free_bits = peek - len;
+        for (int i = 0; i < (1 << free_bits); i++)
+            t->e[base + (int)(code << free_bits) + i] = e;
+    }
+};
+
+}  // namespace
+
+void build_tm_tables(TmTables* t)
+{
+    std::memset(t, 0, sizeof(*t));  // all zero = "no such code"
+    TmBuilder B{t};
+    const uint32_t wTypeP = tm_word(kTbTypeP, 6), wMbaA2 = tm_word(kTbMbaA2, 6), wMbaB1 = tm_word(kTbMbaB1, 8),
+                   wMbaB2 = tm_word(kTbMbaB2, 6), wMvH2 = tm_word(kTbMvH2, 6), wMvV1 = tm_word(kTbMvV1, 8),
+                   wMvV2 = tm_word(kTbMvV2, 6), wDctLo = tm_word(kTbDctLo, 10), wEscR = tm_word(kTbEscR, 6),
+                   wEscL = tm_word(kTbEscL, 8), wEscP = tm_word(kTbEscP, 1), wEscN = tm_word(kTbEscN, 1),
+                   wDcY2 = tm_word(kTbDcY2, 1), wDcC2 = tm_word(kTbDcC2, 2);
+    const int none = kHaccNone;
+
+    // macroblock_address_increment (table B-1) with stuffing (34) and escape (35), player.cpp:1267-1275.  Code words of
+    // 10 and 11 bits start with five zero bits: the 8-bit first level hands them to a 6-bit second level.  The B tables
+    // are the reference's SECOND loop, which only looks for escapes: after an escape a stuffing code counts as 34.
+    for (int after_escape = 0; after_escape < 2; after_escape++) {
+        const int l1 = after_escape ? kTbMbaB1 : kTbMbaA1, l2 = after_escape ? kTbMbaB2 : kTbMbaA2;
+        for (const VlcCode& c : kMbaCodes) {
+            TmE e;
+            if (c.value == 35)
+                e = TmBuilder::make(0, 0, 0, 33, 0, kHaccInc, wMbaB1);
+            else if (c.value == 34 && !after_escape)
+                e = TmBuilder::make(0, 0, 0, 1, 0, kHaccStuff, kWMbaA1);
+            else
+                e = TmBuilder::make(0, 0, 0, c.value, kTmTypeFix, kHaccInc, wTypeP);
+            if (c.len <= 8) {
+                e.x |= (uint32_t)c.len;
+                B.fill(l1, 8, c.code, c.len, e);
+            } else {
+                e.x |= (uint32_t)(c.len - 5);
+                B.fill(l2, 6, c.code & ((1u << (c.len - 5)) - 1), c.len - 5, e);
+            }
+        }
+        for (int i = 0; i < 6; i++)  // 0000 0xxx, xxx < 110: five zero bits, the rest at the second level
+            t->e[l1 + i] = TmBuilder::make(5, 0, 0, 0, 0, none, after_escape ? wMbaB2 : wMbaA2);
+    }
+
+    // macroblock_type, tables B-2a / B-2b (player.cpp:1292-1296): bit0 intra, bit1 pattern, bit3 motion forward, bit4 quant
+    // (+ 5 bits of quantiser_scale).  What follows is the macroblock's plan: motion, pattern, blocks 0..5 from bit 9 down.
+    auto type_entry = [&](int len, int value) {
+        const int plan = (value & 1) ? 0x3F : (((value & 8) ? 0x80 : 0) | ((value & 2) ? 0x40 : 0));
+        return TmBuilder::make(len, (value & 0x10) ? 5 : 0, plan << 2, value, kTmQuery | kTmType, 0, 0);
+    };
+    for (const VlcCode& c : kTypePCodes)
+        B.fill(kTbTypeP, 6, c.code, c.len, type_entry(c.len, c.value));
+    for (const VlcCode& c : kTypeICodes)
+        B.fill(kTbTypeI, 6, c.code, c.len, type_entry(c.len, c.value));
+
+    // motion codes, table B-4 (motion_vector(), player.cpp:891-910): the code + 16 travels in the run field and lands in
+    // the stream word's position field, forward_r_size residual bits follow every code but 0.  Horizontal, then vertical;
+    // after the vertical one the plan decides (pattern, or the macroblock is complete).
+    for (int vertical = 0; vertical < 2; vertical++) {
+        const int l1 = vertical ? kTbMvV1 : kTbMvH1, l2 = vertical ? kTbMvV2 : kTbMvH2;
+        for (const VlcCode& c : kMotionCodes) {
+            TmE e = TmBuilder::make(0, 0, 0, c.value + 16, kTmEmit | (c.value ? kTmR : 0) | (vertical ? kTmQuery : 0), none,
+                                    vertical ? 0u : wMvV1);
+            if (c.len <= 8) {
+                e.x |= (uint32_t)c.len;
+                B.fill(l1, 8, c.code, c.len, e);
+            } else {
+                e.x |= (uint32_t)(c.len - 5);
+                B.fill(l2, 6, c.code & ((1u << (c.len - 5)) - 1), c.len - 5, e);
+            }
+        }
+        for (int i = 0; i < 6; i++)
+            t->e[l1 + i] = TmBuilder::make(5, 0, 0, 0, 0, none, vertical ? wMvV2 : wMvH2);
+    }
+
+    // coded_block_pattern, table B-3 (player.cpp:1307): the blocks join the plan.  The six 9-bit codes share three 8-bit
+    // prefixes; each prefix has its own two-entry second level.
+    for (const VlcCode& c : kCbpCodes) {
+        if (c.len <= 8)
+            B.fill(kTbCbp1, 8, c.code, c.len, TmBuilder::make(c.len, 0, c.value << 4, 0, kTmQuery, none, 0));
+        else {
+            const int prefix = c.code >> 1;  // 1, 2 or 3
+            t->e[kTbCbp1 + prefix] = TmBuilder::make(8, 0, 0, 0, 0, none, tm_word(kTbCbp2 + 2 * (prefix - 1), 1));
+            t->e[kTbCbp2 + 2 * (prefix - 1) + (c.code & 1)] = TmBuilder::make(1, 0, c.value << 4, 0, kTmQuery, none, 0);
+        }
+    }
+
+    // dct_dc_size (player.cpp:1010-1068 as it reads them, beyond tables B-5a / B-5b): the size is the value AND the
+    // number of differential bits that follow.  Luminance: 00 -> 1, 01 -> 2, 100 -> 0, 101 -> 3, then k >= 2 ones and
+    // a zero -> k + 2 in k + 1 bits.  Chrominance: 00 -> 0, 01 -> 1, k ones and a zero -> k + 1 in min(k + 1, 10) bits.
+    auto dc_entry = [&](int len, int size) { return TmBuilder::make(len, size, size, 0, kTmEmit, none, kWDct); };
+    B.fill(kTbDcY1, 8, 0x0, 2, dc_entry(2, 1));
+    B.fill(kTbDcY1, 8, 0x1, 2, dc_entry(2, 2));
+    B.fill(kTbDcY1, 8, 0x4, 3, dc_entry(3, 0));
+    B.fill(kTbDcY1, 8, 0x5, 3, dc_entry(3, 3));
+    for (int k = 2; k <= 7; k++)
+        B.fill(kTbDcY1, 8, (1u << (k + 1)) - 2, k + 1, dc_entry(k + 1, k + 2));
+    t->e[kTbDcY1 + 0xFF] = TmBuilder::make(8, 0, 0, 0, 0, none, wDcY2);
+    t->e[kTbDcY2 + 0] = dc_entry(1, 10);  // eight ones and a zero
+    t->e[kTbDcY2 + 1] = dc_entry(2, 11);  // nine ones: ten bits are consumed whatever the tenth is
+    B.fill(kTbDcC1, 8, 0x0, 2, dc_entry(2, 0));
+    B.fill(kTbDcC1, 8, 0x1, 2, dc_entry(2, 1));
+    for (int k = 1; k <= 7; k++)
+        B.fill(kTbDcC1, 8, (1u << (k + 1)) - 2, k + 1, dc_entry(k + 1, k + 1));
+    t->e[kTbDcC1 + 0xFF] = TmBuilder::make(8, 0, 0, 0, 0, none, wDcC2);
+    t->e[kTbDcC2 + 0] = t->e[kTbDcC2 + 1] = dc_entry(1, 9);  // eight ones and a zero
+    t->e[kTbDcC2 + 2] = dc_entry(2, 10);                      // nine ones and a zero
+    t->e[kTbDcC2 + 3] = dc_entry(2, 11);                      // ten ones: ten bits consumed
+
+    // DCT coefficients, tables B-5c..f (player.cpp:1070-1103, 532-644): run / level with the sign as one raw bit.  Code
+    // words of more than 8 bits start with six zero bits: the first level consumes those, a 10-bit second level has the
+    // rest.  "10" = end_of_block: the plan decides; as the FIRST coefficient of a non-intra block "1s" is (0, +-1).  The
+    // escape 000001 is followed by a 6-bit run and a level of one byte, or 0x00 / 0x80 and a second byte.
+    const uint32_t coef = kTmEmit | kTmCoef;
+    for (int first = 0; first < 2; first++) {
+        const int hi = first ? kTbDctF : kTbDct;
+        for (const DctCode& c : kDctCodes) {
+            if (c.len <= 8)
+                B.fill(hi, 8, c.code, c.len, TmBuilder::make(c.len, 1, c.level, c.run, coef, none, kWDct));
+            else if (!first)
+                B.fill(kTbDctLo, 10, c.code & ((1u << (c.len - 6)) - 1), c.len - 6,
+                       TmBuilder::make(c.len - 6, 1, c.level, c.run, coef, none, kWDct));
+        }
+        B.fill(hi, 8, 0x0, 6, TmBuilder::make(6, 0, 0, 0, 0, none, wDctLo));
+        B.fill(hi, 8, kDctEscapeCode, kDctEscapeLen, TmBuilder::make(kDctEscapeLen, 0, 0, 0, 0, none, wEscR));
+        if (first)
+            B.fill(hi, 8, 0x1, 1, TmBuilder::make(1, 1, 1, 0, coef, none, kWDct));
+        else {
+            B.fill(hi, 8, 0x2, 2, TmBuilder::make(2, 0, 0, 0, kTmQuery, none, 0));
+            B.fill(hi, 8, 0x3, 2, TmBuilder::make(2, 1, 1, 0, coef, none, kWDct));
+        }
+    }
+    for (int run = 0; run < 64; run++)
+        t->e[kTbEscR + run] = TmBuilder::make(6, 0, 0, run, 0, none, wEscL);
+    for (int b = 0; b < 256; b++) {
+        if (b == 0x00)
+            t->e[kTbEscL + b] = TmBuilder::make(8, 0, 0, 0, 0, none, wEscP);
+        else if (b == 0x80)
+            t->e[kTbEscL + b] = TmBuilder::make(8, 0, 0, 0, 0, none, wEscN);
+        else
+            t->e[kTbEscL + b] = TmBuilder::make(8, 0, (int8_t)b, 0, coef, none, kWDct);
+    }
+    // second byte of a 16-bit level: its top bit chooses the entry, the other seven are raw bits ADDED to the value
+    t->e[kTbEscP + 0] = TmBuilder::make(1, 7, 0, 0, coef | kTmAdd, none, kWDct);
+    t->e[kTbEscP + 1] = TmBuilder::make(1, 7, 128, 0, coef | kTmAdd, none, kWDct);
+    t->e[kTbEscN + 0] = TmBuilder::make(1, 7, -256, 0, coef | kTmAdd, none, kWDct);
+    t->e[kTbEscN + 1] = TmBuilder::make(1, 7, -128, 0, coef | kTmAdd, none, kWDct);
+}
+
+}  // namespace efx

@@ -20,6 +20,8 @@
 
 #include "efx_internal.h"
 #include "efx.h"
+#include "parse_tm.h"
+#include "efx_probe.h"
 
 namespace efx {
 
@@ -143,6 +145,9 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
 
     const int lane = threadIdx.x;
     const int s = stream0 + blockIdx.x;
+    EFX_PROBE_CLAIM(2, blockIdx.x * gridDim.y + blockIdx.y);
+    EFX_PROBE_STAMP(1);
+    EFX_PROBE_SET(6, pic);
     const int b_raw = blockIdx.y * 64 + lane;
     const bool have = b_raw < kBlocksPerPicture;
     const int b = have ? b_raw : kBlocksPerPicture - 1;
@@ -302,7 +307,10 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             const uint32_t e = ent[k];
             const uint32_t f = (uint32_t)own[k] >> 8;
             const bool o_intra = f & 1;
-            const int n = e & 63, level = (int)e >> 6;
+            // k_parse's stream word: raw bits << 16 | value << 6 | scan position (parse_tm.h); an intra block's first word
+            // is its DC value << 6
+            const int n = e & 63;
+            const int level = (o_intra && n == 0) ? (int)e >> 6 : tm_level(e);
             // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
             uint32_t t = lds[n * kLaneDwords + 32];
             if (f & 0x80)
@@ -471,6 +479,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         if (stored)
             *reinterpret_cast<uint2*>(cur + dst0 + r * kStride) = make_uint2(lo, hi);
     }
+    EFX_PROBE_STAMP(4);
 }
 
 // FNV-1a-64 of whole ring frames, one lane per frame (verification helper, not on the timed path)
@@ -501,3 +510,5 @@ __global__ void k_fill(uint32_t* __restrict__ p, uint32_t v, size_t n)
 }
 
 }  // namespace efx
+
+EFX_PROBE_READER(recon)

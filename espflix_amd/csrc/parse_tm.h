@@ -1,0 +1,438 @@
+// parse_tm.h -- the slice parser of k_parse as a per-lane TOKEN MACHINE, lane-level code that also compiles for the host
+// (tests/parse_harness.cpp checks it against the parse trace of the test oracle without a GPU).
+//
+// Restates MpegDecoder::slice() (reference src/player.cpp:1251-1316), motion_vector(s) (891-920) and the entropy-decode
+// half of block() (999-1107) in two passes per slice, both run by the slice's lane:
+//
+//   1. tm_trip(): ONE TRIP = ONE CODE WORD, whatever it is -- an address increment, a macroblock type, a motion code, a
+//      coded block pattern, a DC size, a run/level, an end_of_block, a piece of an escape.  The lane is a state machine:
+//      its state names a table, the table entry (64 bits, one LDS read) says how many bits the word has, how many raw
+//      bits follow it, what it is worth and which state comes next.  There is no code per kind of token: coefficient
+//      entries, DC sizes + differential bits and motion codes + residuals all leave as the same 32-bit stream word
+//      (extra bits << 16 | value << 6 | scan position); macroblock_type / quantiser_scale / the address increment are
+//      ADDED into one header word (`hacc`) at a shift the entry names (tokens that are none of these add into a bit that
+//      is never read); every stream word counts into the byte of a 64-bit counter that the lane's place in the macroblock
+//      selects.  What follows a macroblock type, a pattern, the second motion code and an end_of_block comes from the
+//      macroblock's PLAN (a bit mask: motion, pattern, blocks 0..5) -- the one piece of per-kind logic, and the only
+//      place besides the end of a macroblock (one 16-byte record store) where lanes of a wave part ways.
+//      The 64 slices of a wave are at 64 different places of their macroblocks; a parser that walks blocks and
+//      macroblocks in lock-step (rounds 1-3) retires a symbol in one lane out of five (P pictures: one in seven).  Here
+//      every lane retires a code word on every trip.
+//   2. tm_finish(): the chains that run ACROSS the macroblocks of a slice, one macroblock per trip: address increments and
+//      skipped macroblocks (inc_mb, predict_zero: 1277-1289), quantiser_scale, motion vector prediction with its
+//      wrap-around (891-910), DC prediction (1053-1063, reset rules 1280,1302) -- turns the raw records into the MbRec
+//      k_recon reads and the DC tokens into absolute DC values.
+#pragma once
+#include <cstdint>
+
+#include "efx.h"
+#include "efx_internal.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define EFX_HD __host__ __device__ __forceinline__
+#else
+#define EFX_HD inline
+#endif
+
+namespace efx {
+
+// ---- tables -----------------------------------------------------------------------------------------------------------
+// One array of 64-bit entries; a state word = byte offset of its table << 16 | (32 - peek bits): index = window >> shift.
+//
+// entry.x (low dword)
+//   [4:0]   bits of the code word (0: no such code -- the lane stops)
+//   [5]     forward_r_size more raw bits follow (motion codes other than 0)
+//   [15:6]  value: coefficient level (sign-magnitude with the sign bit as raw bit, or two's complement: escapes), DC size;
+//           for entries that consult the plan: plan bits to add (<< 22: motion, pattern, blocks 0..5 from bit 31 down)
+//   [19:16] raw bits behind the code: the sign (1), quantiser_scale (5), the DC differential (= size), 7 of an escape's 8
+//   [25:20] run (added to the scan position); header tokens: the value added into hacc; motion: code + 16
+//   [26]    emit a stream word
+//   [27]    the next state comes from the macroblock's plan
+//   [28]    macroblock_type follows: in I pictures the state word gets the lane's TYPE_I bit
+//   [29]    a coefficient: its scan position must stay below 64
+//   [30]    a macroblock_type: a macroblock begins (the slice may hold no more)
+//   [31]    (copied into the stream word) level = value + raw bits instead of sign-magnitude
+// entry.y (high dword) = the next state word, with [11:6] = shift of THIS token's hacc contribution
+constexpr uint32_t kTmR = 1u << 5, kTmEmit = 1u << 26, kTmQuery = 1u << 27, kTmTypeFix = 1u << 28, kTmCoef = 1u << 29,
+                   kTmType = 1u << 30, kTmAdd = 1u << 31;
+constexpr uint32_t kTmOutMask = 0x8000FFC0u;
+
+// stream word: raw bits << 16 | value << 6 | scan position  (bit 31: additive level)
+EFX_HD int tm_level(uint32_t w)  // the signed level of a coefficient word (k_recon, harness)
+{
+    const int v = (int)(w << 16) >> 22;
+    const uint32_t x = (w >> 16) & 0x7FF;
+    return (w >> 31) ? v + (int)x : ((x & 1) ? -v : v);
+}
+
+// header word of a macroblock: macroblock_type [5:0] | quantiser_scale [10:6] | address increment [27:12] |
+// macroblock_stuffing seen [30:28] | [31] never read
+constexpr int kHaccInc = 12, kHaccStuff = 28, kHaccNone = 31;
+
+// table placement, in entries
+constexpr int kTbDcY1 = 0, kTbDcC1 = 256, kTbDctF = 512, kTbMvH1 = 768, kTbCbp1 = 1024;  // the plan's targets: 2 KB apart
+constexpr int kTbTypeP = 1280, kTbMbaA2 = 1344, kTbMbaB2 = 1408, kTbMvH2 = 1472, kTbMvV2 = 1536, kTbEscR = 1600;
+constexpr int kTbCbp2 = 1664 /* 3 x 2 */, kTbDcY2 = 1670, kTbDcC2 = 1672 /* 4 */, kTbEscP = 1676, kTbEscN = 1678;
+constexpr int kTbTypeI = kTbTypeP + 512;  // = 1792: the TYPE_I bit of a state word is bit 28 (4096 bytes)
+constexpr int kTbDct = 2048, kTbDctLo = 2304, kTbMbaA1 = 3328, kTbMbaB1 = 3584, kTbEscL = 3840, kTbMvV1 = 4096;
+constexpr int kTmEntries = 4352;
+constexpr uint32_t tm_word(int base, int peek) { return ((uint32_t)base * 8u) << 16 | (uint32_t)(32 - peek); }
+constexpr uint32_t kTmTypeIBit = 1u << 28;
+static_assert(((kTbTypeP * 8) & 4096) == 0 && kTbTypeI * 8 == kTbTypeP * 8 + 4096, "TYPE_I = TYPE_P + 4096 bytes");
+constexpr uint32_t kWMbaA1 = tm_word(kTbMbaA1, 8), kWPlan0 = tm_word(kTbDcY1, 8), kWDct = tm_word(kTbDct, 8);
+// plan position (motion, pattern, blocks 0..5) -> table, as nibbles indexed by the counter byte the position owns:
+// bytes 0..5 = blocks, 6 = motion, 7 = pattern
+constexpr uint32_t kPlanInter = 0x43222222u, kPlanIntra = 0x43110000u;
+
+struct alignas(8) TmE {
+    uint32_t x, y;
+};
+struct TmTables {
+    TmE e[kTmEntries];
+};
+void build_tm_tables(TmTables* t);
+
+// raw record of a coded macroblock (pass 1 -> pass 2): hacc | entries of blocks 0-3 | entries of blocks 4, 5, stream words
+// of the motion codes, flags | index of the macroblock's first stream word
+constexpr uint32_t kRawOverrun = 1u << 24, kRawBadBlock = 1u << 25, kRawRanPast = 1u << 26;
+
+// why a lane stopped
+enum : uint32_t { kStopNone = 0, kStopCode = 1 /* a table said "no such code" (or 23 zero bits) */, kStopRanPast = 2, kStopLimit = 3 };
+
+// direct sink (host; a slice's words beyond its region are dropped)
+struct TmDirectSink {
+    uint32_t* coefs;
+    uint32_t coef_last;
+    EFX_HD void put(uint32_t slot, uint32_t w)
+    {
+        if (slot <= coef_last)
+            coefs[slot] = w;
+    }
+    EFX_HD void commit(uint32_t, uint32_t) {}
+    EFX_HD void rewind(uint32_t, uint32_t) {}
+};
+
+struct TmSlice {      // constants of a slice
+    uint32_t coef_last;  // last stream slot of the slice's region
+    uint32_t type_bit;   // kTmTypeIBit in I pictures
+    uint32_t r_size;     // forward_f_code - 1
+    uint32_t max_mbs;    // coded macroblocks the slice can hold: mb_limit - its first address
+};
+
+struct TmLane {       // pass-1 state of a lane
+    uint32_t st;      // state word
+    uint32_t tok;     // next stream slot
+    uint32_t n;       // scan position of the next coefficient
+    uint32_t todo;    // the rest of the macroblock's plan, next item in bit 31
+    uint32_t c8;      // 8 x the counter byte of the item in progress (mod 64)
+    uint32_t hacc;
+    uint64_t cnt;
+    uint32_t mb_first;
+    uint32_t nmb;
+    uint32_t stop;    // kStop*
+    uint32_t stop_st, stop_win;
+};
+
+EFX_HD uint32_t tm_ubfe(uint32_t v, uint32_t off, uint32_t width)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(v, off, width);
+#else
+    off &= 31;
+    width &= 31;
+    return width ? (v >> off) & ((1u << width) - 1) : 0u;
+#endif
+}
+EFX_HD uint32_t tm_ffbh(uint32_t v)  // leading zeros; 0xFFFFFFFF for 0 (v_ffbh_u32)
+{
+    return v ? (uint32_t)__builtin_clz(v) : 0xFFFFFFFFu;
+}
+
+EFX_HD void tm_begin(TmLane& L, uint32_t tok_base)
+{
+    L.st = kWMbaA1;
+    L.tok = L.mb_first = tok_base;
+    L.n = L.todo = L.hacc = L.nmb = 0;
+    L.cnt = 0;
+    L.c8 = 40;
+    L.stop = kStopNone;
+    L.stop_st = L.stop_win = 0;
+}
+
+// One code word.  `win` = the next 32 bits of the slice, `e` = the entry of the lane's state for them (the caller looks
+// it up: address = (L.st >> 16) + ((win >> (L.st & 31)) << 3)); returns the number of bits consumed.
+// `sink` takes the stream words: put(slot, word) for every trip (a token that emits none writes the slot the next word
+// overwrites), commit(next slot, emitted) after it, rewind(old next slot, new next slot) when an abandoned block gives its slots back.
+template <class Sink, class RawStore>
+EFX_HD uint32_t tm_trip(TmLane& L, uint32_t win, TmE e, const TmSlice& sp, Sink&& sink, RawStore&& store_raw)
+{
+    const uint32_t len = e.x & 31;
+    const uint32_t xb = ((e.x >> 16) & 15) + ((e.x >> 5) & 1) * sp.r_size;
+    const uint32_t tot = len + xb;
+    const uint32_t x = tm_ubfe(win, 32 - tot, xb);
+    const uint32_t emit = (e.x >> 26) & 1;
+    const uint32_t r6 = (e.x >> 20) & 63;
+    const uint32_t npos = L.n + r6;
+    sink.put(L.tok, (x << 16) | (e.x & kTmOutMask) | npos);
+    L.tok += emit;
+    sink.commit(L.tok, emit);
+    L.n = npos + emit;
+    L.cnt += (uint64_t)emit << (L.c8 & 63);
+    L.hacc += (r6 | (x << 6)) << ((e.y >> 6) & 31);
+    // (where the lane was, should it stop here: only read when it does)
+    L.stop_st = L.st;
+    L.stop_win = win;
+    L.st = e.y | (e.x & sp.type_bit);
+    // no such code (or the 23 zero bits that end a slice): the lane stops where it is -- an all-zero entry changed nothing
+    uint32_t stop = len == 0 ? (uint32_t)kStopCode : (uint32_t)kStopNone;
+    bool query = (e.x & kTmQuery) != 0;
+    uint32_t plan_add = (e.x >> 6) & 0x3FF;
+    if ((e.x & kTmCoef) && npos > 63) {
+        // a coefficient beyond position 63: the block is abandoned (player.cpp:1106-1107) -- its stream words are forgotten,
+        // except an intra block's DC token, which pass 2 needs for the predictor (marked by a count of 0xFF)
+        const uint32_t sh = L.c8 & 63;
+        const uint32_t c = (uint32_t)(L.cnt >> sh) & 0xFF;
+        const uint32_t keep = L.hacc & 1;  // intra
+        const uint32_t tok_was = L.tok;
+        L.tok -= c - keep;
+        sink.rewind(tok_was, L.tok);
+        L.cnt = (L.cnt & ~((uint64_t)0xFF << sh)) | ((uint64_t)(keep ? 0xFFu : 0u) << sh) | ((uint64_t)kRawOverrun << 32);
+        plan_add = 0;
+        query = true;
+    }
+    if (query) {
+        // one macroblock more than the slice can hold (its address lies beyond the picture or in the next slice's rows):
+        // pass 2 decides what that means; nothing of it is kept
+        const bool full = (e.x & kTmType) && L.nmb >= sp.max_mbs;
+        stop = full ? (uint32_t)kStopLimit : stop;
+        // the plan: what a macroblock_type / coded_block_pattern adds to it, then its next item
+        L.todo |= plan_add << 22;
+        const uint32_t b = tm_ffbh(L.todo), sh = b + 1;
+        const bool more = L.todo != 0;
+        L.todo = more ? L.todo << (sh & 31) : 0u;
+        L.c8 += sh << 3;
+        const uint32_t plan = (L.hacc & 1) ? kPlanIntra : kPlanInter;
+        L.st = kWPlan0 + (tm_ubfe(plan, (L.c8 & 63) >> 1, 4) << 27);
+        L.n = 0;
+        if (!more) {  // the macroblock is complete
+            const bool ran_past = L.tok > sp.coef_last;  // ran past this slice's bytes without finding its end
+            store_raw(L.nmb, L.hacc, (uint32_t)L.cnt, (uint32_t)(L.cnt >> 32) | (ran_past ? kRawRanPast : 0u), L.mb_first);
+            L.nmb++;
+            L.mb_first = L.tok;
+            L.hacc = 0;
+            L.cnt = 0;
+            L.c8 = 40;
+            L.st = kWMbaA1;
+            stop = ran_past ? (uint32_t)kStopRanPast : stop;
+        }
+    }
+    L.stop = stop;
+    return tot;
+}
+
+// After the loop: the record of the macroblock in progress.  A code that does not exist inside a block leaves the
+// macroblock with the blocks before it (player.cpp: block() fails, slice() goes on -- into the same wall); inside a
+// macroblock header it leaves the address increment for pass 2 (the skipped macroblocks before it exist).
+EFX_HD bool tm_state_in_block(uint32_t st)
+{
+    const uint32_t base = st >> 19;  // entries
+    return base == kTbDcY1 || base == kTbDcC1 || base == kTbDctF || base == kTbDct || base == kTbDctLo || base == kTbEscR ||
+           base == kTbEscL || base == kTbEscP || base == kTbEscN || base == kTbDcY2 || base == kTbDcC2;
+}
+EFX_HD bool tm_state_in_mba(uint32_t st)
+{
+    const uint32_t base = st >> 19;
+    return base == kTbMbaA1 || base == kTbMbaA2 || base == kTbMbaB1 || base == kTbMbaB2;
+}
+template <class RawStore>
+EFX_HD void tm_end(TmLane& L, const TmSlice& sp, RawStore&& store_raw)
+{
+    if (L.stop != kStopCode)
+        return;
+    if (tm_state_in_block(L.stop_st)) {
+        const uint32_t sh = L.c8 & 63;
+        L.cnt &= ~((uint64_t)0xFF << sh);
+        store_raw(L.nmb, L.hacc, (uint32_t)L.cnt, (uint32_t)(L.cnt >> 32) | kRawBadBlock, L.mb_first);
+        L.nmb++;
+    } else if (L.nmb < sp.max_mbs)
+        store_raw(L.nmb, L.hacc, 0u, 0u, L.mb_first);  // (not counted: the header that could not be read)
+}
+
+// ---- pass 2 ------------------------------------------------------------------------------------------------------------
+struct TmFix {
+    int code;          // slice start code
+    int mb_limit;
+    uint32_t qscale;   // the slice header's quantiser_scale
+    uint32_t full_pel, r_size;
+    uint32_t rec_flags;  // 0x80 when the picture uses loaded quantiser matrices
+    uint32_t epoch;
+};
+
+#if defined(__HIPCC__)
+using TmU4 = ::uint4;
+#else
+struct alignas(16) TmU4 {
+    uint32_t x, y, z, w;
+};
+#endif
+
+EFX_HD int tm_motion(int pred, int mcode, uint32_t residual, int r_size)  // motion_vector(), player.cpp:891-910
+{
+    int d = mcode;
+    if (mcode != 0 && r_size != 0) {
+        const int a = mcode < 0 ? -mcode : mcode;
+        d = ((a - 1) << r_size) + (int)residual + 1;
+        if (mcode < 0)
+            d = -d;
+    }
+    const int scale = 1 << r_size;
+    int m = pred + d;
+    if (m > (scale << 4) - 1)
+        m -= scale << 5;
+    else if (m < -(scale << 4))
+        m += scale << 5;
+    return m;
+}
+
+// `raw(k)` reads raw record k of the slice; `recs` = the picture's 264 MbRec; returns the status bits of the slice.
+template <class RawLoad>
+EFX_HD uint32_t tm_finish(const TmLane& L, const TmFix& fx, RawLoad&& raw, uint32_t* coefs, TmU4* recs, uint32_t* n_mbs_out,
+                          uint32_t* n_coefs_out)
+{
+    uint32_t status = 0, n_mbs = 0, n_coefs = 0;
+    int mb_addr = (fx.code - 1) * kMbW - 1;
+    int dc_y = 128, dc_cr = 128, dc_cb = 128, mv_h = 0, mv_v = 0;
+    uint32_t qscale = fx.qscale;
+    const bool partial = L.stop == kStopCode && !tm_state_in_block(L.stop_st) && !tm_state_in_mba(L.stop_st) && L.nmb < (uint32_t)(fx.mb_limit - (fx.code - 1) * kMbW);
+    const uint32_t n_rec = L.nmb + (partial ? 1u : 0u);
+    bool stopped = false;
+    for (uint32_t k = 0; k < n_rec; k++) {
+        const TmU4 r = raw(k);
+        const uint32_t type = r.x & 63, qf = (r.x >> 6) & 31;
+        int inc = (int)((r.x >> kHaccInc) & 0xFFFF);
+        if (k == 0)
+            mb_addr += 1;  // inc_mb() ignores its argument: the first macroblock sits in column 0 (player.cpp:823-833,1277)
+        else {
+            if (inc > 1) {
+                dc_y = dc_cr = dc_cb = 128;  // reset_predictors(), player.cpp:1280-1281
+                mv_h = mv_v = 0;
+            }
+            while (inc > 1 && mb_addr + 1 < fx.mb_limit) {  // skipped macroblocks copy the reference (1283-1288)
+                mb_addr++;
+                TmU4 o;
+                o.x = r.w;
+                o.y = 0;
+                o.z = (2u << 16) | ((fx.epoch & 0xFF) << 24);
+                o.w = 0;
+                recs[mb_addr] = o;
+                n_mbs++;
+                inc--;
+            }
+            mb_addr++;
+        }
+        if (mb_addr >= fx.mb_limit) {  // past the picture, or into the macroblocks of the next slice
+            if (fx.mb_limit == kMbCount)
+                status |= EFX_STREAM_MB_OVERRUN;
+            stopped = true;
+            break;
+        }
+        if (k == L.nmb) {  // the header that could not be read
+            status |= EFX_STREAM_BAD_VLC;
+            stopped = true;
+            break;
+        }
+        const bool intra = type & 1;
+        if (type & 0x10)
+            qscale = qf;
+        uint32_t first = r.w;
+        if (intra)
+            mv_h = mv_v = 0;  // player.cpp:1300
+        else {
+            dc_y = dc_cr = dc_cb = 128;  // player.cpp:1302
+            if (type & 0x08) {
+                // the two motion codes left stream words: code + 16 (+ what the scan position had become) | residual << 16
+                const uint32_t wh = coefs[first], wv = coefs[first + 1];
+                const int ph = (int)(wh & 127), pv = (int)(wv & 127);
+                mv_h = tm_motion(mv_h, ph - 16, wh >> 16, (int)fx.r_size);
+                mv_v = tm_motion(mv_v, pv - (ph + 1) - 16, wv >> 16, (int)fx.r_size);
+                first += 2;
+            } else
+                mv_h = mv_v = 0;
+        }
+        uint32_t w_y = r.y, w_z = r.z & 0xFFFF;
+        if (intra) {
+            // DC tokens (size << 6 | differential bits << 16) -> absolute values (player.cpp:1010-1068), block by block
+            uint32_t at = first;
+            for (int b = 0; b < 6; b++) {
+                const uint32_t c = b < 4 ? (w_y >> (8 * b)) & 0xFF : (w_z >> (8 * (b - 4))) & 0xFF;
+                if (!c)
+                    continue;
+                const uint32_t tkn = coefs[at];
+                const uint32_t size = (tkn >> 6) & 0x3FF, bits = (tkn >> 16) & 0x7FF;
+                int pred = b < 4 ? dc_y : (b == 4 ? dc_cr : dc_cb);
+                if (size) {
+                    if (bits & (1u << (size - 1)))
+                        pred += (int)bits;
+                    else
+                        pred += (int)((~0u << size) | (bits + 1));
+                }
+                dc_y = b < 4 ? pred : dc_y;
+                dc_cr = b == 4 ? pred : dc_cr;
+                dc_cb = b == 5 ? pred : dc_cb;
+                if (c == 0xFF) {
+                    // an abandoned block: its DC moved the predictor, the block itself is not reconstructed -- take its
+                    // token out of the macroblock's entry list
+                    uint32_t rest = 0;
+                    for (int c2 = b + 1; c2 < 6; c2++) {
+                        const uint32_t cc = c2 < 4 ? (w_y >> (8 * c2)) & 0xFF : (w_z >> (8 * (c2 - 4))) & 0xFF;
+                        rest += cc == 0xFF ? 1u : cc;
+                    }
+                    for (uint32_t j = 0; j < rest; j++)
+                        coefs[at + j] = coefs[at + j + 1];
+                    if (b < 4)
+                        w_y &= ~(0xFFu << (8 * b));
+                    else
+                        w_z &= ~(0xFFu << (8 * (b - 4)));
+                    continue;
+                }
+                coefs[at] = (uint32_t)pred << 6;
+                at += c;
+            }
+        }
+        for (int b = 0; b < 6; b++)
+            n_coefs += b < 4 ? (w_y >> (8 * b)) & 0xFF : (w_z >> (8 * (b - 4))) & 0xFF;
+        // predict(), player.cpp:878-881: full-pel vectors are doubled
+        const uint32_t rec_mv = ((uint32_t)(fx.full_pel ? mv_h << 1 : mv_h) & 0xFFFF) | ((uint32_t)(fx.full_pel ? mv_v << 1 : mv_v) << 16);
+        const uint32_t rec_flags = (intra ? 1u : 0u) | (qscale << 2) | fx.rec_flags;
+        TmU4 o;
+        o.x = first;
+        o.y = w_y;
+        o.z = w_z | (rec_flags << 16) | ((fx.epoch & 0xFF) << 24);
+        o.w = rec_mv;
+        recs[mb_addr] = o;
+        n_mbs++;
+        if (r.z & kRawOverrun)
+            status |= EFX_STREAM_COEF_OVERRUN;
+        if (r.z & (kRawBadBlock | kRawRanPast)) {
+            status |= EFX_STREAM_BAD_VLC;
+            stopped = true;
+            break;
+        }
+    }
+    if (!stopped && L.stop == kStopCode && tm_state_in_mba(L.stop_st)) {
+        // an address increment that does not exist -- unless it is the 23 zero bits that end a slice (slice_done(),
+        // player.cpp:1238-1249), met where a macroblock would start (no stuffing, no escape before them)
+        const bool a2 = (L.stop_st >> 19) == (uint32_t)kTbMbaA2;
+        const bool clean = a2 && (L.stop_win >> 14) == 0 && ((L.hacc >> kHaccInc) & 0x7FFFF) == 0;
+        if (!clean)
+            status |= EFX_STREAM_BAD_VLC;
+    }
+    if (!stopped && L.stop == kStopLimit && fx.mb_limit == kMbCount)
+        status |= EFX_STREAM_MB_OVERRUN;  // a macroblock beyond the last one
+    *n_mbs_out = n_mbs;
+    *n_coefs_out = n_coefs;
+    return status;
+}
+
+}  // namespace efx

@@ -1,0 +1,289 @@
+// tests/parse_harness.cpp -- TEST TOOL: runs the lane-level slice parser of k_parse (espflix_amd/csrc/parse_tm.h, compiled
+// here for the host) over every slice of an elementary stream and checks each macroblock record and coefficient entry
+// against the parse trace of the test oracle (oracle/efx_oracle.c, efxo_set_trace) decoding the same stream.  CPU only: the
+// token machine's tables and both of its passes are verified without a GPU; the -m gpu tests then check the kernel built
+// from the same header against the frames of the reference.
+//
+//   parse_harness <file> [ts]     exit 0 and "OK slices=.. macroblocks=.. entries=.. trips=.." or a mismatch report
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+extern "C" {
+#include "efx_oracle.h"
+}
+#include "parse_tm.h"
+
+using namespace efx;
+
+namespace {
+
+struct Ev {
+    int kind, a, b, c, e;
+};
+std::vector<Ev> g_ev;
+void on_trace(void*, int kind, int a, int b, int c, int e) { g_ev.push_back({kind, a, b, c, e}); }
+
+struct HostBits {
+    const uint8_t* base;
+    uint32_t pos;
+    uint32_t window() const
+    {
+        const uint8_t* q = base + (pos >> 3);
+        uint64_t w = 0;
+        for (int i = 0; i < 8; i++)
+            w = (w << 8) | q[i];
+        return (uint32_t)((w << (pos & 7)) >> 32);
+    }
+};
+
+struct ExpMb {
+    int addr;
+    uint32_t flags;
+    int mvx, mvy;
+    uint32_t cnt[6];
+    std::vector<uint32_t> entries;
+};
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) {
+        fprintf(stderr, "usage: parse_harness <file> [ts]\n");
+        return 2;
+    }
+    FILE* f = fopen(argv[1], "rb");
+    if (!f)
+        return 2;
+    std::vector<uint8_t> in;
+    uint8_t buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0)
+        in.insert(in.end(), buf, buf + n);
+    fclose(f);
+    const bool ts = argc > 2 && !strcmp(argv[2], "ts");
+    std::vector<uint8_t> es;
+    if (ts) {
+        es.resize(in.size());
+        es.resize(efxo_ts_to_es(in.data(), in.size(), es.data(), es.size()));
+    } else
+        es = in;
+    const size_t es_len = es.size();
+    static const uint8_t tail[kEsTailBytes] = {0, 0, 0, 1, 0xB7, 0, 0, 1, 0xB7};
+    es.insert(es.end(), tail, tail + kEsTailBytes);
+    es.resize(es.size() + kEsGuardBytes, 0);
+
+    efxo_set_trace(on_trace, nullptr);
+    efxo_decode(in.data(), in.size(), ts ? 1 : 0, 1, nullptr, nullptr, nullptr, 0);
+    efxo_set_trace(nullptr, nullptr);
+
+    // start codes in stream order (byte aligned, up to the first sequence_end_code)
+    struct Unit {
+        uint32_t off;
+        int code;
+    };
+    std::vector<Unit> units;
+    for (size_t i = 0; i + 3 < es_len + kEsTailBytes; i++)
+        if (es[i] == 0 && es[i + 1] == 0 && es[i + 2] == 1) {
+            units.push_back({(uint32_t)i + 4, es[i + 3]});
+            if (es[i + 3] == 0xB7)
+                break;
+            i += 3;
+        }
+
+    TmTables* tab = new TmTables;
+    build_tm_tables(tab);
+    std::vector<uint32_t> coefs(es.size() * kCoefsPerEsByte + 16);
+    std::vector<MbRec> recs(kMbCount);
+    std::vector<TmU4> raw(kMbCount + 1);
+
+    size_t ev = 0;
+    long slices = 0, mbs = 0, entries = 0, rejected = 0, diverged = 0, trips = 0;
+    const uint32_t epoch = 7;
+    for (size_t u = 0; u < units.size(); u++) {
+        const int code = units[u].code;
+        if (code < 0x01 || code > 0xAF)
+            continue;
+        while (ev < g_ev.size() && g_ev[ev].kind != EFXO_T_SLICE)
+            ev++;
+        if (ev >= g_ev.size()) {
+            fprintf(stderr, "slice at %u: the oracle saw no more slices\n", units[u].off);
+            return 1;
+        }
+        const Ev se = g_ev[ev++];
+        if (se.b != code) {
+            // damaged stream: the oracle hunts for start codes bit by bit (player.cpp:1360-1363) and can see phantom ones
+            // that are not byte aligned (documented deviation); from here on the two no longer look at the same slices
+            diverged = 1;
+            break;
+        }
+        const bool decoded = (se.c >> 16) & 1;
+        if (se.a < 0 || !decoded || code - 2 >= kMbH) {
+            rejected++;
+            continue;
+        }
+        // the slice stops at the first macroblock of the next slice of its picture (k_slice_emit's rule, for slices in order)
+        int mb_limit = kMbCount;
+        for (size_t v = u + 1; v < units.size(); v++) {
+            if (units[v].code >= 0x01 && units[v].code <= 0xAF) {
+                if (units[v].code > code)
+                    mb_limit = (units[v].code - 1) * kMbW < kMbCount ? (units[v].code - 1) * kMbW : kMbCount;
+                break;
+            }
+            if (units[v].code == 0x00 || units[v].code == 0xB7 || units[v].code == 0xB3 || units[v].code == 0xB8)
+                break;
+        }
+        const uint32_t next = (u + 1 < units.size()) ? units[u + 1].off - 4 : (uint32_t)(es_len + kEsTailBytes);
+        const uint32_t len = next - units[u].off;
+        // expected macroblocks of this slice
+        std::vector<ExpMb> exp;
+        std::vector<uint32_t> blk_entries;
+        size_t e2 = ev, e_cut = 0;
+        std::vector<size_t> mb_event;
+        for (; e2 < g_ev.size() && g_ev[e2].kind != EFXO_T_SLICE; e2++) {
+            const Ev& x = g_ev[e2];
+            if (x.kind == EFXO_T_MB) {
+                mb_event.push_back(e2);
+                ExpMb m{};
+                m.addr = x.a;
+                m.flags = (uint32_t)x.b;
+                m.mvx = x.c;
+                m.mvy = x.e;
+                exp.push_back(m);
+                blk_entries.clear();
+            } else if (x.kind == EFXO_T_COEF) {
+                blk_entries.push_back(((uint32_t)x.c << 6) | (uint32_t)x.b);
+            } else if (x.kind == EFXO_T_BLOCK) {
+                if (x.b == 0) {
+                    exp.back().cnt[x.a] = (uint32_t)blk_entries.size();
+                    exp.back().entries.insert(exp.back().entries.end(), blk_entries.begin(), blk_entries.end());
+                }
+                blk_entries.clear();
+            }
+        }
+        // (a damaged slice that runs on: the oracle, one serial decoder, follows it into the rows of the next slice; a parse
+        // lane stops where that slice starts -- SliceDesc::mb_limit -- so only the macroblocks before it are compared)
+        e_cut = e2;
+        for (size_t q = 0; q < exp.size(); q++)
+            if (exp[q].addr >= mb_limit) {
+                exp.resize(q);
+                e_cut = mb_event[q];
+                break;
+            }
+        for (auto& r : recs)
+            memset(&r, 0, sizeof r);
+
+        // ---- the parser, as k_parse runs it ----------------------------------------------------------------------------
+        HostBits br{es.data(), units[u].off * 8};
+        TmSlice sp;
+        sp.coef_last = (units[u].off + len) * kCoefsPerEsByte - 1;
+        sp.type_bit = (se.c & 15) == 1 ? kTmTypeIBit : 0u;
+        sp.r_size = (se.c >> 8) & 7;
+        sp.max_mbs = (uint32_t)(mb_limit - (code - 1) * kMbW);
+        TmFix fx;
+        fx.code = code;
+        fx.mb_limit = mb_limit;
+        fx.full_pel = (se.c >> 4) & 1;
+        fx.r_size = sp.r_size;
+        fx.rec_flags = se.e ? 0x80u : 0u;
+        fx.epoch = epoch;
+        {
+            uint32_t w = br.window();
+            fx.qscale = w >> 27;
+            br.pos += 5;
+            while (br.window() >> 31)  // extra_bit_slice, player.cpp:1261-1262
+                br.pos += 9;
+            br.pos += 1;
+        }
+        TmLane L;
+        tm_begin(L, units[u].off * kCoefsPerEsByte);
+        auto store_raw = [&](uint32_t k, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { raw[k] = TmU4{a, b, c, d}; };
+        long guard = 0;
+        const long trips0 = trips;
+        while (L.stop == kStopNone) {
+            const uint32_t win = br.window();
+            const TmE e = tab->e[(L.st >> 19) + (win >> (L.st & 31))];
+            br.pos += tm_trip(L, win, e, sp, TmDirectSink{coefs.data(), sp.coef_last}, store_raw);
+            trips++;
+            if (++guard > 50000000) {
+                fprintf(stderr, "slice at %u: parser did not terminate\n", units[u].off);
+                return 1;
+            }
+        }
+        tm_end(L, sp, store_raw);
+        if (getenv("EFX_HARNESS_TRIPS"))
+            printf("slice pic=%d code=%d type=%d trips=%ld mbs=%u bytes=%u\n", se.a, code, se.c & 15, trips - trips0, L.nmb, len);
+        uint32_t nm = 0, nc = 0;
+        const uint32_t st = tm_finish(L, fx, [&](uint32_t k) { return raw[k]; }, coefs.data(), reinterpret_cast<TmU4*>(recs.data()), &nm, &nc);
+
+        if (nm != exp.size()) {
+            fprintf(stderr, "slice at %u (picture %d code %d): %u macroblock records, oracle %zu (status %u, stop %u)\n", units[u].off,
+                    se.a, code, nm, exp.size(), st, L.stop);
+            return 1;
+        }
+        uint32_t want_coefs = 0;
+        for (const ExpMb& m : exp) {
+            const MbRec& r = recs[m.addr];
+            const bool skipped = m.flags & 2;
+            const uint32_t want_flags = skipped ? 2u : ((m.flags & ~2u) | fx.rec_flags);
+            bool same = r.epoch == epoch && r.flags == want_flags && r.mvx == (skipped ? 0 : m.mvx) && r.mvy == (skipped ? 0 : m.mvy);
+            for (int k = 0; k < 6; k++)
+                same = same && r.cnt[k] == m.cnt[k];
+            size_t bad_k = 0;
+            for (size_t k = 0; same && k < m.entries.size(); k++) {
+                const uint32_t w = coefs[r.coef_base + k];
+                // an intra block's first entry is the DC value pass 2 wrote; everything else is a raw stream word
+                bool is_dc = false;
+                if (m.flags & 1) {
+                    size_t at = 0;
+                    for (int b = 0; b < 6; b++) {
+                        if (m.cnt[b] && at == k)
+                            is_dc = true;
+                        at += m.cnt[b];
+                    }
+                }
+                const uint32_t got = is_dc ? w : (((uint32_t)tm_level(w) << 6) | (w & 63));
+                same = got == m.entries[k];
+                bad_k = k;
+            }
+            if (!same) {
+                fprintf(stderr, "slice at %u (picture %d code %d) macroblock %d differs: flags %02x/%02x mv %d,%d/%d,%d cnt", units[u].off,
+                        se.a, code, m.addr, r.flags, want_flags, r.mvx, r.mvy, m.mvx, m.mvy);
+                for (int k = 0; k < 6; k++)
+                    fprintf(stderr, " %u/%u", r.cnt[k], m.cnt[k]);
+                fprintf(stderr, " (entry %zu)\n", bad_k);
+                return 1;
+            }
+            want_coefs += (uint32_t)m.entries.size();
+        }
+        if (nc != want_coefs) {
+            fprintf(stderr, "slice at %u: %u entries counted, oracle %u\n", units[u].off, nc, want_coefs);
+            return 1;
+        }
+        // what the oracle says about the slice's health, against the status bits
+        bool o_bad = false, o_over = false;
+        for (size_t q = ev; q < e_cut; q++)
+            if (g_ev[q].kind == EFXO_T_BLOCK) {
+                o_bad |= g_ev[q].b == -2;
+                o_over |= g_ev[q].b == -1;
+            }
+        if (o_over != ((st & EFX_STREAM_COEF_OVERRUN) != 0) || (o_bad && !(st & EFX_STREAM_BAD_VLC))) {
+            fprintf(stderr, "slice at %u (picture %d code %d): status %u, oracle abandoned=%d bad=%d\n", units[u].off, se.a, code, st, o_over,
+                    o_bad);
+            return 1;
+        }
+        if (getenv("EFX_HARNESS_CLEAN") && st) {
+            fprintf(stderr, "slice at %u (picture %d code %d): status %u on a stream declared clean\n", units[u].off, se.a, code, st);
+            return 1;
+        }
+        slices++;
+        mbs += nm;
+        entries += nc;
+        ev = e2;
+    }
+    printf("OK slices=%ld macroblocks=%ld entries=%ld trips=%ld rejected=%ld diverged=%ld\n", slices, mbs, entries, trips, rejected, diverged);
+    return 0;
+}
