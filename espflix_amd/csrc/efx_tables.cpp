@@ -273,8 +273,28 @@ struct TmBuilder {
 
 void build_tm_tables(TmTables* t)
 {
-    std::memset(t, 0, sizeof(*t));  // all zero = "no such code"
     TmBuilder B{t};
+    // every table starts out as "no such code": nothing consumed, nothing changed, on to the dead state of its kind
+    auto dead_fill = [&](int base, int count, uint32_t why) {
+        for (int i = 0; i < count; i++)
+            t->e[base + i] = TmBuilder::make(0, 0, 0, 0, 0, kHaccNone, tm_dead(why));
+    };
+    dead_fill(0, kTmEntries, kDeadBadBlock);
+    dead_fill(kTbMvH1, 256, kDeadBadHeader);
+    dead_fill(kTbCbp1, 256, kDeadBadHeader);
+    dead_fill(kTbTypeP, 64, kDeadBadHeader);
+    dead_fill(kTbTypeI, 64, kDeadBadHeader);
+    dead_fill(kTbMvH2, 64, kDeadBadHeader);
+    dead_fill(kTbMvV2, 64, kDeadBadHeader);
+    dead_fill(kTbMvV1, 256, kDeadBadHeader);
+    dead_fill(kTbCbp2, 6, kDeadBadHeader);
+    dead_fill(kTbMbaA1, 256, kDeadBadMba);
+    dead_fill(kTbMbaB1, 256, kDeadBadMba);
+    dead_fill(kTbMbaA2, 64, kDeadBadMba);
+    dead_fill(kTbMbaB2, 64, kDeadBadMba);
+    dead_fill(kTbEnd3, 48, kDeadBadMba);
+    for (uint32_t why = 0; why < 8; why++)
+        dead_fill(kTbDead + 2 * (int)why, 2, why);  // a dead state leads to itself
     const uint32_t wTypeP = tm_word(kTbTypeP, 6), wMbaA2 = tm_word(kTbMbaA2, 6), wMbaB1 = tm_word(kTbMbaB1, 8),
                    wMbaB2 = tm_word(kTbMbaB2, 6), wMvH2 = tm_word(kTbMvH2, 6), wMvV1 = tm_word(kTbMvV1, 8),
                    wMvV2 = tm_word(kTbMvV2, 6), wDctLo = tm_word(kTbDctLo, 10), wEscR = tm_word(kTbEscR, 6),
@@ -306,6 +326,13 @@ void build_tm_tables(TmTables* t)
         for (int i = 0; i < 6; i++)  // 0000 0xxx, xxx < 110: five zero bits, the rest at the second level
             t->e[l1 + i] = TmBuilder::make(5, 0, 0, 0, 0, none, after_escape ? wMbaB2 : wMbaA2);
     }
+    // slice_done(), player.cpp:1238-1249: 23 zero bits where an address increment would start end the slice.  11 of them
+    // have brought the lane to entry 0 of the second level; 4 + 4 + 4 more lead to the dead state kDeadEnd (tm_finish
+    // checks that no stuffing came before them: the reference looks for the end of the slice only between macroblocks).
+    t->e[kTbMbaA2] = TmBuilder::make(6, 0, 0, 0, 0, none, tm_word(kTbEnd3, 4));
+    t->e[kTbEnd3] = TmBuilder::make(4, 0, 0, 0, 0, none, tm_word(kTbEnd4, 4));
+    t->e[kTbEnd4] = TmBuilder::make(4, 0, 0, 0, 0, none, tm_word(kTbEnd5, 4));
+    t->e[kTbEnd5] = TmBuilder::make(0, 0, 0, 0, 0, none, tm_dead(kDeadEnd));
 
     // macroblock_type, tables B-2a / B-2b (player.cpp:1292-1296): bit0 intra, bit1 pattern, bit3 motion forward, bit4 quant
     // (+ 5 bits of quantiser_scale).  What follows is the macroblock's plan: motion, pattern, blocks 0..5 from bit 9 down.
@@ -318,14 +345,14 @@ void build_tm_tables(TmTables* t)
     for (const VlcCode& c : kTypeICodes)
         B.fill(kTbTypeI, 6, c.code, c.len, type_entry(c.len, c.value));
 
-    // motion codes, table B-4 (motion_vector(), player.cpp:891-910): the code + 16 travels in the run field and lands in
-    // the stream word's position field, forward_r_size residual bits follow every code but 0.  Horizontal, then vertical;
-    // after the vertical one the plan decides (pattern, or the macroblock is complete).
+    // motion codes, table B-4 (motion_vector(), player.cpp:891-910): the code + 16 and the forward_r_size residual bits
+    // that follow every code but 0 go into the macroblock's header word.  Horizontal, then vertical; after the vertical one
+    // the plan decides (pattern, or the macroblock is complete).
     for (int vertical = 0; vertical < 2; vertical++) {
         const int l1 = vertical ? kTbMvV1 : kTbMvH1, l2 = vertical ? kTbMvV2 : kTbMvH2;
         for (const VlcCode& c : kMotionCodes) {
-            TmE e = TmBuilder::make(0, 0, 0, c.value + 16, kTmEmit | (c.value ? kTmR : 0) | (vertical ? kTmQuery : 0), none,
-                                    vertical ? 0u : wMvV1);
+            TmE e = TmBuilder::make(0, 0, 0, c.value + 16, (c.value ? kTmR : 0) | (vertical ? kTmQuery : 0),
+                                    vertical ? kHaccMvV : kHaccMvH, vertical ? 0u : wMvV1);
             if (c.len <= 8) {
                 e.x |= (uint32_t)c.len;
                 B.fill(l1, 8, c.code, c.len, e);
@@ -394,6 +421,22 @@ void build_tm_tables(TmTables* t)
             B.fill(hi, 8, 0x2, 2, TmBuilder::make(2, 0, 0, 0, kTmQuery, none, 0));
             B.fill(hi, 8, 0x3, 2, TmBuilder::make(2, 1, 1, 0, coef, none, kWDct));
         }
+        // A short code word, its sign AND the end_of_block behind it, where all of that fits the 8-bit peek, are ONE token
+        // (the signed level in the entry, no raw bit): most blocks end on a short code, and an end_of_block of its own
+        // was one trip in seven.
+        auto with_eob = [&](uint32_t code, int len, int run, int level) {
+            if (len + 3 > 8)
+                return;
+            for (uint32_t sign = 0; sign < 2; sign++)
+                B.fill(hi, 8, (((code << 1) | sign) << 2) | 0x2, len + 3,
+                       TmBuilder::make(len + 3, 0, sign ? -level : level, run, coef | kTmQuery, none, kWDct));
+        };
+        for (const DctCode& c : kDctCodes)
+            with_eob(c.code, c.len, c.run, c.level);
+        if (first)
+            with_eob(0x1, 1, 0, 1);
+        else
+            with_eob(0x3, 2, 0, 1);
     }
     for (int run = 0; run < 64; run++)
         t->e[kTbEscR + run] = TmBuilder::make(6, 0, 0, run, 0, none, wEscL);

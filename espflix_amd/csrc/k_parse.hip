@@ -40,11 +40,9 @@ struct BitReader {
     uint32_t* ring;      // &ring[0][lane]; dword k lives at ring[(k % kRingDwords) * 64]
     uint32_t pos;        // bit position relative to gp
     uint32_t wr;         // dwords copied global -> ring so far (a multiple of 4)
-    // the window: dwords i, i + 1, i + 2 of the stream (i = pos >> 5).  A token is at most 28 bits, so an advance crosses at
-    // most one dword boundary; the dword that then becomes i + 2 is requested at once (`pend`) and put in place by the
-    // NEXT advance, where its latency has long been covered by that token's table look-up.
-    uint32_t hi, lo, nx, pend;
-    bool crossed;
+    // the window: dwords i, i + 1 of the stream (i = pos >> 5) and, on its way from the ring since the last advance, dword
+    // i + 2.  A token is at most 28 bits, so an advance crosses at most one dword boundary.
+    uint32_t hi, lo, nx;
 
     __device__ inline void topup()
     {
@@ -81,8 +79,6 @@ struct BitReader {
         hi = ring[(i % kRingDwords) * 64];
         lo = ring[((i + 1) % kRingDwords) * 64];
         nx = ring[((i + 2) % kRingDwords) * 64];
-        pend = 0;
-        crossed = false;
     }
     // the next 32 bits of the stream, MSB first
     __device__ inline uint32_t window() const
@@ -91,60 +87,67 @@ struct BitReader {
     }
     __device__ inline void advance(uint32_t n)  // n <= 32
     {
-        nx = crossed ? pend : nx;
         const uint32_t np = pos + n;
         const bool c = ((np ^ pos) >> 5) != 0;
         pos = np;
         hi = c ? lo : hi;
         lo = c ? nx : lo;
-        crossed = c;
-        pend = ring[(((np >> 5) + 2) % kRingDwords) * 64];
+        nx = ring[(((np >> 5) + 2) % kRingDwords) * 64];  // (used by the NEXT advance: a whole trip away)
+    }
+    __device__ inline void back(uint32_t n)  // gives the last n bits back (rare: the ring still holds their dwords)
+    {
+        pos -= n;
+        const uint32_t i = pos >> 5;
+        hi = ring[(i % kRingDwords) * 64];
+        lo = ring[((i + 1) % kRingDwords) * 64];
+        nx = ring[((i + 2) % kRingDwords) * 64];
     }
 };
 
-// Stream words leave in groups of four: a wave's 64 lanes write 64 different lines whatever a lane stores, and with one
-// dword per lane per trip the stores were what a trip cost (every lane emits on most trips now).  A lane stages its words
-// in four LDS dwords and stores 16 bytes when a group is full -- on a given trip only the lanes that just filled one.
+// Stream words leave in groups of four, every kTripsPerTopup trips: a wave's 64 lanes write 64 different lines whatever a
+// lane stores, and a store instruction costs the wave ~0.1 us however few lanes take part -- one dword per lane per trip
+// was what a trip cost, and one 16-byte store per trip by the lanes that had just filled a group still a third of it.  A
+// lane parks its words in an eight-dword LDS ring; between two groups of trips every lane that has four or more parked
+// stores one aligned group.
 struct StageSink {
-    uint32_t* stage;  // &stage[0][lane], dword j at stage[j * 64]
+    uint32_t* stage;  // &stage[0][lane], word k of the slice's stream at stage[(k & 7) * 64]
     uint32_t* coefs;
     uint32_t coef_last;  // last slot of the slice's region (regions start and end on multiples of four slots)
-    __device__ inline void put(uint32_t slot, uint32_t w) { stage[(slot & 3) * 64] = w; }
-    __device__ inline void flush(uint32_t group)
+    uint32_t flushed;    // slots below this one are in memory (a multiple of four)
+    __device__ inline void put(uint32_t slot, uint32_t w) { stage[(slot & 7) * 64] = w; }
+    __device__ inline void commit(uint32_t, uint32_t) {}
+    // between two groups of at most four trips: at most one group has filled up
+    __device__ inline void drain(uint32_t next)
     {
-        if (group * 4 <= coef_last)  // (words beyond the slice's region are dropped: the slice is flagged)
-            *reinterpret_cast<uint4*>(coefs + (size_t)group * 4) = make_uint4(stage[0], stage[64], stage[128], stage[192]);
-    }
-    __device__ inline void commit(uint32_t next, uint32_t emitted)
-    {
-        if (emitted && (next & 3) == 0)
-            flush((next >> 2) - 1);
-    }
-    __device__ inline void rewind(uint32_t was, uint32_t slot)
-    {
-        // an abandoned block gave slots back: if the group they lie in has left already, take its first words back
-        if ((slot >> 2) == (was >> 2))
-            return;
-        const uint4 v = *reinterpret_cast<const uint4*>(coefs + (size_t)(slot >> 2) * 4);
-        const uint32_t k = slot & 3;
-        if (k > 0)
-            stage[0] = v.x;
-        if (k > 1)
-            stage[64] = v.y;
-        if (k > 2)
-            stage[128] = v.z;
+        if (next - flushed >= 4) {
+            const uint32_t* g = stage + (flushed & 4) * 64;
+            if (flushed + 3 <= coef_last)  // (words beyond the slice's region are dropped: the slice is flagged)
+                *reinterpret_cast<uint4*>(coefs + (size_t)flushed) = make_uint4(g[0], g[64], g[128], g[192]);
+            flushed += 4;
+        }
     }
     __device__ inline void finish(uint32_t next)
     {
-        if (next & 3)
-            flush(next >> 2);
+        drain(next);
+        for (uint32_t k = flushed; k < next; k++)
+            if (k <= coef_last)
+                coefs[k] = stage[(k & 7) * 64];
+    }
+    __device__ inline void rewind(uint32_t, uint32_t slot)
+    {
+        // an abandoned block gave slots back: if they reach below what has left, those words come back from memory
+        if (slot < flushed) {
+            flushed = slot & ~3u;
+            for (uint32_t k = flushed; k < slot; k++)
+                stage[(k & 7) * 64] = coefs[k];
+        }
     }
 };
 
 struct SharedTables {
     TmTables t;
     uint32_t ring[kParseWaves][kRingDwords + 4][64];  // [wave][dword][lane]; rows kRingDwords ... are scratch
-    uint32_t stage[kParseWaves][4][64];               // [wave][word of the group][lane]
+    uint32_t stage[kParseWaves][8][64];               // [wave][stream word & 7][lane]
 };
 
 }  // namespace
@@ -182,15 +185,15 @@ __global__ __launch_bounds__(64 * kParseWaves) void k_parse(const uint8_t* __res
     const int first_mb = (code - 1) * kMbW;
     const int mb_limit = (int)d.mb_limit;
     // (a slice superseded by a later one with the same start code has limit 0: nothing of it is parsed)
-    bool alive = mine && mb_limit > first_mb;
+    const bool has_slice = mine && mb_limit > first_mb;
 
     TmSlice sp;
     sp.coef_last = (d.es_off + d.es_len) * kCoefsPerEsByte - 1;  // (a slice never outgrows its region: kCoefsPerEsByte)
     sp.type_bit = ((d.pic_code_flags >> 16) & 3) == 1 ? kTmTypeIBit : 0u;
     sp.r_size = (d.pic_code_flags >> 19) & 7;
-    sp.max_mbs = alive ? (uint32_t)(mb_limit - first_mb) : 0u;
+    sp.max_mbs = has_slice ? (uint32_t)(mb_limit - first_mb) : 0u;
     const size_t rec0 = ((size_t)d.stream * max_pictures + pic) * kMbCount;
-    TmU4* const raw = raw_recs + rec0 + (alive ? first_mb : 0);
+    TmU4* const raw = raw_recs + rec0 + (has_slice ? first_mb : 0);
 
     BitReader br;
     br.init(es, d.es_off, &sh.ring[threadIdx.x >> 6][0][threadIdx.x & 63]);
@@ -200,20 +203,27 @@ __global__ __launch_bounds__(64 * kParseWaves) void k_parse(const uint8_t* __res
     {
         fx.qscale = br.window() >> 27;
         br.advance(5);
-        while (alive && (br.window() >> 31)) {  // extra_bit_slice = 1: skip it and 8 bits of information
+        while (has_slice && (br.window() >> 31)) {  // extra_bit_slice = 1: skip it and 8 bits of information
             br.advance(9);
             br.topup();
         }
         br.advance(1);
     }
     TmLane L;
-    tm_begin(L, d.es_off * kCoefsPerEsByte);
+    const uint32_t tok_base = d.es_off * kCoefsPerEsByte;
+    tm_begin(L, tok_base, has_slice);
     auto store_raw = [&](uint32_t k, uint32_t a, uint32_t b, uint32_t c, uint32_t e) { raw[k] = make_uint4(a, b, c, e); };
     const char* const tab = reinterpret_cast<const char*>(&sh.t);
-    StageSink sink{&sh.stage[threadIdx.x >> 6][0][threadIdx.x & 63], coefs, sp.coef_last};
+    StageSink sink{&sh.stage[threadIdx.x >> 6][0][threadIdx.x & 63], coefs, sp.coef_last, d.es_off * kCoefsPerEsByte};
+    auto lookup = [&](uint32_t st, uint32_t win) {
+        return *reinterpret_cast<const TmE*>(tab + (st >> 16) + ((win >> (st & 31)) << 3));
+    };
 
     // ---- pass 1: one code word per lane per trip -----------------------------------------------------------------------
-    // (kTripsPerTopup trips between two looks at the ring: a trip consumes less than a dword and the ring keeps kRingLow ahead)
+    // The table entry of the NEXT token is requested as soon as this token's length and successor state are known; the
+    // rest of the trip runs in the shadow of that LDS round trip.  kTripsPerTopup trips between two looks at the ring (a
+    // trip consumes less than a dword and the ring keeps kRingLow ahead) and at who is still alive: a lane that has stopped
+    // sits in a dead state and takes the wave's trips without effect.
     EFX_PROBE_STAMP(2);
     EFX_PROBE_SET(6, pic | ((d.pic_code_flags >> 16) & 3) << 8);
     constexpr int kTripsPerTopup = 4;
@@ -221,24 +231,38 @@ __global__ __launch_bounds__(64 * kParseWaves) void k_parse(const uint8_t* __res
 #ifdef EFX_PROBE
     unsigned efx_probe_trips = 0;
 #endif
+    uint32_t win = br.window();
+    TmE e = lookup(L.st, win);
     do {
         br.topup();
+        sink.drain(L.tok);
 #pragma unroll
         for (int t = 0; t < kTripsPerTopup; t++) {
-            if (alive) {
-                const uint32_t win = br.window();
-                const TmE e = *reinterpret_cast<const TmE*>(tab + (L.st >> 16) + ((win >> (L.st & 31)) << 3));
-                br.advance(tm_trip(L, win, e, sp, sink, store_raw));
-                alive = L.stop == kStopNone;
+            const uint32_t win0 = win;
+            const TmE e0 = e;
+            const bool overflow = tm_trip(
+                L, win0, e0, sp,
+                [&](uint32_t bits, uint32_t st) {
+                    br.advance(bits);
+                    win = br.window();
+                    e = lookup(st, win);
+                },
+                sink, store_raw);
+            if (__any(overflow)) {  // (damaged streams only)
+                if (overflow) {
+                    br.back(tm_overflow(L, e0, sp, sink, store_raw));
+                    win = br.window();
+                    e = lookup(L.st, win);
+                }
             }
         }
 #ifdef EFX_PROBE
         efx_probe_trips += kTripsPerTopup;
 #endif
-    } while (__any(alive));
+    } while (__any(tm_alive(L.st)));
     EFX_PROBE_STAMP(3);
     EFX_PROBE_SET(5, efx_probe_trips);
-    if (!mine || mb_limit <= first_mb)
+    if (!has_slice)
         return;
     sink.finish(L.tok);
     tm_end(L, sp, store_raw);
@@ -251,8 +275,8 @@ __global__ __launch_bounds__(64 * kParseWaves) void k_parse(const uint8_t* __res
     fx.rec_flags = ((d.pic_code_flags >> 22) & 1) ? 0x80u : 0u;  // loaded quantiser matrices: recorded per macroblock for k_recon
     fx.epoch = (uint32_t)epoch;
     uint32_t n_mbs = 0, n_coefs = 0;
-    const uint32_t st = tm_finish(L, fx, [&](uint32_t k) { return raw[k]; }, coefs, reinterpret_cast<TmU4*>(mbrecs + rec0), &n_mbs,
-                                  &n_coefs);
+    const uint32_t st = tm_finish(L, fx, tok_base, [&](uint32_t k) { return raw[k]; }, coefs, reinterpret_cast<TmU4*>(mbrecs + rec0),
+                                  &n_mbs, &n_coefs);
     EFX_PROBE_MAX(4, wall_clock64());
     if (st)
         atomicOr(&status[d.stream], st);

@@ -41,12 +41,12 @@ namespace efx {
 // One array of 64-bit entries; a state word = byte offset of its table << 16 | (32 - peek bits): index = window >> shift.
 //
 // entry.x (low dword)
-//   [4:0]   bits of the code word (0: no such code -- the lane stops)
+//   [4:0]   bits of the code word
 //   [5]     forward_r_size more raw bits follow (motion codes other than 0)
 //   [15:6]  value: coefficient level (sign-magnitude with the sign bit as raw bit, or two's complement: escapes), DC size;
 //           for entries that consult the plan: plan bits to add (<< 22: motion, pattern, blocks 0..5 from bit 31 down)
 //   [19:16] raw bits behind the code: the sign (1), quantiser_scale (5), the DC differential (= size), 7 of an escape's 8
-//   [25:20] run (added to the scan position); header tokens: the value added into hacc; motion: code + 16
+//   [25:20] run (added to the scan position); header tokens: the value added into hacc
 //   [26]    emit a stream word
 //   [27]    the next state comes from the macroblock's plan
 //   [28]    macroblock_type follows: in I pictures the state word gets the lane's TYPE_I bit
@@ -54,6 +54,11 @@ namespace efx {
 //   [30]    a macroblock_type: a macroblock begins (the slice may hold no more)
 //   [31]    (copied into the stream word) level = value + raw bits instead of sign-magnitude
 // entry.y (high dword) = the next state word, with [11:6] = shift of THIS token's hacc contribution
+//
+// A bit pattern that is no code word leads to a DEAD state: a two-entry table whose entries consume nothing, change nothing
+// and lead back to it -- a lane that has stopped keeps taking trips with its wave at no cost to its state, and WHY it
+// stopped is which dead state it is in.  The 23 zero bits that end a slice (slice_done(), player.cpp:1238-1249) are a
+// chain of link entries through the address-increment tables that ends in the dead state kDeadEnd.
 constexpr uint32_t kTmR = 1u << 5, kTmEmit = 1u << 26, kTmQuery = 1u << 27, kTmTypeFix = 1u << 28, kTmCoef = 1u << 29,
                    kTmType = 1u << 30, kTmAdd = 1u << 31;
 constexpr uint32_t kTmOutMask = 0x8000FFC0u;
@@ -66,21 +71,38 @@ EFX_HD int tm_level(uint32_t w)  // the signed level of a coefficient word (k_re
     return (w >> 31) ? v + (int)x : ((x & 1) ? -v : v);
 }
 
-// header word of a macroblock: macroblock_type [5:0] | quantiser_scale [10:6] | address increment [27:12] |
-// macroblock_stuffing seen [30:28] | [31] never read
-constexpr int kHaccInc = 12, kHaccStuff = 28, kHaccNone = 31;
+// header word of a macroblock (64 bits): macroblock_type [5:0] | quantiser_scale [10:6] | address increment [27:12] |
+// macroblock_stuffing seen [30:28] | horizontal motion code + 16 [37:32], its residual [43:38] | vertical [49:44], [55:50] |
+// [63] never read
+constexpr int kHaccInc = 12, kHaccStuff = 28, kHaccMvH = 32, kHaccMvV = 44, kHaccNone = 63;
 
 // table placement, in entries
 constexpr int kTbDcY1 = 0, kTbDcC1 = 256, kTbDctF = 512, kTbMvH1 = 768, kTbCbp1 = 1024;  // the plan's targets: 2 KB apart
 constexpr int kTbTypeP = 1280, kTbMbaA2 = 1344, kTbMbaB2 = 1408, kTbMvH2 = 1472, kTbMvV2 = 1536, kTbEscR = 1600;
 constexpr int kTbCbp2 = 1664 /* 3 x 2 */, kTbDcY2 = 1670, kTbDcC2 = 1672 /* 4 */, kTbEscP = 1676, kTbEscN = 1678;
+constexpr int kTbEnd3 = 1680, kTbEnd4 = 1696, kTbEnd5 = 1712;  // 16 each: the rest of a slice's 23 closing zero bits
 constexpr int kTbTypeI = kTbTypeP + 512;  // = 1792: the TYPE_I bit of a state word is bit 28 (4096 bytes)
 constexpr int kTbDct = 2048, kTbDctLo = 2304, kTbMbaA1 = 3328, kTbMbaB1 = 3584, kTbEscL = 3840, kTbMvV1 = 4096;
-constexpr int kTmEntries = 4352;
+constexpr int kTbDead = 4352;  // 8 x 2: the dead states (the HIGHEST tables: "alive" is one comparison)
+constexpr int kTmEntries = kTbDead + 16;
 constexpr uint32_t tm_word(int base, int peek) { return ((uint32_t)base * 8u) << 16 | (uint32_t)(32 - peek); }
 constexpr uint32_t kTmTypeIBit = 1u << 28;
 static_assert(((kTbTypeP * 8) & 4096) == 0 && kTbTypeI * 8 == kTbTypeP * 8 + 4096, "TYPE_I = TYPE_P + 4096 bytes");
 constexpr uint32_t kWMbaA1 = tm_word(kTbMbaA1, 8), kWPlan0 = tm_word(kTbDcY1, 8), kWDct = tm_word(kTbDct, 8);
+// why a lane stopped
+enum : uint32_t {
+    kDeadEnd = 0,       // the 23 zero bits that end a slice
+    kDeadBadBlock = 1,  // no such code, inside a block
+    kDeadBadHeader = 2, // ... in macroblock_type, a motion code, coded_block_pattern
+    kDeadBadMba = 3,    // ... in macroblock_address_increment
+    kDeadRanPast = 4,   // the slice's stream words outgrew its region
+    kDeadLimit = 5,     // one macroblock more than the slice can hold
+    kDeadIdle = 6,      // never had a slice
+};
+constexpr uint32_t tm_dead(uint32_t why) { return tm_word(kTbDead + 2 * (int)why, 1); }
+constexpr uint32_t kWDeadMin = tm_word(kTbDead, 0) & 0xFFFF0000u;
+EFX_HD bool tm_alive(uint32_t st) { return st < kWDeadMin; }
+EFX_HD uint32_t tm_why(uint32_t st) { return ((st >> 19) - (uint32_t)kTbDead) >> 1; }
 // plan position (motion, pattern, blocks 0..5) -> table, as nibbles indexed by the counter byte the position owns:
 // bytes 0..5 = blocks, 6 = motion, 7 = pattern
 constexpr uint32_t kPlanInter = 0x43222222u, kPlanIntra = 0x43110000u;
@@ -93,12 +115,8 @@ struct TmTables {
 };
 void build_tm_tables(TmTables* t);
 
-// raw record of a coded macroblock (pass 1 -> pass 2): hacc | entries of blocks 0-3 | entries of blocks 4, 5, stream words
-// of the motion codes, flags | index of the macroblock's first stream word
+// raw record of a coded macroblock (pass 1 -> pass 2): hacc (64 bits) | entries of blocks 0-3 | entries of blocks 4, 5, flags
 constexpr uint32_t kRawOverrun = 1u << 24, kRawBadBlock = 1u << 25, kRawRanPast = 1u << 26;
-
-// why a lane stopped
-enum : uint32_t { kStopNone = 0, kStopCode = 1 /* a table said "no such code" (or 23 zero bits) */, kStopRanPast = 2, kStopLimit = 3 };
 
 // direct sink (host; a slice's words beyond its region are dropped)
 struct TmDirectSink {
@@ -126,12 +144,9 @@ struct TmLane {       // pass-1 state of a lane
     uint32_t n;       // scan position of the next coefficient
     uint32_t todo;    // the rest of the macroblock's plan, next item in bit 31
     uint32_t c8;      // 8 x the counter byte of the item in progress (mod 64)
-    uint32_t hacc;
+    uint64_t hacc;
     uint64_t cnt;
-    uint32_t mb_first;
     uint32_t nmb;
-    uint32_t stop;    // kStop*
-    uint32_t stop_st, stop_win;
 };
 
 EFX_HD uint32_t tm_ubfe(uint32_t v, uint32_t off, uint32_t width)
@@ -149,23 +164,24 @@ EFX_HD uint32_t tm_ffbh(uint32_t v)  // leading zeros; 0xFFFFFFFF for 0 (v_ffbh_
     return v ? (uint32_t)__builtin_clz(v) : 0xFFFFFFFFu;
 }
 
-EFX_HD void tm_begin(TmLane& L, uint32_t tok_base)
+EFX_HD void tm_begin(TmLane& L, uint32_t tok_base, bool has_slice)
 {
-    L.st = kWMbaA1;
-    L.tok = L.mb_first = tok_base;
-    L.n = L.todo = L.hacc = L.nmb = 0;
-    L.cnt = 0;
+    L.st = has_slice ? kWMbaA1 : tm_dead(kDeadIdle);
+    L.tok = tok_base;
+    L.n = L.todo = L.nmb = 0;
+    L.hacc = L.cnt = 0;
     L.c8 = 40;
-    L.stop = kStopNone;
-    L.stop_st = L.stop_win = 0;
 }
 
-// One code word.  `win` = the next 32 bits of the slice, `e` = the entry of the lane's state for them (the caller looks
-// it up: address = (L.st >> 16) + ((win >> (L.st & 31)) << 3)); returns the number of bits consumed.
+// One code word.  `win` = the next 32 bits of the slice, `e` = the entry of the lane's state for them (address =
+// (L.st >> 16) + ((win >> (L.st & 31)) << 3)).  `next(bits, state word)` is called as soon as the token's length and the
+// state that follows it are known -- the caller advances its bit reader and starts the next table look-up there, in the
+// shadow of which the rest of the trip runs (stream word, counters, the record of a finished macroblock).
 // `sink` takes the stream words: put(slot, word) for every trip (a token that emits none writes the slot the next word
-// overwrites), commit(next slot, emitted) after it, rewind(old next slot, new next slot) when an abandoned block gives its slots back.
-template <class Sink, class RawStore>
-EFX_HD uint32_t tm_trip(TmLane& L, uint32_t win, TmE e, const TmSlice& sp, Sink&& sink, RawStore&& store_raw)
+// overwrites), commit(next slot, emitted) after it, rewind(old next slot, new next slot) when an abandoned block gives its
+// slots back.  A lane in a dead state takes trips like any other: its entries are all zero.
+template <class Next, class Sink, class RawStore>
+EFX_HD bool tm_trip(TmLane& L, uint32_t win, TmE e, const TmSlice& sp, Next&& next, Sink&& sink, RawStore&& store_raw)
 {
     const uint32_t len = e.x & 31;
     const uint32_t xb = ((e.x >> 16) & 15) + ((e.x >> 5) & 1) * sp.r_size;
@@ -174,89 +190,95 @@ EFX_HD uint32_t tm_trip(TmLane& L, uint32_t win, TmE e, const TmSlice& sp, Sink&
     const uint32_t emit = (e.x >> 26) & 1;
     const uint32_t r6 = (e.x >> 20) & 63;
     const uint32_t npos = L.n + r6;
-    sink.put(L.tok, (x << 16) | (e.x & kTmOutMask) | npos);
-    L.tok += emit;
-    sink.commit(L.tok, emit);
-    L.n = npos + emit;
+    const uint32_t word = (x << 16) | (e.x & kTmOutMask) | npos;
+    const uint32_t slot = L.tok;
+    // a coefficient beyond position 63: the caller follows up with tm_overflow() (rare: damaged streams)
+    const bool overflow = (e.x & kTmCoef) && npos > 63;
+    L.hacc += (uint64_t)(r6 | (x << 6)) << ((e.y >> 6) & 63);
     L.cnt += (uint64_t)emit << (L.c8 & 63);
-    L.hacc += (r6 | (x << 6)) << ((e.y >> 6) & 31);
-    // (where the lane was, should it stop here: only read when it does)
-    L.stop_st = L.st;
-    L.stop_win = win;
+    L.tok += emit;
+    L.n = npos + emit;
     L.st = e.y | (e.x & sp.type_bit);
-    // no such code (or the 23 zero bits that end a slice): the lane stops where it is -- an all-zero entry changed nothing
-    uint32_t stop = len == 0 ? (uint32_t)kStopCode : (uint32_t)kStopNone;
-    bool query = (e.x & kTmQuery) != 0;
-    uint32_t plan_add = (e.x >> 6) & 0x3FF;
-    if ((e.x & kTmCoef) && npos > 63) {
-        // a coefficient beyond position 63: the block is abandoned (player.cpp:1106-1107) -- its stream words are forgotten,
-        // except an intra block's DC token, which pass 2 needs for the predictor (marked by a count of 0xFF)
-        const uint32_t sh = L.c8 & 63;
-        const uint32_t c = (uint32_t)(L.cnt >> sh) & 0xFF;
-        const uint32_t keep = L.hacc & 1;  // intra
-        const uint32_t tok_was = L.tok;
-        L.tok -= c - keep;
-        sink.rewind(tok_was, L.tok);
-        L.cnt = (L.cnt & ~((uint64_t)0xFF << sh)) | ((uint64_t)(keep ? 0xFFu : 0u) << sh) | ((uint64_t)kRawOverrun << 32);
-        plan_add = 0;
-        query = true;
-    }
-    if (query) {
-        // one macroblock more than the slice can hold (its address lies beyond the picture or in the next slice's rows):
-        // pass 2 decides what that means; nothing of it is kept
-        const bool full = (e.x & kTmType) && L.nmb >= sp.max_mbs;
-        stop = full ? (uint32_t)kStopLimit : stop;
-        // the plan: what a macroblock_type / coded_block_pattern adds to it, then its next item
+    bool mb_end = false, ran_past = false;
+    if ((e.x & kTmQuery) && !overflow) {
+        // the plan: what a macroblock_type / coded_block_pattern adds to it (the value field holds plan bits in their
+        // entries, a level in a coefficient's), then its next item
+        const uint32_t plan_add = (e.x & kTmCoef) ? 0u : (e.x >> 6) & 0x3FF;
         L.todo |= plan_add << 22;
         const uint32_t b = tm_ffbh(L.todo), sh = b + 1;
         const bool more = L.todo != 0;
         L.todo = more ? L.todo << (sh & 31) : 0u;
         L.c8 += sh << 3;
-        const uint32_t plan = (L.hacc & 1) ? kPlanIntra : kPlanInter;
+        const uint32_t plan = ((uint32_t)L.hacc & 1) ? kPlanIntra : kPlanInter;
         L.st = kWPlan0 + (tm_ubfe(plan, (L.c8 & 63) >> 1, 4) << 27);
         L.n = 0;
-        if (!more) {  // the macroblock is complete
-            const bool ran_past = L.tok > sp.coef_last;  // ran past this slice's bytes without finding its end
-            store_raw(L.nmb, L.hacc, (uint32_t)L.cnt, (uint32_t)(L.cnt >> 32) | (ran_past ? kRawRanPast : 0u), L.mb_first);
-            L.nmb++;
-            L.mb_first = L.tok;
-            L.hacc = 0;
-            L.cnt = 0;
-            L.c8 = 40;
-            L.st = kWMbaA1;
-            stop = ran_past ? (uint32_t)kStopRanPast : stop;
-        }
+        mb_end = !more;
+        ran_past = L.tok > sp.coef_last;  // (only looked at when a macroblock ends) ran past this slice's bytes without finding its end
+        L.st = mb_end ? (ran_past ? tm_dead(kDeadRanPast) : kWMbaA1) : L.st;
+        // one macroblock more than the slice can hold (its address lies beyond the picture or in the next slice's rows):
+        // pass 2 decides what that means; nothing of it is kept
+        L.st = ((e.x & kTmType) && L.nmb >= sp.max_mbs) ? tm_dead(kDeadLimit) : L.st;
     }
-    L.stop = stop;
-    return tot;
+    next(tot, L.st);
+    sink.put(slot, word);
+    sink.commit(L.tok, emit);
+    if (mb_end) {  // the macroblock is complete
+        store_raw(L.nmb, (uint32_t)L.hacc, (uint32_t)(L.hacc >> 32), (uint32_t)L.cnt,
+                  (uint32_t)(L.cnt >> 32) | (ran_past ? kRawRanPast : 0u));
+        L.nmb++;
+        L.hacc = L.cnt = 0;
+        L.c8 = 40;
+    }
+    return overflow;
+}
+
+// The follow-up of a trip that returned true: the block is abandoned (player.cpp:1106-1107) -- its stream words are
+// forgotten, except an intra block's DC token, which pass 2 needs for the predictor (marked by a count of 0xFF) -- and the
+// plan moves on to what follows it.  Returns the bits the trip must give back (a token that carried its block's
+// end_of_block as well consumed two bits the reference never saw); the caller re-reads its window and looks up L.st.
+template <class Sink, class RawStore>
+EFX_HD uint32_t tm_overflow(TmLane& L, TmE e, const TmSlice& sp, Sink&& sink, RawStore&& store_raw)
+{
+    const uint32_t sh = L.c8 & 63;
+    const uint32_t c = (uint32_t)(L.cnt >> sh) & 0xFF;
+    const uint32_t keep = (uint32_t)L.hacc & 1;  // intra
+    const uint32_t tok_was = L.tok;
+    L.tok -= c - keep;
+    sink.rewind(tok_was, L.tok);
+    L.cnt = (L.cnt & ~((uint64_t)0xFF << sh)) | ((uint64_t)(keep ? 0xFFu : 0u) << sh) | ((uint64_t)kRawOverrun << 32);
+    L.n = 0;
+    const uint32_t b = tm_ffbh(L.todo), shp = b + 1;
+    const bool more = L.todo != 0;
+    L.todo = more ? L.todo << (shp & 31) : 0u;
+    L.c8 += shp << 3;
+    const uint32_t plan = ((uint32_t)L.hacc & 1) ? kPlanIntra : kPlanInter;
+    L.st = kWPlan0 + (tm_ubfe(plan, (L.c8 & 63) >> 1, 4) << 27);
+    if (!more) {
+        const bool ran_past = L.tok > sp.coef_last;
+        L.st = ran_past ? tm_dead(kDeadRanPast) : kWMbaA1;
+        store_raw(L.nmb, (uint32_t)L.hacc, (uint32_t)(L.hacc >> 32), (uint32_t)L.cnt,
+                  (uint32_t)(L.cnt >> 32) | (ran_past ? kRawRanPast : 0u));
+        L.nmb++;
+        L.hacc = L.cnt = 0;
+        L.c8 = 40;
+    }
+    return (e.x & kTmQuery) ? 2u : 0u;
 }
 
 // After the loop: the record of the macroblock in progress.  A code that does not exist inside a block leaves the
 // macroblock with the blocks before it (player.cpp: block() fails, slice() goes on -- into the same wall); inside a
 // macroblock header it leaves the address increment for pass 2 (the skipped macroblocks before it exist).
-EFX_HD bool tm_state_in_block(uint32_t st)
-{
-    const uint32_t base = st >> 19;  // entries
-    return base == kTbDcY1 || base == kTbDcC1 || base == kTbDctF || base == kTbDct || base == kTbDctLo || base == kTbEscR ||
-           base == kTbEscL || base == kTbEscP || base == kTbEscN || base == kTbDcY2 || base == kTbDcC2;
-}
-EFX_HD bool tm_state_in_mba(uint32_t st)
-{
-    const uint32_t base = st >> 19;
-    return base == kTbMbaA1 || base == kTbMbaA2 || base == kTbMbaB1 || base == kTbMbaB2;
-}
 template <class RawStore>
 EFX_HD void tm_end(TmLane& L, const TmSlice& sp, RawStore&& store_raw)
 {
-    if (L.stop != kStopCode)
-        return;
-    if (tm_state_in_block(L.stop_st)) {
+    const uint32_t why = tm_why(L.st);
+    if (why == kDeadBadBlock) {
         const uint32_t sh = L.c8 & 63;
         L.cnt &= ~((uint64_t)0xFF << sh);
-        store_raw(L.nmb, L.hacc, (uint32_t)L.cnt, (uint32_t)(L.cnt >> 32) | kRawBadBlock, L.mb_first);
+        store_raw(L.nmb, (uint32_t)L.hacc, (uint32_t)(L.hacc >> 32), (uint32_t)L.cnt, (uint32_t)(L.cnt >> 32) | kRawBadBlock);
         L.nmb++;
-    } else if (L.nmb < sp.max_mbs)
-        store_raw(L.nmb, L.hacc, 0u, 0u, L.mb_first);  // (not counted: the header that could not be read)
+    } else if (why == kDeadBadHeader && L.nmb < sp.max_mbs)
+        store_raw(L.nmb, (uint32_t)L.hacc, (uint32_t)(L.hacc >> 32), 0u, 0u);  // (not counted: the header that could not be read)
 }
 
 // ---- pass 2 ------------------------------------------------------------------------------------------------------------
@@ -295,20 +317,47 @@ EFX_HD int tm_motion(int pred, int mcode, uint32_t residual, int r_size)  // mot
     return m;
 }
 
-// `raw(k)` reads raw record k of the slice; `recs` = the picture's 264 MbRec; returns the status bits of the slice.
+// `raw(k)` reads raw record k of the slice; `recs` = the picture's 264 MbRec; `tok_base` = the slice's first stream slot;
+// returns the status bits of the slice.  One macroblock per trip; the raw records come two trips ahead and an intra
+// macroblock's DC tokens one trip ahead of their use, so that a trip does not wait for memory.
 template <class RawLoad>
-EFX_HD uint32_t tm_finish(const TmLane& L, const TmFix& fx, RawLoad&& raw, uint32_t* coefs, TmU4* recs, uint32_t* n_mbs_out,
-                          uint32_t* n_coefs_out)
+EFX_HD uint32_t tm_finish(const TmLane& L, const TmFix& fx, uint32_t tok_base, RawLoad&& raw, uint32_t* coefs, TmU4* recs,
+                          uint32_t* n_mbs_out, uint32_t* n_coefs_out)
 {
     uint32_t status = 0, n_mbs = 0, n_coefs = 0;
     int mb_addr = (fx.code - 1) * kMbW - 1;
     int dc_y = 128, dc_cr = 128, dc_cb = 128, mv_h = 0, mv_v = 0;
     uint32_t qscale = fx.qscale;
-    const bool partial = L.stop == kStopCode && !tm_state_in_block(L.stop_st) && !tm_state_in_mba(L.stop_st) && L.nmb < (uint32_t)(fx.mb_limit - (fx.code - 1) * kMbW);
+    const uint32_t why = tm_why(L.st);
+    const bool partial = why == kDeadBadHeader && L.nmb < (uint32_t)(fx.mb_limit - (fx.code - 1) * kMbW);
     const uint32_t n_rec = L.nmb + (partial ? 1u : 0u);
+    const TmU4 none = {0, 0, 0, 0};
+    auto count = [](const TmU4& r, int b) { return b < 4 ? (r.z >> (8 * b)) & 0xFF : (r.w >> (8 * (b - 4))) & 0xFF; };
+    auto words = [&](const TmU4& r) {  // stream words of the macroblock (an abandoned intra block kept its DC token)
+        uint32_t t = 0;
+        for (int b = 0; b < 6; b++) {
+            const uint32_t c = count(r, b);
+            t += c == 0xFF ? 1u : c;
+        }
+        return t;
+    };
+    auto load_dc = [&](const TmU4& r, uint32_t first, uint32_t (&w)[6]) {
+        uint32_t at = first;
+        for (int b = 0; b < 6; b++) {
+            const uint32_t c = count(r, b);
+            w[b] = ((r.x & 1) && c) ? coefs[at] : 0u;
+            at += c == 0xFF ? 1u : c;
+        }
+    };
+    TmU4 r = n_rec > 0 ? raw(0) : none, r1 = n_rec > 1 ? raw(1) : none;
+    uint32_t first = tok_base;
+    uint32_t dcw[6], dcw1[6];
+    load_dc(r, first, dcw);
     bool stopped = false;
     for (uint32_t k = 0; k < n_rec; k++) {
-        const TmU4 r = raw(k);
+        const TmU4 r2 = k + 2 < n_rec ? raw(k + 2) : none;
+        const uint32_t first1 = first + words(r);
+        load_dc(r1, first1, dcw1);
         const uint32_t type = r.x & 63, qf = (r.x >> 6) & 31;
         int inc = (int)((r.x >> kHaccInc) & 0xFFFF);
         if (k == 0)
@@ -321,7 +370,7 @@ EFX_HD uint32_t tm_finish(const TmLane& L, const TmFix& fx, RawLoad&& raw, uint3
             while (inc > 1 && mb_addr + 1 < fx.mb_limit) {  // skipped macroblocks copy the reference (1283-1288)
                 mb_addr++;
                 TmU4 o;
-                o.x = r.w;
+                o.x = first;
                 o.y = 0;
                 o.z = (2u << 16) | ((fx.epoch & 0xFF) << 24);
                 o.w = 0;
@@ -345,30 +394,25 @@ EFX_HD uint32_t tm_finish(const TmLane& L, const TmFix& fx, RawLoad&& raw, uint3
         const bool intra = type & 1;
         if (type & 0x10)
             qscale = qf;
-        uint32_t first = r.w;
         if (intra)
             mv_h = mv_v = 0;  // player.cpp:1300
         else {
             dc_y = dc_cr = dc_cb = 128;  // player.cpp:1302
             if (type & 0x08) {
-                // the two motion codes left stream words: code + 16 (+ what the scan position had become) | residual << 16
-                const uint32_t wh = coefs[first], wv = coefs[first + 1];
-                const int ph = (int)(wh & 127), pv = (int)(wv & 127);
-                mv_h = tm_motion(mv_h, ph - 16, wh >> 16, (int)fx.r_size);
-                mv_v = tm_motion(mv_v, pv - (ph + 1) - 16, wv >> 16, (int)fx.r_size);
-                first += 2;
+                mv_h = tm_motion(mv_h, (int)(r.y & 63) - 16, (r.y >> 6) & 63, (int)fx.r_size);
+                mv_v = tm_motion(mv_v, (int)((r.y >> 12) & 63) - 16, (r.y >> 18) & 63, (int)fx.r_size);
             } else
                 mv_h = mv_v = 0;
         }
-        uint32_t w_y = r.y, w_z = r.z & 0xFFFF;
+        uint32_t w_y = r.z, w_z = r.w & 0xFFFF;
         if (intra) {
             // DC tokens (size << 6 | differential bits << 16) -> absolute values (player.cpp:1010-1068), block by block
             uint32_t at = first;
             for (int b = 0; b < 6; b++) {
-                const uint32_t c = b < 4 ? (w_y >> (8 * b)) & 0xFF : (w_z >> (8 * (b - 4))) & 0xFF;
+                const uint32_t c = count(r, b);
                 if (!c)
                     continue;
-                const uint32_t tkn = coefs[at];
+                const uint32_t tkn = dcw[b];
                 const uint32_t size = (tkn >> 6) & 0x3FF, bits = (tkn >> 16) & 0x7FF;
                 int pred = b < 4 ? dc_y : (b == 4 ? dc_cr : dc_cb);
                 if (size) {
@@ -385,7 +429,7 @@ EFX_HD uint32_t tm_finish(const TmLane& L, const TmFix& fx, RawLoad&& raw, uint3
                     // token out of the macroblock's entry list
                     uint32_t rest = 0;
                     for (int c2 = b + 1; c2 < 6; c2++) {
-                        const uint32_t cc = c2 < 4 ? (w_y >> (8 * c2)) & 0xFF : (w_z >> (8 * (c2 - 4))) & 0xFF;
+                        const uint32_t cc = count(r, c2);
                         rest += cc == 0xFF ? 1u : cc;
                     }
                     for (uint32_t j = 0; j < rest; j++)
@@ -412,24 +456,27 @@ EFX_HD uint32_t tm_finish(const TmLane& L, const TmFix& fx, RawLoad&& raw, uint3
         o.w = rec_mv;
         recs[mb_addr] = o;
         n_mbs++;
-        if (r.z & kRawOverrun)
+        if (r.w & kRawOverrun)
             status |= EFX_STREAM_COEF_OVERRUN;
-        if (r.z & (kRawBadBlock | kRawRanPast)) {
+        if (r.w & (kRawBadBlock | kRawRanPast)) {
             status |= EFX_STREAM_BAD_VLC;
             stopped = true;
             break;
         }
+        r = r1;
+        r1 = r2;
+        first = first1;
+        for (int b = 0; b < 6; b++)
+            dcw[b] = dcw1[b];
     }
-    if (!stopped && L.stop == kStopCode && tm_state_in_mba(L.stop_st)) {
-        // an address increment that does not exist -- unless it is the 23 zero bits that end a slice (slice_done(),
-        // player.cpp:1238-1249), met where a macroblock would start (no stuffing, no escape before them)
-        const bool a2 = (L.stop_st >> 19) == (uint32_t)kTbMbaA2;
-        const bool clean = a2 && (L.stop_win >> 14) == 0 && ((L.hacc >> kHaccInc) & 0x7FFFF) == 0;
-        if (!clean)
+    if (!stopped) {
+        // an address increment that does not exist -- or the 23 zero bits that end a slice (slice_done(),
+        // player.cpp:1238-1249) met anywhere but where a macroblock would start (after stuffing)
+        if (why == kDeadBadMba || (why == kDeadEnd && (((uint32_t)L.hacc >> kHaccInc) & 0x7FFFF) != 0))
             status |= EFX_STREAM_BAD_VLC;
+        if ((why == kDeadLimit || (why == kDeadBadHeader && !partial)) && fx.mb_limit == kMbCount)
+            status |= EFX_STREAM_MB_OVERRUN;  // a macroblock beyond the last one
     }
-    if (!stopped && L.stop == kStopLimit && fx.mb_limit == kMbCount)
-        status |= EFX_STREAM_MB_OVERRUN;  // a macroblock beyond the last one
     *n_mbs_out = n_mbs;
     *n_coefs_out = n_coefs;
     return status;

@@ -199,14 +199,16 @@ int main(int argc, char** argv)
             br.pos += 1;
         }
         TmLane L;
-        tm_begin(L, units[u].off * kCoefsPerEsByte);
+        const uint32_t tok_base = units[u].off * kCoefsPerEsByte;
+        tm_begin(L, tok_base, true);
         auto store_raw = [&](uint32_t k, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { raw[k] = TmU4{a, b, c, d}; };
         long guard = 0;
         const long trips0 = trips;
-        while (L.stop == kStopNone) {
+        while (tm_alive(L.st)) {
             const uint32_t win = br.window();
             const TmE e = tab->e[(L.st >> 19) + (win >> (L.st & 31))];
-            br.pos += tm_trip(L, win, e, sp, TmDirectSink{coefs.data(), sp.coef_last}, store_raw);
+            if (tm_trip(L, win, e, sp, [&](uint32_t bits, uint32_t) { br.pos += bits; }, TmDirectSink{coefs.data(), sp.coef_last}, store_raw))
+                br.pos -= tm_overflow(L, e, sp, TmDirectSink{coefs.data(), sp.coef_last}, store_raw);
             trips++;
             if (++guard > 50000000) {
                 fprintf(stderr, "slice at %u: parser did not terminate\n", units[u].off);
@@ -217,11 +219,11 @@ int main(int argc, char** argv)
         if (getenv("EFX_HARNESS_TRIPS"))
             printf("slice pic=%d code=%d type=%d trips=%ld mbs=%u bytes=%u\n", se.a, code, se.c & 15, trips - trips0, L.nmb, len);
         uint32_t nm = 0, nc = 0;
-        const uint32_t st = tm_finish(L, fx, [&](uint32_t k) { return raw[k]; }, coefs.data(), reinterpret_cast<TmU4*>(recs.data()), &nm, &nc);
+        const uint32_t st = tm_finish(L, fx, tok_base, [&](uint32_t k) { return raw[k]; }, coefs.data(), reinterpret_cast<TmU4*>(recs.data()), &nm, &nc);
 
         if (nm != exp.size()) {
-            fprintf(stderr, "slice at %u (picture %d code %d): %u macroblock records, oracle %zu (status %u, stop %u)\n", units[u].off,
-                    se.a, code, nm, exp.size(), st, L.stop);
+            fprintf(stderr, "slice at %u (picture %d code %d): %u macroblock records, oracle %zu (status %u, why %u)\n", units[u].off,
+                    se.a, code, nm, exp.size(), st, tm_why(L.st));
             return 1;
         }
         uint32_t want_coefs = 0;
