@@ -28,32 +28,45 @@ namespace efx {
 namespace {
 
 
-__device__ inline int rnd8(int x) { return (x + 128) >> 8; }  // the reference's "(... + 128) >> 8" rounding points
+// v_mul_i32_i24 / v_mad_i32_i24 by name: `__mul24` is library code ((x << 8 >> 8) * (y << 8 >> 8)) that the compiler turns
+// into the 24-bit multiply only where it can PROVE the operand fits -- the column pass; in the row pass it kept the two
+// shifts and a quarter-rate v_mul_lo_u32 per product (40 of them: a tenth of the kernel's issue time).
+__device__ inline int mul24(int a, int k)
+{
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "s"(k), "v"(a));
+    return r;
+}
+__device__ inline int mad24(int a, int k, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
+    return r;
+}
 
 // One 8-point pass of the reference's scaled integer IDCT (player.cpp:938-995): the same products
-// and the same rounding points (integer sums are associative, so only those matter for the bits),
+// and the same rounding points "(x + 128) >> 8" (integer sums are associative, so only those matter for the bits),
 // written as an even / odd decomposition.
-// The products use the full-rate 24-bit multiplier (v_mul_i32_i24 / v_mad_i32_i24; a 32-bit
-// v_mul_lo_u32 issues at quarter rate): every multiplied operand is a combination of AC
+// The products use the full-rate 24-bit multiplier: every multiplied operand is a combination of AC
 // coefficients only -- the DC term v0 enters through dc_sum / dc_dif and is never multiplied --
 // and AC coefficients are clamped to +-2048 and scaled by a premultiplier <= 62, which bounds the
 // operands by 2^19 in the column pass and 2^22.5 in the row pass (L1 norm of the linear map).  The
 // low 32 bits of the 48-bit product equal the reference's wrapped 32-bit product.
-__device__ inline void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v5, int& v6, int& v7)
+__device__ inline void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v5, int& v6, int& v7, int half)
 {
     // even half: inputs 0, 4 as sum / difference; inputs 2, 6 through one rotation (362 / 256)
     const int dc_sum = v0 + v4, dc_dif = v0 - v4;
     const int c_sum = v2 + v6;
-    const int c_rot = rnd8(__mul24(v2 - v6, 362)) - c_sum;
+    const int c_rot = (mad24(v2 - v6, 362, half) >> 8) - c_sum;
     const int even0 = dc_sum + c_sum, even3 = dc_sum - c_sum;
     const int even1 = dc_dif + c_rot, even2 = dc_dif - c_rot;
     // odd half: inputs 1, 7 and 3, 5 as sums and differences, three rotations (473, 196, 362 over 256)
     const int p17 = v1 + v7, m17 = v1 - v7;
     const int p35 = v3 + v5, m53 = v5 - v3;
     const int odd_all = p17 + p35;
-    const int odd_a = rnd8(__mul24(m17, 473) - __mul24(m53, 196)) - odd_all;
-    const int odd_b = odd_a - rnd8(__mul24(p17 - p35, 362));
-    const int odd_c = -odd_b - rnd8(__mul24(m53, 473) + __mul24(m17, 196));
+    const int odd_a = (mad24(m17, 473, mad24(m53, -196, half)) >> 8) - odd_all;
+    const int odd_b = odd_a - (mad24(p17 - p35, 362, half) >> 8);
+    const int odd_c = -odd_b - (mad24(m53, 473, mad24(m17, 196, half)) >> 8);
     // output butterflies
     v0 = even0 + odd_all;
     v7 = even0 - odd_all;
@@ -213,12 +226,23 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     const bool want = live && !intra;
     int16_t* mine = cfh + lane * kLaneHalfwords;
     if (!__any(want && !inside)) {
+        // One byte offset for the window's first row (a 24-bit multiply: rows < 2^8), then a constant step per row; a
+        // chroma window crosses from one strip's eight rows into the next strip's once, at row `jump`.  Every row is
+        // loaded by every lane of a wave that predicts at all (a lane that does not -- intra, not live -- reads its
+        // own position: no exec-mask region per row, and the ninth row costs less than asking whether it is needed).
         const int xa = px0 & ~3;
+        const int y0 = want ? py0 : 0;
+        const uint32_t off0 = (uint32_t)(luma ? mul24(y0, kStride) : mul24(((y0 >> 3) << 4) + (y0 & 7), kStride) + chroma_base) +
+                              (uint32_t)(want ? xa : 0);
+        const uint32_t jump = luma ? 99u : 8u - ((uint32_t)y0 & 7u);
 #pragma unroll
-        for (int r = 0; r < 9; r++) {
+        for (int r = 0; r < 9; r++)
             wa[r] = wb[r] = wc[r] = 0;
-            if (want && (r < 8 || hy)) {
-                const uint32_t* p = reinterpret_cast<const uint32_t*>(ref + row_off(py0 + r) + xa);
+        if (__any(want)) {
+#pragma unroll
+            for (int r = 0; r < 9; r++) {
+                const uint32_t off = off0 + (uint32_t)(r * kStride) + ((uint32_t)r >= jump ? 8u * kStride : 0u);
+                const uint32_t* p = reinterpret_cast<const uint32_t*>(ref + off);
                 wa[r] = p[0];
                 wb[r] = p[1];
                 wc[r] = p[2];
@@ -342,33 +366,31 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     // ---- prediction of the 8 rows, in the shadow of the entry loads just issued (a wave's life is its chain of
     // memory round trips: record -> owner search -> entries; this arithmetic needs only the windows, which were
     // requested before) -- the 27 window registers die here, before the 64 IDCT registers come alive -----------
+    // Per window row: the eight pixels at the block's position (P) and the eight one pixel to the right if the vector has
+    // a horizontal half (Q, else the same) -- four byte permutes with per-lane selectors (byte `sh` / `sh + hx` of the row's
+    // three dwords onward).  All four half-pel cases of mocomp() are then ONE expression, (a + b + c + d + 2) >> 2 per byte
+    // with  a = P[r], b = Q[r], c = P[r + hy], d = Q[r + hy]: with equal operands it degenerates exactly to
+    // (a + b + 1) >> 1 and to a.  (Lanes of one wave carry different vectors, so a branch per case would execute all four.)
     uint32_t pr_lo[8], pr_hi[8];
+    {
+        const uint32_t selP = 0x03020100u + 0x01010101u * (uint32_t)(px0 & 3), selQ = selP + 0x01010101u * (uint32_t)hx;
+        const uint32_t hym = 0u - (uint32_t)hy;
+        uint32_t P_lo[9], P_hi[9], Q_lo[9], Q_hi[9];
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        uint32_t p_lo = 0, p_hi = 0;
-        if (!intra) {
-            // ---- prediction: the four half-pel cases of mocomp(), player.cpp:767-820 ----------------
-            const uint32_t a0 = wa[r], a1 = wb[r], a2 = wc[r], b0 = wa[r + 1], b1 = wb[r + 1], b2 = wc[r + 1];
-            const int sh = px0 & 3;
-            // pixels 0..7 of the row (A) and of the next row (B); pixel 8 is byte `sh` of the third dword.
-            // All four half-pel cases of mocomp() are one expression, (a + b + c + d + 2) >> 2 per byte
-            // with  b = the pixel to the right if hx else a,  c = the pixel below if hy else a,
-            // d = below-right / below / right / a:  with equal operands it degenerates exactly to
-            // (a + b + 1) >> 1 and to a.  Lanes of one wave carry different vectors, so a branch per
-            // case would execute all four.
-            const uint32_t A_lo = __builtin_amdgcn_alignbit(a1, a0, sh * 8), A_hi = __builtin_amdgcn_alignbit(a2, a1, sh * 8);
-            const uint32_t B_lo = __builtin_amdgcn_alignbit(b1, b0, sh * 8), B_hi = __builtin_amdgcn_alignbit(b2, b1, sh * 8);
-            const uint32_t A9 = (a2 >> (sh * 8)) & 0xFF, B9 = (b2 >> (sh * 8)) & 0xFF;
-            const uint32_t Ar_lo = __builtin_amdgcn_alignbit(A_hi, A_lo, 8), Ar_hi = (A_hi >> 8) | (A9 << 24);
-            const uint32_t Br_lo = __builtin_amdgcn_alignbit(B_hi, B_lo, 8), Br_hi = (B_hi >> 8) | (B9 << 24);
-            const uint32_t b_lo = hx ? Ar_lo : A_lo, b_hi = hx ? Ar_hi : A_hi;
-            const uint32_t c_lo = hy ? B_lo : A_lo, c_hi = hy ? B_hi : A_hi;
-            const uint32_t d_lo = hy ? (hx ? Br_lo : B_lo) : b_lo, d_hi = hy ? (hx ? Br_hi : B_hi) : b_hi;
-            p_lo = avg4_lerp(A_lo, b_lo, c_lo, d_lo);
-            p_hi = avg4_lerp(A_hi, b_hi, c_hi, d_hi);
+        for (int r = 0; r < 9; r++) {
+            P_lo[r] = __builtin_amdgcn_perm(wb[r], wa[r], selP);
+            P_hi[r] = __builtin_amdgcn_perm(wc[r], wb[r], selP);
+            Q_lo[r] = __builtin_amdgcn_perm(wb[r], wa[r], selQ);
+            Q_hi[r] = __builtin_amdgcn_perm(wc[r], wb[r], selQ);
         }
-        pr_lo[r] = p_lo;
-        pr_hi[r] = p_hi;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            // (as bit selects: written as `hy ? P[r + 1] : P[r]` the compiler indexes the arrays by hy -- in scratch memory)
+            const uint32_t c_lo = (P_lo[r + 1] & hym) | (P_lo[r] & ~hym), c_hi = (P_hi[r + 1] & hym) | (P_hi[r] & ~hym);
+            const uint32_t d_lo = (Q_lo[r + 1] & hym) | (Q_lo[r] & ~hym), d_hi = (Q_hi[r + 1] & hym) | (Q_hi[r] & ~hym);
+            pr_lo[r] = intra ? 0u : avg4_lerp(P_lo[r], Q_lo[r], c_lo, d_lo);
+            pr_hi[r] = intra ? 0u : avg4_lerp(P_hi[r], Q_hi[r], c_hi, d_hi);
+        }
     }
 
 
@@ -407,6 +429,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     // single value X at raster position 0; the butterflies turn that into X at all 64 positions
     // exactly, so clearing X's low byte makes the final (x + 128) >> 8 deliver X >> 8, the shortcut.
     int v[64];
+    const int half = 128;  // (in a register: v_mad_i32_i24 takes no literal)
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         // column c: eight int16 from the private block, scaled by immediates, one butterfly
@@ -418,7 +441,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             v[0] = dc_only ? (v[0] & ~0xFF) : v[0];
         }
 #if !defined(EFX_ABL_NO_IDCT) && !defined(EFX_ABL_NO_COL)
-        idct8(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
+        idct8(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c], half);
 #endif
         // one butterfly at a time (volatile asm statements keep their order): with all sixteen in
         // flight the temporaries push the kernel past 128 registers and an occupancy step
@@ -432,7 +455,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         // residual fits 16 bits, so bytes 1 and 2 of x + 128 ARE the shifted value
         v[r * 8] += 128;
 #ifndef EFX_ABL_NO_IDCT
-        idct8(v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
+        idct8(v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7], half);
 #endif
         asm volatile("" : "+v"(v[r * 8]), "+v"(v[r * 8 + 1]), "+v"(v[r * 8 + 2]), "+v"(v[r * 8 + 3]), "+v"(v[r * 8 + 4]),
                      "+v"(v[r * 8 + 5]), "+v"(v[r * 8 + 6]), "+v"(v[r * 8 + 7]));
@@ -455,7 +478,10 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     auto widen = [](uint32_t p, bool upper) {  // bytes 0, 1 (or 2, 3) of p as two uint16
         return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(0u, p, upper ? 0x0C030C02u : 0x0C010C00u));
     };
-    const pk16 zero = {0, 0}, top = {248, 248};
+    // (a block without coefficients keeps its prediction as it is -- it may hold the unclamped bytes of an intra DC-only
+    // replica: its residual is zero, so lifting the ceiling to 255 makes the clamped sum that copy)
+    const short ceiling = my_cnt == 0 ? 255 : 248;
+    const pk16 zero = {0, 0}, top = {ceiling, ceiling};
     uint32_t flat4 = (uint32_t)(v[0] >> 8);  // intra DC-only block: replicated exactly as copy_block_dc does, unclamped and
     flat4 |= flat4 << 8;                      // unmasked (player.cpp:1175-1187)
     flat4 |= flat4 << 16;
@@ -473,9 +499,9 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             b = __builtin_elementwise_min(__builtin_elementwise_max(b, zero), top);
             w[h] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 0x06040200u);
         }
-        // prediction only (skipped macroblock, block without coefficients) / intra DC-only replica / the clamped sum
-        const uint32_t lo = my_cnt == 0 ? p_lo : (clamped ? w[0] : flat4);
-        const uint32_t hi = my_cnt == 0 ? p_hi : (clamped ? w[1] : flat4);
+        // the clamped sum (= the prediction for a block without coefficients) / intra DC-only replica
+        const uint32_t lo = clamped ? w[0] : flat4;
+        const uint32_t hi = clamped ? w[1] : flat4;
         if (stored)
             *reinterpret_cast<uint2*>(cur + dst0 + r * kStride) = make_uint2(lo, hi);
     }
