@@ -12,22 +12,35 @@ namespace {
 constexpr unsigned kProbeRecords = 1u << 17;
 __device__ unsigned long long g_probe[kProbeRecords * 8];
 __device__ unsigned int g_probe_next;
+__device__ unsigned int g_probe_window[2] = {0u, 0xFFFFFFFFu};  // kernels that pass a `when` record only inside [lo, hi]
 }  // namespace
-__device__ inline unsigned long long* probe_claim(unsigned tag, unsigned wave)
+// `seq` < 0: the record comes from the unit's atomic counter; otherwise record (seq mod ring size) -- no atomic: a kernel of
+// ten thousand short waves must not queue for one counter (the first k_recon probe stretched its launch 3.5 x)
+__device__ inline unsigned long long* probe_claim(unsigned tag, unsigned wave, long long seq = -1, unsigned when = 0)
 {
     unsigned slot = 0;
-    if ((threadIdx.x & 63) == 0)
-        slot = atomicAdd(&g_probe_next, 1u) % kProbeRecords;
-    slot = (unsigned)__builtin_amdgcn_readfirstlane((int)slot);
+    if (seq >= 0)
+        slot = (when >= g_probe_window[0] && when <= g_probe_window[1]) ? (unsigned)((unsigned long long)seq % (kProbeRecords - 1))
+                                                                        : kProbeRecords - 1;  // (the last record: a dump)
+    else {
+        if ((threadIdx.x & 63) == 0)
+            slot = atomicAdd(&g_probe_next, 1u) % kProbeRecords;
+        slot = (unsigned)__builtin_amdgcn_readfirstlane((int)slot);
+    }
     unsigned hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned long long* r = g_probe + (size_t)slot * 8;
-    if ((threadIdx.x & 63) == 0)
+    if ((threadIdx.x & 63) == 0) {
         r[0] = tag | ((unsigned long long)wave << 8) | ((unsigned long long)hw << 32);
+        r[7] = xcc;
+    }
     return r;
 }
 }  // namespace efx
 #define EFX_PROBE_CLAIM(tag, wave) unsigned long long* const efx_probe_rec = efx::probe_claim(tag, wave)
+#define EFX_PROBE_CLAIM_AT(tag, wave, seq, when) unsigned long long* const efx_probe_rec = efx::probe_claim(tag, wave, seq, when)
 #define EFX_PROBE_STAMP(i)                        \
     do {                                          \
         if ((threadIdx.x & 63) == 0)              \
@@ -41,6 +54,11 @@ __device__ inline unsigned long long* probe_claim(unsigned tag, unsigned wave)
     } while (0)
 // int efx_probe_read_<name>(dst, max_records, &next): copies the ring (dst == NULL: clears it)
 #define EFX_PROBE_READER(name)                                                                                            \
+    extern "C" int efx_probe_window_##name(unsigned lo, unsigned hi)                                                      \
+    {                                                                                                                     \
+        const unsigned w[2] = {lo, hi};                                                                                   \
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(efx::g_probe_window), w, sizeof(w));                                     \
+    }                                                                                                                     \
     extern "C" int efx_probe_read_##name(unsigned long long* dst, size_t max_records, unsigned* next)                    \
     {                                                                                                                     \
         if (!dst) {                                                                                                       \
@@ -59,6 +77,7 @@ __device__ inline unsigned long long* probe_claim(unsigned tag, unsigned wave)
 #else
 #define EFX_PROBE_READER(name)
 #define EFX_PROBE_CLAIM(tag, wave) ((void)0)
+#define EFX_PROBE_CLAIM_AT(tag, wave, seq, when) ((void)0)
 #define EFX_PROBE_STAMP(i) ((void)0)
 #define EFX_PROBE_MAX(i, v) ((void)0)
 #define EFX_PROBE_SET(i, v) ((void)0)

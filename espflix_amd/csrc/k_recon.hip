@@ -158,9 +158,12 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
 
     const int lane = threadIdx.x;
     const int s = stream0 + blockIdx.x;
-    EFX_PROBE_CLAIM(2, blockIdx.x * gridDim.y + blockIdx.y);
+    // (one record per wave, placed by launch: the ring holds ten launches of 512 streams)
+    EFX_PROBE_CLAIM_AT(2, blockIdx.x * gridDim.y + blockIdx.y,
+                       ((long long)(epoch & 0xFF) * 16 + pic) * (gridDim.x * gridDim.y) + blockIdx.x * gridDim.y + blockIdx.y,
+                       (unsigned)(epoch & 0xFF));
     EFX_PROBE_STAMP(1);
-    EFX_PROBE_SET(6, pic);
+    EFX_PROBE_SET(6, (unsigned long long)pic | (unsigned long long)(epoch & 0xFF) << 8 | (unsigned long long)stream0 << 16);
     const int b_raw = blockIdx.y * 64 + lane;
     const bool have = b_raw < kBlocksPerPicture;
     const int b = have ? b_raw : kBlocksPerPicture - 1;
@@ -366,31 +369,33 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     // ---- prediction of the 8 rows, in the shadow of the entry loads just issued (a wave's life is its chain of
     // memory round trips: record -> owner search -> entries; this arithmetic needs only the windows, which were
     // requested before) -- the 27 window registers die here, before the 64 IDCT registers come alive -----------
-    // Per window row: the eight pixels at the block's position (P) and the eight one pixel to the right if the vector has
-    // a horizontal half (Q, else the same) -- four byte permutes with per-lane selectors (byte `sh` / `sh + hx` of the row's
-    // three dwords onward).  All four half-pel cases of mocomp() are then ONE expression, (a + b + c + d + 2) >> 2 per byte
-    // with  a = P[r], b = Q[r], c = P[r + hy], d = Q[r + hy]: with equal operands it degenerates exactly to
-    // (a + b + 1) >> 1 and to a.  (Lanes of one wave carry different vectors, so a branch per case would execute all four.)
     uint32_t pr_lo[8], pr_hi[8];
-    {
-        const uint32_t selP = 0x03020100u + 0x01010101u * (uint32_t)(px0 & 3), selQ = selP + 0x01010101u * (uint32_t)hx;
-        const uint32_t hym = 0u - (uint32_t)hy;
-        uint32_t P_lo[9], P_hi[9], Q_lo[9], Q_hi[9];
 #pragma unroll
-        for (int r = 0; r < 9; r++) {
-            P_lo[r] = __builtin_amdgcn_perm(wb[r], wa[r], selP);
-            P_hi[r] = __builtin_amdgcn_perm(wc[r], wb[r], selP);
-            Q_lo[r] = __builtin_amdgcn_perm(wb[r], wa[r], selQ);
-            Q_hi[r] = __builtin_amdgcn_perm(wc[r], wb[r], selQ);
+    for (int r = 0; r < 8; r++) {
+        uint32_t p_lo = 0, p_hi = 0;
+        if (!intra) {
+            // ---- prediction: the four half-pel cases of mocomp(), player.cpp:767-820 ----------------
+            const uint32_t a0 = wa[r], a1 = wb[r], a2 = wc[r], b0 = wa[r + 1], b1 = wb[r + 1], b2 = wc[r + 1];
+            const int sh = px0 & 3;
+            // pixels 0..7 of the row (A) and of the next row (B); pixel 8 is byte `sh` of the third dword.
+            // All four half-pel cases of mocomp() are one expression, (a + b + c + d + 2) >> 2 per byte
+            // with  b = the pixel to the right if hx else a,  c = the pixel below if hy else a,
+            // d = below-right / below / right / a:  with equal operands it degenerates exactly to
+            // (a + b + 1) >> 1 and to a.  Lanes of one wave carry different vectors, so a branch per
+            // case would execute all four.
+            const uint32_t A_lo = __builtin_amdgcn_alignbit(a1, a0, sh * 8), A_hi = __builtin_amdgcn_alignbit(a2, a1, sh * 8);
+            const uint32_t B_lo = __builtin_amdgcn_alignbit(b1, b0, sh * 8), B_hi = __builtin_amdgcn_alignbit(b2, b1, sh * 8);
+            const uint32_t A9 = (a2 >> (sh * 8)) & 0xFF, B9 = (b2 >> (sh * 8)) & 0xFF;
+            const uint32_t Ar_lo = __builtin_amdgcn_alignbit(A_hi, A_lo, 8), Ar_hi = (A_hi >> 8) | (A9 << 24);
+            const uint32_t Br_lo = __builtin_amdgcn_alignbit(B_hi, B_lo, 8), Br_hi = (B_hi >> 8) | (B9 << 24);
+            const uint32_t b_lo = hx ? Ar_lo : A_lo, b_hi = hx ? Ar_hi : A_hi;
+            const uint32_t c_lo = hy ? B_lo : A_lo, c_hi = hy ? B_hi : A_hi;
+            const uint32_t d_lo = hy ? (hx ? Br_lo : B_lo) : b_lo, d_hi = hy ? (hx ? Br_hi : B_hi) : b_hi;
+            p_lo = avg4_lerp(A_lo, b_lo, c_lo, d_lo);
+            p_hi = avg4_lerp(A_hi, b_hi, c_hi, d_hi);
         }
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            // (as bit selects: written as `hy ? P[r + 1] : P[r]` the compiler indexes the arrays by hy -- in scratch memory)
-            const uint32_t c_lo = (P_lo[r + 1] & hym) | (P_lo[r] & ~hym), c_hi = (P_hi[r + 1] & hym) | (P_hi[r] & ~hym);
-            const uint32_t d_lo = (Q_lo[r + 1] & hym) | (Q_lo[r] & ~hym), d_hi = (Q_hi[r + 1] & hym) | (Q_hi[r] & ~hym);
-            pr_lo[r] = intra ? 0u : avg4_lerp(P_lo[r], Q_lo[r], c_lo, d_lo);
-            pr_hi[r] = intra ? 0u : avg4_lerp(P_hi[r], Q_hi[r], c_hi, d_hi);
-        }
+        pr_lo[r] = p_lo;
+        pr_hi[r] = p_hi;
     }
 
 
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     // single value X at raster position 0; the butterflies turn that into X at all 64 positions
     // exactly, so clearing X's low byte makes the final (x + 128) >> 8 deliver X >> 8, the shortcut.
     int v[64];
-    const int half = 128;  // (in a register: v_mad_i32_i24 takes no literal)
+    const int half = 128;
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         // column c: eight int16 from the private block, scaled by immediates, one butterfly
@@ -478,8 +483,6 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     auto widen = [](uint32_t p, bool upper) {  // bytes 0, 1 (or 2, 3) of p as two uint16
         return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(0u, p, upper ? 0x0C030C02u : 0x0C010C00u));
     };
-    // (a block without coefficients keeps its prediction as it is -- it may hold the unclamped bytes of an intra DC-only
-    // replica: its residual is zero, so lifting the ceiling to 255 makes the clamped sum that copy)
     const short ceiling = my_cnt == 0 ? 255 : 248;
     const pk16 zero = {0, 0}, top = {ceiling, ceiling};
     uint32_t flat4 = (uint32_t)(v[0] >> 8);  // intra DC-only block: replicated exactly as copy_block_dc does, unclamped and
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             b = __builtin_elementwise_min(__builtin_elementwise_max(b, zero), top);
             w[h] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 0x06040200u);
         }
-        // the clamped sum (= the prediction for a block without coefficients) / intra DC-only replica
+        // prediction only (skipped macroblock, block without coefficients) / intra DC-only replica / the clamped sum
         const uint32_t lo = clamped ? w[0] : flat4;
         const uint32_t hi = clamped ? w[1] : flat4;
         if (stored)

@@ -2,8 +2,9 @@
 
     tools/exp/build_variant.sh p "-DEFX_PROBE" && EFX_LIB=espflix_amd/libefx_p.so python tools/dbg/probe_waves.py [serial|pipelined] [flags]
 
-serial: one efx_decode at a time; pipelined: 40 back-to-back calls (the last ones are what the rings hold).
-Prints, per kernel: waves, lifetime percentiles (us), and for k_recon the number of waves resident per CU over time."""
+serial: one efx_decode at a time; pipelined: back-to-back calls (the rings hold the last launches).
+Prints, per kernel: waves, lifetime percentiles (us); for k_recon per launch: how long a wave lives and how many k_recon /
+k_parse waves a CU holds while the launch runs (every CU of the chip identified by XCC_ID + HW_ID)."""
 import ctypes as C
 import os
 import sys
@@ -26,7 +27,7 @@ def read(name):
     buf = np.zeros((N, 8), dtype=np.uint64)
     nxt = C.c_uint(0)
     assert fn(buf.ctypes.data, N, C.byref(nxt)) == 0
-    return buf[: min(nxt.value, N)], nxt.value
+    return buf
 
 
 def clear():
@@ -45,7 +46,11 @@ clear()
 if mode == "serial":
     dec.decode()
 else:
-    for _ in range(6):
+    # k_recon keeps ten launches: those of ONE hand-over epoch in the middle of a run of back-to-back calls (a slot's
+    # epoch advances once per call that uses it: three slots, two groups per call)
+    lib.efx_probe_window_recon.argtypes = [C.c_uint, C.c_uint]
+    lib.efx_probe_window_recon(8, 8)
+    for _ in range(16):
         dec.decode(sync=False)
     dec.sync()
 
@@ -54,56 +59,58 @@ def pct(a, qs=(0, 10, 50, 90, 99, 100)):
     return " ".join(f"{np.percentile(a, q):8.1f}" for q in qs)
 
 
-def hw_cu(hw):
-    # HW_ID (gfx9): wave [3:0] simd [5:4] pipe [7:6] cu [11:8] sh [12] se [15:13] ... ; XCC from a different register, so
-    # CUs of different XCDs alias here: (se, sh, cu) identifies a CU inside an XCD
-    return ((hw >> 8) & 0xF) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5)
+def cu_key(r):
+    hw = (r[:, 0] >> np.uint64(32)).astype(np.int64)
+    xcc = r[:, 7].astype(np.int64) & 15
+    return (xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xF)
 
 
-for name in ("parse", "recon"):
-    r, total = read(name)
-    if not len(r):
-        continue
+def valid(r):
     t1 = r[:, 1].astype(np.int64)
     t4 = r[:, 4].astype(np.int64)
     ok = (t4 > t1) & (t1 > 0)
-    r, t1, t4 = r[ok], t1[ok], t4[ok]
-    t0 = t1.min()
-    life = (t4 - t1) / 100.0  # 100 MHz -> us
-    print(f"k_{name}: {len(r)} waves recorded ({total} claimed), span {(t4.max() - t0) / 100.0:.1f} us")
+    return r[ok], t1[ok], t4[ok]
+
+
+parse, p1, p4 = valid(read("parse"))
+recon, r1, r4 = valid(read("recon"))
+if len(parse):
+    life = (p4 - p1) / 100.0
+    t2 = parse[:, 2].astype(np.int64)
+    t3 = parse[:, 3].astype(np.int64)
+    trips = parse[:, 5].astype(np.int64)
+    print(f"k_parse: {len(parse)} waves recorded")
     print("  lifetime us  p0 p10 p50 p90 p99 p100:", pct(life))
-    if name == "parse":
-        t2 = r[:, 2].astype(np.int64)
-        t3 = r[:, 3].astype(np.int64)
-        trips = r[:, 5].astype(np.int64)
-        ptype = (r[:, 6] >> np.uint64(8)) & np.uint64(3)
-        print("  staging us  :", pct((t2 - t1) / 100.0))
-        print("  pass 1 us   :", pct((t3 - t2) / 100.0))
-        print("  pass 2 us   :", pct((t4 - t3) / 100.0))
-        print("  trips       :", pct(trips))
-        print("  ns per trip :", pct((t3 - t2) * 10.0 / np.maximum(trips, 1)))
-        for ty, nm in ((1, "I"), (2, "P")):
-            m = ptype == ty
-            if m.any():
-                print(f"  {nm} waves {m.sum()}: pass1 us {pct((t3 - t2)[m] / 100.0)} | trips {pct(trips[m])} | pass2 {pct((t4 - t3)[m] / 100.0)}")
-        # launches: cluster by start time
-        order = np.argsort(t1)
-        starts = t1[order]
-        gaps = np.where(np.diff(starts) > 2000)[0]
-        print("  launches seen:", len(gaps) + 1)
-    else:
-        # resident waves per CU (identified inside an XCD by HW_ID) sampled every 2 us, averaged over busy CU-samples
-        hw = (r[:, 0] >> np.uint64(32)).astype(np.int64)
-        cu = np.array([hw_cu(int(h)) for h in hw])
-        pic = r[:, 6].astype(np.int64)
-        span = int(t4.max() - t0)
-        ts = np.arange(0, span, 200)
-        res = np.zeros(len(ts))
-        for i, t in enumerate(ts):
-            m = (t1 - t0 <= t) & (t4 - t0 > t)
-            res[i] = m.sum()
-        print(f"  resident waves chip-wide: mean {res.mean():.0f} max {res.max():.0f} (256 CUs: {res.mean() / 256:.1f} per CU)")
-        for p in sorted(set(pic.tolist()))[:12]:
-            m = pic == p
-            print(f"  picture {p}: {m.sum()} waves, lifetime {pct(life[m])}, launch span {(t4[m].max() - t1[m].min()) / 100.0:.1f} us")
+    print("  pass 1 us   :", pct((t3 - t2) / 100.0))
+    print("  pass 2 us   :", pct((p4 - t3) / 100.0))
+    print("  trips       :", pct(trips))
+    print("  ns per trip :", pct((t3 - t2) * 10.0 / np.maximum(trips, 1)))
+if len(recon):
+    life = (r4 - r1) / 100.0
+    print(f"k_recon: {len(recon)} waves recorded; lifetime us p0 p10 p50 p90 p99 p100: {pct(life)}")
+    tagv = recon[:, 6].astype(np.int64)
+    rcu = cu_key(recon)
+    pcu = cu_key(parse) if len(parse) else np.zeros(0, np.int64)
+    print("  CUs seen:", len(set(rcu.tolist())))
+    rows = []
+    for tg in sorted(set(tagv.tolist()), key=lambda t: r1[tagv == t].min()):
+        m = tagv == tg
+        if m.sum() < 1000:
+            continue
+        a, z = r1[m].min(), r4[m].max()
+        ts = np.linspace(a, z, 12)[1:-1]
+        res_r, res_p = [], []
+        for t in ts:
+            alive = m & (r1 <= t) & (r4 > t)
+            cnt = np.bincount(rcu[alive], minlength=4096)
+            res_r.append(cnt[cnt > 0].mean() if (cnt > 0).any() else 0)
+            if len(parse):
+                pa = (p1 <= t) & (p4 > t)
+                cp = np.bincount(pcu[pa], minlength=4096)
+                res_p.append(cp.sum() / 256.0)
+        rows.append((tg & 0xFF, (tg >> 8) & 0xFF, tg >> 16, m.sum(), (z - a) / 100.0, np.median(life[m]), np.percentile(life[m], 90),
+                     np.mean(res_r), np.mean(res_p) if res_p else 0.0))
+    print("  per launch: picture epoch stream0 waves | span us | wave life p50 p90 us | k_recon waves per busy CU | k_parse waves per CU")
+    for row in rows[-26:]:
+        print("   pic %2d ep %3d s0 %4d  %5d | %6.1f | %6.1f %6.1f | %5.1f | %4.2f" % row)
 dec.close()
