@@ -58,6 +58,10 @@ WORKLOADS = {
 }
 
 
+PDM_VALU_PER_STEP = 10.2          # VALU instructions per delta-sigma step and lane in k_pdm's main loop (hipcc -S)
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # int32 lane-operations per second, every SIMD-32 issuing a wave64 op per 2 cycles
+
+
 def log(msg):
     sys.stderr.write(f"[bench rank {os.environ.get('RANK', '0')}] {msg}\n")
     sys.stderr.flush()
@@ -309,7 +313,13 @@ def run_video_out(job, args, S):
     for bfr in (d_pcm, d_state, d_out):
         bfr.free()
     out["pdm"] = {"what": "stream-seconds of 48 kHz audio modulated per second (32 delta-sigma steps per sample, one lane per stream: "
-                          "the recurrence is serial, so the rate grows with the stream count until every SIMD holds waves)", "by_streams": {}}
+                          "the recurrence is serial, so the rate grows with the stream count until every SIMD holds waves -- 1024 "
+                          "streams are 16 waves on a chip of 1024 SIMDs: an occupancy artefact, not a property of the kernel)",
+                  "bound": "valu",
+                  "valu_peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                  "valu_peak_note": "256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md: a wave64 VALU instruction issues over "
+                                    "2 cycles); valu_frac = streams x samples x 32 steps x %.1f VALU instructions per step / time / peak" % PDM_VALU_PER_STEP,
+                  "by_streams": {}}
     for n_streams, samples in ((S, 48000), (16 * S, 9600), (64 * S, 4800), (256 * S, 2400)):
         d_pcm, d_state, d_out = dec.alloc(n_streams * samples * 2), dec.alloc(n_streams * 12), dec.alloc(n_streams * samples * 4)
         one = np.round(8000 * np.sin(2 * np.pi * 220 * np.arange(samples) / 48000)).astype(np.int16)
@@ -319,9 +329,13 @@ def run_video_out(job, args, S):
         dec.sync()
         ms = _event_ms(torch, stream, lambda i: dec.pdm(n_streams, d_pcm, samples, d_state, d_out), 3)
         alg = n_streams * samples * 6
+        # the recurrence's roof is the integer VALU, not HBM: 32 delta-sigma steps per sample, PDM_VALU_PER_STEP VALU
+        # instructions per step and lane in the kernel's 8-sample loop body (hipcc -S: 2.6 k v_* for 256 steps)
+        lane_ops = n_streams * samples * 32 * PDM_VALU_PER_STEP / (ms * 1e-3)
         out["pdm"]["by_streams"][str(n_streams)] = {"samples_per_stream": samples, "ms_per_launch": ms,
                                                     "stream_seconds_per_s": n_streams * samples / 48000 / ms * 1e3,
-                                                    "achieved_GBs": alg / ms / 1e6, "frac": alg / ms / 1e6 / HBM_PEAK_GBS}
+                                                    "valu_lane_ops_per_s": lane_ops, "valu_frac": lane_ops / VALU_PEAK_LANE_OPS,
+                                                    "achieved_GBs": alg / ms / 1e6, "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS}
         for bfr in (d_pcm, d_state, d_out):
             bfr.free()
     dec.close()
@@ -479,7 +493,7 @@ def timed_region(job, dec, steps, warmup, overlap=True):
     return edist.max_over_ranks(elapsed, job.dist, job.device)
 
 
-def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_serial=True):
+def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_serial=True, sustained_steps=0):
     """Generate, gate, time one workload on this rank.  Returns a dict of rank-local + job results."""
     from espflix_amd import dist as edist
     from espflix_amd import gen
@@ -537,6 +551,20 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
         if not np.array_equal(chains, want):
             raise SystemExit(f"parity gate ({workload}): gathered chain hashes differ from the reference on {int((chains != want).sum())} streams")
 
+    # sustained: the driver's K (20 steps = 30 ms) pays the pipeline's fill and drain; the same region over >= 1000 steps
+    # is what a service that decodes batch after batch sees.  Gated like the timed region.
+    sustained = None
+    if sustained_steps and not args.timed_only:
+        s_elapsed = timed_region(job, dec, sustained_steps, 0, overlap=not args.no_overlap)
+        hashes = dec.frame_hashes()
+        for p in (P - 2, P - 1):
+            if p >= 0 and not np.array_equal(hashes[:, dec.picture_slot(p)], got[:, p]):
+                raise SystemExit(f"parity gate ({workload}, sustained leg): picture {p} differs from the reference decoder")
+        sustained = {"steps": sustained_steps, "frames_per_s": totals[0] * sustained_steps / s_elapsed,
+                     "ms_per_step": s_elapsed / sustained_steps * 1e3,
+                     "what": "the timed region again with this many back-to-back steps (barrier + synchronize on both sides, max "
+                             "over ranks), pictures P-2 and P-1 compared with the reference decoder afterwards"}
+
     # ingest included: every step uploads the batch from host memory again (staging copy, H2D on the copy stream
     # into the bitstream buffer the running decode does not read) and decodes it; upload n+1 overlaps decode n
     ingest = None
@@ -580,7 +608,7 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
         csum = int(np.bitwise_xor.reduce(chains * edist.GOLDEN)) if chains.size else 0
     return {"workload": workload, "S": S, "P": P, "es_bytes": es_bytes, "n_i": n_i, "n_p": n_p, "elapsed": elapsed,
             "stage_ms": stage_ms, "serial_ms": serial_ms, "timed_calls": timed_calls, "groups": groups, "halves": halves, "n_coefs": int(n_coefs),
-            "gen_seconds": t_gen, "batch0": batches[0][1], "ingest": ingest, "job_pictures": totals[0], "job_es_bytes": totals[1],
+            "gen_seconds": t_gen, "batch0": batches[0][1], "ingest": ingest, "sustained": sustained, "job_pictures": totals[0], "job_es_bytes": totals[1],
             "checksum": csum, "streams_checked": int(chains.size), "first_id": int(ids[0]), "last_id": int(ids[-1])}
 
 
@@ -640,7 +668,7 @@ def run(job, args):
     if world > 1 and rank == 0:
         log(f"{'RCCL' if job.device == 'cuda' else 'gloo'} saw {world} ranks")
 
-    r = run_workload(job, args, "gop12", S, ids, threads, args.steps, args.warmup)
+    r = run_workload(job, args, "gop12", S, ids, threads, args.steps, args.warmup, sustained_steps=args.sustained_steps)
     P = r["P"]
 
     # SURVEY 8d config 5 as written: the FIXED 8192-stream batch, stream k on rank floor(k*N/8192)
@@ -733,6 +761,7 @@ def run(job, args):
                                 "ranks gathered and compared on rank 0", "passed": True},
         "checksum_of_checksums": f"{r['checksum']:016x}",
         "gen_seconds": r["gen_seconds"],
+        "sustained": r["sustained"],
         "ingest": r["ingest"],
         "fixed_batch_8192": fixed,
         "other_workloads": others,
@@ -767,6 +796,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-video-out", action="store_true", help="skip the composite / PDM / demux / SBC legs (N = 1 only anyway)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=5.0, help="wall-time target of the CPU baseline leg")
+    ap.add_argument("--sustained-steps", type=int, default=1000, help="steps of the sustained leg beside the K timed ones (0: skip)")
     ap.add_argument("--no-overlap", action="store_true", help="synchronise after every step (no cross-step pipelining)")
     ap.add_argument("--timed-only", action="store_true",
                     help="profiling aid: skip the ingest and one-call-at-a-time legs so that (nearly) every kernel launch of the "

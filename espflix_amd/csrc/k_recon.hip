@@ -147,10 +147,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     // What else a lane needs to know about another lane's block (first entry, quantiser) is fetched from that lane's
     // registers (ds_bpermute).  Measured: this layout at 16 / 18 / 19 waves per CU 8.07 / 8.16 / 7.85 M frames/s
     // (19 with the search through ds_bpermute as well), the previous one (9.7 KB, 16 waves) 7.78.
-#ifndef EFX_RECON_LDS_PAD
-#define EFX_RECON_LDS_PAD 0
-#endif
-    __shared__ uint32_t lds[64 * kLaneDwords + 32 + 16 + EFX_RECON_LDS_PAD];  // (pad: occupancy experiments)
+    __shared__ uint32_t lds[64 * kLaneDwords + 32 + 16];
     int16_t* const cfh = reinterpret_cast<int16_t*>(lds);
     uint16_t* const s_pre = reinterpret_cast<uint16_t*>(lds + 64 * kLaneDwords);  // entries before the block in the wave
     uint8_t* const s_zd = reinterpret_cast<uint8_t*>(lds + 64 * kLaneDwords + 32);  // bit 7: an entry sits at scan position 0;
@@ -445,9 +442,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             v[0] = intra ? (dc_raw << 8) : v[0];
             v[0] = dc_only ? (v[0] & ~0xFF) : v[0];
         }
-#if !defined(EFX_ABL_NO_IDCT) && !defined(EFX_ABL_NO_COL)
         idct8(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c], half);
-#endif
         // one butterfly at a time (volatile asm statements keep their order): with all sixteen in
         // flight the temporaries push the kernel past 128 registers and an occupancy step
         asm volatile("" : "+v"(v[c]), "+v"(v[8 + c]), "+v"(v[16 + c]), "+v"(v[24 + c]), "+v"(v[32 + c]), "+v"(v[40 + c]),
@@ -459,9 +454,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         // (it is never multiplied), so the 128 is added there, once; the shift is left to the byte permutes below -- a
         // residual fits 16 bits, so bytes 1 and 2 of x + 128 ARE the shifted value
         v[r * 8] += 128;
-#ifndef EFX_ABL_NO_IDCT
         idct8(v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7], half);
-#endif
         asm volatile("" : "+v"(v[r * 8]), "+v"(v[r * 8 + 1]), "+v"(v[r * 8 + 2]), "+v"(v[r * 8 + 3]), "+v"(v[r * 8 + 4]),
                      "+v"(v[r * 8 + 5]), "+v"(v[r * 8 + 6]), "+v"(v[r * 8 + 7]));
     }
