@@ -39,7 +39,11 @@ __global__ void k_frame_hash(const uint8_t*, int, uint64_t*);
 __global__ void k_fill(uint32_t*, uint32_t, size_t);
 __global__ void k_composite(const uint8_t*, const VideoTables*, const VideoLineTemplates*, FieldArgs, uint16_t*);
 __global__ void k_pdm(const int16_t*, int, int, int32_t*, uint16_t*);
-__global__ void k_sbc(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int);
+__global__ void k_sbc(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int,
+                      const uint32_t*);
+__global__ void k_sbc_par(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int,
+                          const uint32_t*);
+__global__ void k_sbc_check(const uint8_t*, size_t, int, int, uint32_t*);
 }  // namespace efx
 
 using namespace efx;
@@ -175,6 +179,8 @@ struct efx_ctx {
     VideoTables* d_video[2] = {nullptr, nullptr};  // [0] PAL, [1] NTSC
     VideoLineTemplates* d_video_lines[2] = {nullptr, nullptr};
     SbcTables* d_sbc_tables = nullptr;
+    uint32_t* d_sbc_flags = nullptr;  // per stream of an efx_sbc_decode call: 1 = decoded frame-parallel (k_sbc_check)
+    size_t sbc_flags_cap = 0;
     uint64_t* d_hash = nullptr;
 
     // results of the last decode (fetch_results)
@@ -502,7 +508,7 @@ void efx_destroy(efx_ctx* ctx)
             (void)hipStreamSynchronize(ps);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
-    void* bufs[] = {ctx->d_tables, ctx->d_tm_tables, ctx->d_state, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0],
+    void* bufs[] = {ctx->d_tables, ctx->d_tm_tables, ctx->d_sbc_flags, ctx->d_state, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0],
                     ctx->d_video_lines[1], ctx->d_hash, ctx->d_ts, ctx->d_sbc_tables, ctx->d_idx_info, ctx->d_ts_off, ctx->d_idx_len,
                     ctx->d_idx_base, ctx->d_idx_seq};
     for (auto& te : ctx->timing_ring)
@@ -1460,9 +1466,27 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
     if (!ctx || !frames_device || !state_device || !pcm_device || n_streams <= 0 || n_frames < 0 || frame_bytes <= 0 ||
         (size_t)frame_bytes * (size_t)n_frames > 0x7FFFFFFFu || ((uintptr_t)state_device & 3))
         return EFX_ERR_ARG;
+    // which streams decode frame-parallel (every frame accepted, one geometry): k_sbc_check; those k_sbc_par takes, the rest
+    // -- a rejected frame re-synthesises its predecessor's samples: a chain -- the one-wave-per-stream kernel
+    if ((size_t)n_streams > ctx->sbc_flags_cap) {
+        if (ctx->d_sbc_flags)
+            (void)hipFree(ctx->d_sbc_flags);
+        ctx->d_sbc_flags = nullptr;
+        ctx->sbc_flags_cap = 0;
+        EFX_HIP(dalloc(&ctx->d_sbc_flags, (size_t)n_streams));
+        ctx->sbc_flags_cap = (size_t)n_streams;
+    }
+    EFX_HIP(hipMemsetAsync(ctx->d_sbc_flags, 0xFF, (size_t)n_streams * sizeof(uint32_t), ctx->stream));
+    if (n_frames > 0) {
+        hipLaunchKernelGGL(k_sbc_check, dim3((n_frames + 255) / 256, n_streams), dim3(256), 0, ctx->stream, frames_device, stream_stride,
+                           frame_bytes, n_frames, ctx->d_sbc_flags);
+        hipLaunchKernelGGL(k_sbc_par, dim3((n_frames + 7) / 8, n_streams), dim3(256), 0, ctx->stream, frames_device, stream_stride,
+                           frame_bytes, n_frames, static_cast<SbcState*>(state_device), ctx->d_sbc_tables, pcm_device, pcm_stride,
+                           ret_device, pcm_count_device, flags, ctx->d_sbc_flags);
+    }
     hipLaunchKernelGGL(k_sbc, dim3(n_streams), dim3(64), 0, ctx->stream, frames_device, stream_stride, frame_bytes, n_frames,
                        static_cast<SbcState*>(state_device), ctx->d_sbc_tables, pcm_device, pcm_stride, ret_device,
-                       pcm_count_device, flags);
+                       pcm_count_device, flags, n_frames > 0 ? ctx->d_sbc_flags : nullptr);
     EFX_HIP(hipGetLastError());
     return EFX_OK;
 }

@@ -5,7 +5,12 @@
 // decode_audio() drives it (src/video.cpp:962-989): a stream is a run of equally sized frames
 // decoded in order, the synthesis filter memory carrying over from frame to frame.
 //
-// One wave per stream walks its frames; INSIDE a frame nothing is serial:
+// Two paths.  The synthesis filter is an FIR: the matrixing outputs of a block depend on that block's samples only, a PCM
+// sample on the last ten blocks' outputs -- so a stream whose frames all decode and share one geometry (k_sbc_check) is
+// decoded FRAME-PARALLEL by k_sbc_par: a workgroup takes eight consecutive frames, dequantises them and the nine blocks
+// before them, matrixes, windows.  What chains from frame to frame in the reference -- a rejected frame re-synthesising
+// the PREVIOUS frame's samples under the geometry its header left behind -- stays with k_sbc, one wave per stream walking
+// its frames; INSIDE a frame nothing is serial there either:
 //   * the reference's lazy bit reader is replaced by direct addressing -- every block of a frame
 //     has the same layout, so sample (blk, ch, sb) starts at bit blk * bits_per_block +
 //     prefix[ch][sb] -- one lane per sample extracts, dequantises (32-bit wrapping shift, C
@@ -111,8 +116,10 @@ __global__ __launch_bounds__(64) void k_sbc(const uint8_t* __restrict__ frames, 
                                             int n_frames, SbcState* __restrict__ states,
                                             const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
                                             size_t pcm_stride, uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count,
-                                            int flags)
+                                            int flags, const uint32_t* __restrict__ parallel)
 {
+    if (parallel && parallel[blockIdx.x])
+        return;  // (k_sbc_par decodes this stream)
     __shared__ SbcTables tb;
     __shared__ int32_t sb_sample[16][2][8];  // the reference's sb_sample (persists across frames)
     __shared__ int32_t rows[2][9 + 16][16];   // matrixing outputs: 9 rows of history + this frame's blocks
@@ -286,6 +293,192 @@ __global__ __launch_bounds__(64) void k_sbc(const uint8_t* __restrict__ frames, 
         st->bitpool = (uint8_t)bitpool;
         if (pcm_count)
             pcm_count[s] = written;
+    }
+}
+
+// ---- the frame-parallel path ---------------------------------------------------------------------------------------------
+constexpr int kSbcChunk = 8;                 // frames per workgroup
+constexpr int kSbcFrames = kSbcChunk + 3;    // + the frames that hold the nine blocks before them (blocks >= 4)
+
+// one thread per frame: parallel[s] stays 1 when every frame of stream s decodes (sbc_decoder.cpp:282-295) with the
+// geometry of frame 0.  parallel[] arrives set to all ones.
+__global__ __launch_bounds__(256) void k_sbc_check(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
+                                                   int n_frames, uint32_t* __restrict__ parallel)
+{
+    const int s = blockIdx.y, f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames)
+        return;
+    const uint8_t* base = frames + (size_t)s * stream_stride;
+    const uint8_t* d = base + (size_t)f * frame_bytes;
+    bool ok = frame_bytes >= 4 && d[0] == 0x9C;
+    if (ok) {
+        const uint32_t h1 = d[1], g0 = base[1];
+        const int mode = (h1 >> 2) & 3;
+        ok = mode != 3 && (h1 & 1) && d[2] <= 128;
+        // same blocks, same channel count as frame 0 (the PCM of a frame then sits at f * its size)
+        ok = ok && ((h1 >> 4) & 3) == ((g0 >> 4) & 3) && (mode != 0) == (((g0 >> 2) & 3) != 0);
+    }
+    if (!ok)
+        atomicAnd(&parallel[s], 0u);
+}
+
+// grid = (chunks of kSbcChunk frames, streams), block = 256.  Same arguments and results as k_sbc.
+__global__ __launch_bounds__(256) void k_sbc_par(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
+                                                 int n_frames, SbcState* __restrict__ states,
+                                                 const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
+                                                 size_t pcm_stride, uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count,
+                                                 int flags, const uint32_t* __restrict__ parallel)
+{
+    const int s = blockIdx.y, tid = threadIdx.x;
+    if (!parallel[s] || n_frames <= 0)
+        return;
+    __shared__ SbcTables tb;
+    __shared__ int32_t sb[kSbcFrames][16][2][8];            // dequantised samples of the frames in reach
+    __shared__ int32_t rows[2][9 + kSbcChunk * 16][16];    // matrixing outputs: nine blocks of history + the chunk's
+    __shared__ uint8_t sh_scale[kSbcFrames][2][8], sh_bits[kSbcFrames][2][8];
+    __shared__ uint16_t sh_prefix[kSbcFrames][16], sh_per_block[kSbcFrames];
+
+    const uint8_t* base = frames + (size_t)s * stream_stride;
+    const uint32_t limit = (uint32_t)n_frames * (uint32_t)frame_bytes;
+    const uint32_t g0 = base[1];
+    const int blocks = 4 * (int)(((g0 >> 4) & 3) + 1), channels = ((g0 >> 2) & 3) ? 2 : 1, per_blk = channels * 8;
+    const bool probe = (flags & 1) != 0;  // decode_audio()'s frame-size probe: frame 0 is decoded once more up front
+    const int f0 = blockIdx.x * kSbcChunk, f1 = min(n_frames, f0 + kSbcChunk);
+    // Virtual block timeline: block vb >= 0 is block vb % blocks of frame vb / blocks; with the probe, blocks
+    // -blocks .. -1 are frame 0's once more; everything before comes from the state's nine history rows.
+    const int vb0 = f0 * blocks, vb1 = f1 * blocks;
+    const int first_vb = max(vb0 - 9, probe ? -blocks : 0);      // first block whose samples this workgroup needs
+    const int fr_lo = first_vb < 0 ? -1 : first_vb / blocks;     // ... it lies in this frame (-1: the probe's copy of frame 0)
+    const int n_fr = f1 - fr_lo;                                 // frames in reach (<= kSbcFrames)
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(tables);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&tb);
+        for (int i = tid; i < (int)(sizeof(SbcTables) / 4); i += 256)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+    // ---- headers, scale factors, bit allocation: one thread per (frame, channel) ---------------------------------------
+    if (tid < n_fr * 2) {
+        const int k = tid >> 1, c = tid & 1, f = max(fr_lo + k, 0);
+        const uint8_t* d = base + (size_t)f * frame_bytes;
+        const uint32_t avail = limit - (uint32_t)f * (uint32_t)frame_bytes;
+        if (c < channels) {
+            uint8_t sc[8];
+            for (int j = 0; j < 8; j++) {
+                const uint32_t i = 4 + (uint32_t)((c * 8 + j) >> 1);
+                const uint32_t a = i < avail ? d[i] : 0u;
+                sc[j] = ((c * 8 + j) & 1) ? (a & 0xF) : (a >> 4);
+                sh_scale[k][c][j] = sc[j];
+            }
+            int b[8];
+            bit_allocation((d[1] >> 6) & 3, (d[1] >> 1) & 1, d[2], sc, b);
+            for (int j = 0; j < 8; j++)
+                sh_bits[k][c][j] = (uint8_t)b[j];
+        }
+    }
+    __syncthreads();
+    if (tid < n_fr) {
+        int acc = 0;
+        for (int c = 0; c < channels; c++)
+            for (int j = 0; j < 8; j++) {
+                sh_prefix[tid][c * 8 + j] = (uint16_t)acc;
+                acc += sh_bits[tid][c][j];
+            }
+        sh_per_block[tid] = (uint16_t)acc;
+    }
+    __syncthreads();
+    // ---- samples: one thread per (frame, blk, ch, sb) (IQUANT, sbc_decoder.cpp:263-270) --------------------------------
+    const uint32_t data_off = 4 + (uint32_t)(per_blk >> 1);
+    for (int i = tid; i < n_fr * blocks * per_blk; i += 256) {
+        const int k = i / (blocks * per_blk), r0 = i - k * blocks * per_blk, blk = r0 / per_blk, r = r0 - blk * per_blk;
+        const int f = max(fr_lo + k, 0);
+        const uint8_t* d = base + (size_t)f * frame_bytes;
+        const uint32_t avail = limit - (uint32_t)f * (uint32_t)frame_bytes;
+        const int bits = sh_bits[k][r >> 3][r & 7];
+        int32_t sample = 0;
+        if (bits) {
+            const uint32_t bitpos = data_off * 8 + (uint32_t)blk * sh_per_block[k] + sh_prefix[k][r];
+            const int scale = sh_scale[k][r >> 3][r & 7];
+            int32_t q = (int32_t)be_bits(d, avail, bitpos, bits);
+            q = (q << 1) | 1;
+            q = (int32_t)((uint32_t)q << scale) / ((1 << bits) - 1);
+            sample = q - (1 << scale);
+        }
+        sb[k][blk][r >> 3][r & 7] = sample;
+    }
+    // ---- history rows that predate every frame in reach: the state's ------------------------------------------------------
+    // row t of `rows` is virtual block vb0 - 9 + t
+    const SbcState* st = states + s;
+    const int hist_end = probe ? -blocks : 0;  // virtual blocks below this one are the state's history: block v -> hist[9 + v - hist_end]
+    for (int i = tid; i < channels * 9 * 16; i += 256) {
+        const int c = i / 144, r = i - c * 144, t = r >> 4, o = r & 15, vb = vb0 - 9 + t;
+        if (vb < hist_end)
+            rows[c][t][o] = st->hist[c][9 + vb - hist_end][o];
+    }
+    __syncthreads();
+    // ---- matrixing (sbc_decoder.cpp:86-104): rows[c][t][o] = (sum_j syn[o][j] * sb[blk][c][j]) >> 15 ----------------------
+    const int n_t = 9 + (vb1 - vb0);
+    for (int i = tid; i < channels * n_t * 16; i += 256) {
+        const int c = i / (n_t * 16), r = i - c * n_t * 16, t = r >> 4, o = r & 15, vb = vb0 - 9 + t;
+        if (vb < hist_end)
+            continue;
+        const int f = vb < 0 ? -1 : vb / blocks, blk = vb < 0 ? vb + blocks : vb - f * blocks, k = f - fr_lo;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            acc += (uint32_t)tb.syn[o * 8 + j] * (uint32_t)sb[k][blk][c][j];
+        rows[c][t][o] = (int32_t)acc >> 15;
+    }
+    __syncthreads();
+    // ---- windowing (sbc_decoder.cpp:106-137): sample o of block t from rows t .. t - 9 ---------------------------------------
+    int16_t* out = pcm + (size_t)s * pcm_stride;
+    const int frame_samples = channels * blocks * 8;
+    for (int i = tid; i < (f1 - f0) * frame_samples; i += 256) {
+        const int fl = i / frame_samples, r0 = i - fl * frame_samples, c = r0 / (blocks * 8), r = r0 - c * blocks * 8, blk = r >> 3,
+                  o = r & 7, t = 9 + fl * blocks + blk;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 10; j += 2) {
+            acc += (uint32_t)rows[c][t - j][o] * (uint32_t)tb.proto[o * 10 + j];
+            acc += (uint32_t)rows[c][t - j - 1][o + 8] * (uint32_t)tb.proto[o * 10 + j + 1];
+        }
+        int32_t v = (int32_t)acc >> 15;
+        v = v < -0x7FFF ? -0x7FFF : (v > 0x7FFF ? 0x7FFF : v);
+        out[(size_t)(f0 + fl) * frame_samples + r0] = (int16_t)v;
+    }
+    if (ret)
+        for (int fl = tid; fl < f1 - f0; fl += 256) {
+            const int k = f0 + fl - fr_lo;
+            const uint32_t framelen = data_off + ((uint32_t)blocks * sh_per_block[k] + 7) / 8;
+            ret[(size_t)s * n_frames + f0 + fl] = (framelen & 0xFFFF) | ((uint32_t)(frame_samples * 2) << 16);
+        }
+    // ---- the workgroup of the last frames leaves the decoder state -------------------------------------------------------------
+    if (f1 == n_frames) {
+        SbcState* so = states + s;
+        const int k_last = n_frames - 1 - fr_lo;
+        __syncthreads();
+        for (int i = tid; i < 256; i += 256) {
+            const int blk = i >> 4, c = (i >> 3) & 1, j = i & 7;
+            // (blocks beyond this geometry keep what an earlier frame left there: the reference's array is not cleared)
+            if (blk < blocks && c < channels)
+                so->sb_sample[blk][c][j] = sb[k_last][blk][c][j];
+        }
+        for (int i = tid; i < channels * 144; i += 256) {
+            const int c = i / 144, r = i - c * 144;
+            so->hist[c][r >> 4][r & 15] = rows[c][n_t - 9 + (r >> 4)][r & 15];
+        }
+        if (tid == 0) {
+            const uint8_t* d = base + (size_t)(n_frames - 1) * frame_bytes;
+            so->frequency = (d[1] >> 6) & 3;
+            so->blocks = (uint8_t)blocks;
+            so->channels = (uint8_t)channels;
+            so->mode = (d[1] >> 2) & 3;
+            so->allocation = (d[1] >> 1) & 1;
+            so->subbands = 8;
+            so->bitpool = d[2];
+            if (pcm_count)
+                pcm_count[s] = (uint32_t)n_frames * (uint32_t)frame_samples;
+        }
     }
 }
 

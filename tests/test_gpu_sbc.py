@@ -109,6 +109,43 @@ def test_rejected_frames(efx):
     dec.close()
 
 
+def test_parallel_and_serial_paths_side_by_side(efx):
+    """Streams whose frames all decode with one geometry take the frame-parallel kernel (k_sbc_par), a stream with a
+    rejected frame the one-wave-per-stream kernel -- in the same call, and a stream changes sides from one call to the
+    next with its state (filter memory, stale samples) carried over.  21 and 13 frames: chunks of eight with a tail."""
+    kw = dict(freq=3, blocks=16, mode=0, alloc=0, bitpool=28)
+    fb = common.sbc_frame_bytes(16, 1, 28)
+    clean = [common.sbc_frames(100 + i, 34, **kw) for i in range(3)]
+    dirty = common.sbc_frames(200, 34, **kw).reshape(34, -1).copy()
+    dirty[5, 0] = 0x9D    # first call: a bad sync byte (the serial kernel's case); second call: clean
+    streams = [clean[0], dirty.reshape(-1), clean[1], clean[2].copy()]
+    streams[3].reshape(34, -1)[30, 0] = 0x9D   # clean in the first call (frames 0..20), rejected frame in the second
+    dec = efx.Decoder(1, 1, 2)
+    n = len(streams)
+    stride = 34 * fb + 16
+    buf = np.zeros(n * stride, dtype=np.uint8)
+    for i, st in enumerate(streams):
+        buf[i * stride:i * stride + st.size] = st
+    d_fr, d_st = dec.alloc(buf.size), dec.alloc(n * efx.sbc_state_bytes())
+    d_fr.upload(buf)
+    d_st.upload(np.zeros(n * efx.sbc_state_bytes(), dtype=np.uint8))
+    d_pcm, d_ret, d_cnt = dec.alloc(n * 34 * 256 * 2), dec.alloc(n * 34 * 4), dec.alloc(n * 4)
+    got = [np.zeros(0, np.int16) for _ in range(n)]
+    for f0, f1 in ((0, 21), (21, 34)):
+        dec.sbc_decode(n, d_fr.ptr + f0 * fb, stride, fb, f1 - f0, d_st, d_pcm, 34 * 256, d_ret, d_cnt)
+        dec.sync()
+        cnt = d_cnt.download(np.uint32, n)
+        allpcm = d_pcm.download(np.int16, n * 34 * 256).reshape(n, 34 * 256)
+        for i in range(n):
+            got[i] = np.concatenate([got[i], allpcm[i, :cnt[i]]])
+    for i, st in enumerate(streams):
+        want, _ = oracle.sbc_decode(st, fb)
+        assert np.array_equal(got[i], want), i
+    for b in (d_fr, d_st, d_pcm, d_ret, d_cnt):
+        b.free()
+    dec.close()
+
+
 def test_batch_of_streams_and_pdm_chain(efx):
     """256 streams with different content decode independently; the PCM then feeds k_pdm on the
     device (config 4's audio half: SBC -> PCM -> PDM) and matches the oracle chain."""
