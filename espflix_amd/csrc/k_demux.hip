@@ -11,9 +11,9 @@
 //   2. one thread per packet parses its header out of LDS -> (payload start, payload bytes, PTS);
 //   3. a workgroup prefix sum of the payload sizes gives every packet its ES offset (packet order
 //      is stream order) and compacts the PES PTS list;
-//   4. the ES bytes of the chunk are produced output-centric: one thread per destination dword,
-//      the source packet found by binary search in the LDS prefix array, four LDS byte reads,
-//      one coalesced dword store (byte stores only on the two ragged chunk edges).
+//   4. the ES bytes of the chunk are produced output-centric: one thread per destination group of 16 bytes,
+//      the source packet found by binary search in the LDS prefix array; a group inside one payload is five
+//      aligned LDS dwords funnel-shifted into one 16-byte store, the others go byte by byte.
 //
 // After the last packet the workgroup appends the reference's end-of-data tail
 // 00 | 00 00 01 B7 | 00 00 01 B7 (player.cpp:456,472) and zero-fills the stream's region.
@@ -181,11 +181,15 @@ __device__ __forceinline__ void demux_body(const uint8_t* __restrict__ ts, const
                 sh_prefix[kChunk] = total;
         }
         __syncthreads();
-        // ---- 4. gather: one destination dword per thread -------------------------------------
+        // ---- 4. gather: one destination group of 16 bytes per thread --------------------------
+        // (one search per group; a group that lies inside one packet's payload -- eleven in twelve -- is five aligned LDS
+        // dwords funnel-shifted into four and ONE 16-byte store; the groups across packet boundaries and the ragged
+        // chunk edges go byte by byte)
         const uint32_t lo = es_pos, hi = es_pos + total;
-        for (uint32_t d = (lo >> 2) + tid; d * 4 < hi; d += kThreads) {
-            const uint32_t o0 = d * 4;
-            uint32_t first_o = max(o0, lo), last_o = min(o0 + 4, hi);  // bytes [first_o, last_o) of this dword
+        const uint32_t* pk32 = reinterpret_cast<const uint32_t*>(sh_pkt4);
+        for (uint32_t g = (lo >> 4) + tid; g * 16 < hi; g += kThreads) {
+            const uint32_t g0 = g * 16;
+            const uint32_t first_o = max(g0, lo), last_o = min(g0 + 16, hi);  // bytes [first_o, last_o) of this group
             // packet holding byte first_o: the last j with prefix[j] <= rel (zero-length packets share a prefix)
             uint32_t rel = first_o - lo;
             int a = 0, b = kChunk;  // invariant: prefix[a] <= rel < prefix[b]
@@ -197,22 +201,33 @@ __device__ __forceinline__ void demux_body(const uint8_t* __restrict__ ts, const
                 else
                     b = m;
             }
-            uint32_t word = 0;
             uint32_t next = sh_prefix[a + 1];
-            for (uint32_t o = first_o; o < last_o; o++, rel++) {
-                while (rel >= next) {
-                    a++;
-                    next = sh_prefix[a + 1];
-                }
-                const int32_t sp = sh_src[a];
-                const uint32_t byte = sp < 0 ? 0u : pk[sp + (rel - sh_prefix[a])];
-                word |= byte << ((o & 3) * 8);
+            const int32_t sp0 = sh_src[a];
+            if (last_o - first_o == 16 && sp0 >= 0 && next - rel >= 16) {
+                const uint32_t at = (uint32_t)sp0 + (rel - sh_prefix[a]), w = at >> 2, sh = (at & 3) * 8;
+                const uint32_t d0 = pk32[w], d1 = pk32[w + 1], d2 = pk32[w + 2], d3 = pk32[w + 3], d4 = pk32[w + 4];
+                *reinterpret_cast<uint4*>(dst + g0) = make_uint4(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
+                                                                __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh));
+                continue;
             }
-            if (last_o - first_o == 4)
-                *reinterpret_cast<uint32_t*>(dst + o0) = word;
-            else
-                for (uint32_t o = first_o; o < last_o; o++)
-                    dst[o] = (uint8_t)(word >> ((o & 3) * 8));
+            for (uint32_t o0 = first_o & ~3u; o0 < last_o; o0 += 4) {
+                const uint32_t f_o = max(o0, first_o), l_o = min(o0 + 4, last_o);
+                uint32_t word = 0;
+                for (uint32_t o = f_o; o < l_o; o++, rel++) {
+                    while (rel >= next) {
+                        a++;
+                        next = sh_prefix[a + 1];
+                    }
+                    const int32_t sp = sh_src[a];
+                    const uint32_t byte = sp < 0 ? 0u : pk[sp + (rel - sh_prefix[a])];
+                    word |= byte << ((o & 3) * 8);
+                }
+                if (l_o - f_o == 4)
+                    *reinterpret_cast<uint32_t*>(dst + o0) = word;
+                else
+                    for (uint32_t o = f_o; o < l_o; o++)
+                        dst[o] = (uint8_t)(word >> ((o & 3) * 8));
+            }
         }
         es_pos = hi;
         n_pes += total_pes;
