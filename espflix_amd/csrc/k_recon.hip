@@ -366,35 +366,50 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     // ---- prediction of the 8 rows, in the shadow of the entry loads just issued (a wave's life is its chain of
     // memory round trips: record -> owner search -> entries; this arithmetic needs only the windows, which were
     // requested before) -- the 27 window registers die here, before the 64 IDCT registers come alive -----------
+    // All four half-pel cases of mocomp() (player.cpp:767-820) are ONE expression, (a + b + c + d + 2) >> 2 per byte with
+    // a = the pixel, b = the pixel to the right if hx else a, c = the pixel below if hy else a, d = below-right / below /
+    // right / a: with equal operands it degenerates exactly to (a + b + 1) >> 1 and to a.  (Lanes of one wave carry
+    // different vectors, so a branch per case would execute all four.)  Built from byte-wise averages (v_lerp_u8):
+    // with H = (a + b) >> 1 per WINDOW row, X = a ^ b, and h2 / x2 those of the row below if hy (else the same row's),
+    // the result is lerp(H, h2, 1) + (X & x2 & ~(H ^ h2) & 1).  A window row's P (eight pixels at the block's position),
+    // Q (one pixel to the right if hx: byte permutes with per-lane selectors), H and X serve the output row it is `a` for
+    // and the one it is `c` for.
     uint32_t pr_lo[8], pr_hi[8];
+    {
+        const uint32_t selP = 0x03020100u + 0x01010101u * (uint32_t)(px0 & 3), selQ = selP + 0x01010101u * (uint32_t)hx;
+        const uint32_t hym = 0u - (uint32_t)hy;
+        const uint32_t keep = intra ? 0u : ~0u;  // (an intra block has no prediction: its window registers hold its own position)
+        auto pick = [](uint32_t m, uint32_t set, uint32_t clear) {  // bit by bit: m ? set : clear  (v_bfi_b32)
+            uint32_t r;
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(set), "v"(clear));
+            return r;
+        };
+        auto row = [&](int r, uint32_t& Hl, uint32_t& Hh, uint32_t& Xl, uint32_t& Xh) {
+            const uint32_t Pl = __builtin_amdgcn_perm(wb[r], wa[r], selP), Ph = __builtin_amdgcn_perm(wc[r], wb[r], selP);
+            const uint32_t Ql = __builtin_amdgcn_perm(wb[r], wa[r], selQ), Qh = __builtin_amdgcn_perm(wc[r], wb[r], selQ);
+            Hl = __builtin_amdgcn_lerp(Pl, Ql, 0);
+            Hh = __builtin_amdgcn_lerp(Ph, Qh, 0);
+            Xl = Pl ^ Ql;
+            Xh = Ph ^ Qh;
+        };
+        uint32_t Hl, Hh, Xl, Xh;
+        row(0, Hl, Hh, Xl, Xh);
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        uint32_t p_lo = 0, p_hi = 0;
-        if (!intra) {
-            // ---- prediction: the four half-pel cases of mocomp(), player.cpp:767-820 ----------------
-            const uint32_t a0 = wa[r], a1 = wb[r], a2 = wc[r], b0 = wa[r + 1], b1 = wb[r + 1], b2 = wc[r + 1];
-            const int sh = px0 & 3;
-            // pixels 0..7 of the row (A) and of the next row (B); pixel 8 is byte `sh` of the third dword.
-            // All four half-pel cases of mocomp() are one expression, (a + b + c + d + 2) >> 2 per byte
-            // with  b = the pixel to the right if hx else a,  c = the pixel below if hy else a,
-            // d = below-right / below / right / a:  with equal operands it degenerates exactly to
-            // (a + b + 1) >> 1 and to a.  Lanes of one wave carry different vectors, so a branch per
-            // case would execute all four.
-            const uint32_t A_lo = __builtin_amdgcn_alignbit(a1, a0, sh * 8), A_hi = __builtin_amdgcn_alignbit(a2, a1, sh * 8);
-            const uint32_t B_lo = __builtin_amdgcn_alignbit(b1, b0, sh * 8), B_hi = __builtin_amdgcn_alignbit(b2, b1, sh * 8);
-            const uint32_t A9 = (a2 >> (sh * 8)) & 0xFF, B9 = (b2 >> (sh * 8)) & 0xFF;
-            const uint32_t Ar_lo = __builtin_amdgcn_alignbit(A_hi, A_lo, 8), Ar_hi = (A_hi >> 8) | (A9 << 24);
-            const uint32_t Br_lo = __builtin_amdgcn_alignbit(B_hi, B_lo, 8), Br_hi = (B_hi >> 8) | (B9 << 24);
-            const uint32_t b_lo = hx ? Ar_lo : A_lo, b_hi = hx ? Ar_hi : A_hi;
-            const uint32_t c_lo = hy ? B_lo : A_lo, c_hi = hy ? B_hi : A_hi;
-            const uint32_t d_lo = hy ? (hx ? Br_lo : B_lo) : b_lo, d_hi = hy ? (hx ? Br_hi : B_hi) : b_hi;
-            p_lo = avg4_lerp(A_lo, b_lo, c_lo, d_lo);
-            p_hi = avg4_lerp(A_hi, b_hi, c_hi, d_hi);
+        for (int r = 0; r < 8; r++) {
+            uint32_t Hl1, Hh1, Xl1, Xh1;
+            row(r + 1, Hl1, Hh1, Xl1, Xh1);
+            const uint32_t h2l = pick(hym, Hl1, Hl), h2h = pick(hym, Hh1, Hh);
+            const uint32_t x2l = pick(hym, Xl1, Xl), x2h = pick(hym, Xh1, Xh);
+            pr_lo[r] = (__builtin_amdgcn_lerp(Hl, h2l, 0x01010101u) + (Xl & x2l & ~(Hl ^ h2l) & 0x01010101u)) & keep;
+            pr_hi[r] = (__builtin_amdgcn_lerp(Hh, h2h, 0x01010101u) + (Xh & x2h & ~(Hh ^ h2h) & 0x01010101u)) & keep;
+            Hl = Hl1;
+            Hh = Hh1;
+            Xl = Xl1;
+            Xh = Xh1;
+            // (one row at a time: all nine rows' permutes hoisted to the top cost 139 registers)
+            asm volatile("" : "+v"(pr_lo[r]), "+v"(pr_hi[r]), "+v"(Hl), "+v"(Hh), "+v"(Xl), "+v"(Xh));
         }
-        pr_lo[r] = p_lo;
-        pr_hi[r] = p_hi;
     }
-
 
     if (total) {
         for (uint32_t i0 = lane;;) {  // (uniform trip count: i0 - lane < total)
