@@ -179,6 +179,7 @@ struct efx_ctx {
     VideoTables* d_video[2] = {nullptr, nullptr};  // [0] PAL, [1] NTSC
     VideoLineTemplates* d_video_lines[2] = {nullptr, nullptr};
     SbcTables* d_sbc_tables = nullptr;
+    int parse_wg_cap = 0;  // k_parse workgroups resident per parse half when the call is split (0: no cap); EFX_PARSE_WG_CAP
     uint32_t* d_sbc_flags = nullptr;  // per stream of an efx_sbc_decode call: 1 = decoded frame-parallel (k_sbc_check)
     size_t sbc_flags_cap = 0;
     uint64_t* d_hash = nullptr;
@@ -333,8 +334,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     if (hipSetDevice(cfg->device) != hipSuccess)
         return bail(EFX_ERR_NO_DEVICE);
     StreamSet pooled;
-    const bool experiment = getenv("EFX_EXP_PARSE_CUS") != nullptr;
-    if (!cfg->hip_stream && !experiment && take_stream_set(cfg->device, &pooled)) {
+    if (!cfg->hip_stream && take_stream_set(cfg->device, &pooled)) {
         // the stream set of an earlier context on this device: same queues, same places
         ctx->stream = pooled.recon;
         ctx->own_stream = true;
@@ -365,25 +365,6 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess)
             return bail(EFX_ERR_DEVICE);
-        // development aid ("who takes what from whom"): EFX_EXP_PARSE_CUS=n confines the parse
-        // streams to n of the compute units (every 256/n-th one), EFX_EXP_RECON_REST=1 the reconstruction stream to the others
-        const char* exp_cus = getenv("EFX_EXP_PARSE_CUS");
-        int mask_n = exp_cus ? atoi(exp_cus) : 0;
-        hipDeviceProp_t prop;
-        if (mask_n > 0 && hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && mask_n < prop.multiProcessorCount) {
-            const int total = prop.multiProcessorCount, every = total / mask_n;
-            std::vector<uint32_t> pm((total + 31) / 32, 0), rm((total + 31) / 32, 0);
-            for (int c = 0; c < total; c++)
-                (c % every == 0 ? pm : rm)[c / 32] |= 1u << (c % 32);
-            for (auto& ps : ctx->parse_streams)
-                if (hipExtStreamCreateWithCUMask(&ps, (uint32_t)pm.size(), pm.data()) != hipSuccess)
-                    return bail(EFX_ERR_DEVICE);
-            if (getenv("EFX_EXP_RECON_REST") && ctx->own_stream) {
-                (void)hipStreamDestroy(ctx->stream);
-                if (hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)rm.size(), rm.data()) != hipSuccess)
-                    return bail(EFX_ERR_DEVICE);
-            }
-        } else
         for (auto& ps : ctx->parse_streams)
             if (hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, hi) != hipSuccess)
                 return bail(EFX_ERR_DEVICE);
@@ -452,6 +433,16 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
     if (e != hipSuccess) {
         fprintf(stderr, "efx_create: %s\n", hipGetErrorString(e));
         return bail(EFX_ERR_DEVICE);
+    }
+    {
+        // parse workgroups resident per parse half: one for every second compute unit (two halves in flight: one per CU).
+        // Measured on 256 CUs, 1024 streams x GOP 12 (tools/exp/cap_sweep.py): no cap 8.05-8.18, 144: 8.27-8.34,
+        // 128: 8.44-8.54, 96: 7.60 M frames/s (the parse half becomes the critical path).
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess)
+            ctx->parse_wg_cap = std::max(1, prop.multiProcessorCount / 2);
+        if (const char* cap = getenv("EFX_PARSE_WG_CAP"))  // (development: 0 = no cap)
+            ctx->parse_wg_cap = atoi(cap);
     }
     ParseTables* pt = new ParseTables;
     build_parse_tables(pt);
@@ -960,7 +951,14 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
                 EFX_HIP(hipEventRecord(te->ev[1], sp));
             const int max_slices = n * P * kMaxSlicesPerPicture;
             const int parse_waves = (max_slices + kParseLanes - 1) / kParseLanes;  // (rounded UP: one lane per slice slot)
-            hipLaunchKernelGGL(k_parse, dim3((parse_waves + kParseWaves - 1) / kParseWaves), dim3(64 * kParseWaves), 0, sp, u.d_es,
+            // k_parse's waves pull groups of slices off a counter: the grid is how many of them are resident at a time.  When the
+            // call runs as parse halves (short slices: the reconstruction launches are what it waits for) a parse half is kept to
+            // `parse_wg_cap` workgroups, so that its LDS leaves room for the k_recon waves beside it; with long slices the parse
+            // half is the critical path and takes every workgroup it can use.
+            int parse_wgs = (parse_waves + kParseWaves - 1) / kParseWaves;
+            if (G > 1 && ctx->parse_wg_cap > 0)
+                parse_wgs = std::min(parse_wgs, ctx->parse_wg_cap);
+            hipLaunchKernelGGL(k_parse, dim3(parse_wgs), dim3(64 * kParseWaves), 0, sp, u.d_es,
                                descs, counters, ctx->d_tm_tables, sl.d_mbrecs, sl.d_raw, sl.d_coefs, sl.d_status, P, sl.epoch);
             if (te)
                 EFX_HIP(hipEventRecord(te->ev[2], sp));

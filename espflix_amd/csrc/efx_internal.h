@@ -112,6 +112,8 @@ struct DecodeCounters {
     uint32_t streams;  // streams of the group of streams these counters belong to (k_slice_scan)
     unsigned long long coefficients;
     unsigned long long macroblocks;
+    uint32_t next_wave;  // k_parse: the next group of kParseLanes slices nobody has taken yet (its waves pull their work)
+    uint32_t reserved;
 };
 
 // composite video geometry + tables (video.cpp:514-630)

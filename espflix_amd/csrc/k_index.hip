@@ -452,6 +452,7 @@ __global__ __launch_bounds__(1024) void k_slice_scan(const PicInfo* __restrict__
         counters->streams = (uint32_t)n_streams;
         counters->coefficients = 0;
         counters->macroblocks = 0;
+        counters->next_wave = 0;
         slice_base[n] = carry;
     }
 }

@@ -152,35 +152,20 @@ struct SharedTables {
 
 }  // namespace
 
-__global__ __launch_bounds__(64 * kParseWaves) void k_parse(const uint8_t* __restrict__ es, const SliceDesc* __restrict__ descs,
-                                                            DecodeCounters* __restrict__ counters,
-                                                            const TmTables* __restrict__ gtab, MbRec* __restrict__ mbrecs,
-                                                            TmU4* __restrict__ raw_recs, uint32_t* __restrict__ coefs,
-                                                            uint32_t* __restrict__ status, int max_pictures, int epoch)
+// One group of kParseLanes slices (`w`), one lane per slice: the two passes.
+__device__ __forceinline__ void parse_group(uint32_t w, const uint8_t* __restrict__ es, const SliceDesc* __restrict__ descs,
+                                            DecodeCounters* __restrict__ counters, SharedTables& sh, MbRec* __restrict__ mbrecs,
+                                            TmU4* __restrict__ raw_recs, uint32_t* __restrict__ coefs, uint32_t* __restrict__ status,
+                                            int max_pictures, int epoch)
 {
-    const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t gid = (gthread >> 6) * kParseLanes + (threadIdx.x & 63);
+    const uint32_t gid = w * kParseLanes + (threadIdx.x & 63);
     const bool mine = (threadIdx.x & 63) < kParseLanes && gid < counters->total_slices;
     SliceDesc d = {};
     if (mine)
         d = descs[gid];
-    if (!__syncthreads_or(mine))
-        return;  // no slice in the whole block: leave before staging tables
-    // a few thousand long, latency-bound waves that run next to the (many, short) reconstruction waves of the previous
-    // decode call: ask the SIMD arbiter to favour them
-    __builtin_amdgcn_s_setprio(3);
-    __shared__ SharedTables sh;
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(gtab);
-        uint4* dst = reinterpret_cast<uint4*>(&sh.t);
-        for (int i = threadIdx.x; i < (int)(sizeof(TmTables) / 16); i += blockDim.x)
-            dst[i] = src[i];
-    }
     const uint32_t pic = d.pic_code_flags & 0xFF;
-    EFX_PROBE_CLAIM(1, gthread >> 6);
+    EFX_PROBE_CLAIM(1, w);
     EFX_PROBE_STAMP(1);
-    __syncthreads();
-
     const int code = (d.pic_code_flags >> 8) & 0xFF;
     const int first_mb = (code - 1) * kMbW;
     const int mb_limit = (int)d.mb_limit;
@@ -263,7 +248,7 @@ __global__ __launch_bounds__(64 * kParseWaves) void k_parse(const uint8_t* __res
     EFX_PROBE_STAMP(3);
     EFX_PROBE_SET(5, efx_probe_trips);
     if (!has_slice)
-        return;
+        return;  // (the lane: its wave goes on to the next group when all lanes are back)
     sink.finish(L.tok);
     tm_end(L, sp, store_raw);
 
@@ -284,6 +269,41 @@ __global__ __launch_bounds__(64 * kParseWaves) void k_parse(const uint8_t* __res
     atomicAdd(&counters->macroblocks, (unsigned long long)n_mbs);
 }
 
+// The kernel's waves PULL their work: a workgroup stages the tables once, then each of its waves takes groups of
+// kParseLanes slices off a counter until none is left.  The grid is what the caller wants resident at a time: every parse
+// workgroup holds 60 KB of LDS for as long as it lives, and with one wave per group of slices two parse halves kept
+// 36 of the chip's 41 MB of LDS away from the k_recon launches they run beside (7 instead of 12 reconstruction waves per
+// CU: efx_probe.h, tools/dbg/probe_waves.py) -- those launches, not the parse halves, are what a decode call waits for.
+__global__ __launch_bounds__(64 * kParseWaves) void k_parse(const uint8_t* __restrict__ es, const SliceDesc* __restrict__ descs,
+                                                            DecodeCounters* __restrict__ counters,
+                                                            const TmTables* __restrict__ gtab, MbRec* __restrict__ mbrecs,
+                                                            TmU4* __restrict__ raw_recs, uint32_t* __restrict__ coefs,
+                                                            uint32_t* __restrict__ status, int max_pictures, int epoch)
+{
+    const uint32_t n_groups = (counters->total_slices + kParseLanes - 1) / kParseLanes;
+    if (blockIdx.x * kParseWaves >= n_groups)
+        return;  // (more workgroups than groups of slices: leave before staging tables)
+    // a few thousand long, latency-bound waves that run next to the (many, short) reconstruction waves of the previous
+    // decode call: ask the SIMD arbiter to favour them
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ SharedTables sh;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(gtab);
+        uint4* dst = reinterpret_cast<uint4*>(&sh.t);
+        for (int i = threadIdx.x; i < (int)(sizeof(TmTables) / 16); i += blockDim.x)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+    for (;;) {
+        uint32_t w = 0;
+        if ((threadIdx.x & 63) == 0)
+            w = atomicAdd(&counters->next_wave, 1u);
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+        if (w >= n_groups)
+            break;
+        parse_group(w, es, descs, counters, sh, mbrecs, raw_recs, coefs, status, max_pictures, epoch);
+    }
+}
+
 }  // namespace efx
 
-EFX_PROBE_READER(parse)
