@@ -349,7 +349,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
             return bail(EFX_ERR_DEVICE);
         ctx->own_stream = true;
-        ctx->pooled_streams = !experiment;
+        ctx->pooled_streams = true;
         std::lock_guard<std::mutex> lk(g_pool_guard);
         ctx->stream_serial = ++g_set_serial;
     }
