@@ -61,7 +61,7 @@ constexpr int kMaxGroups = 16;      // an efx_decode call parses its streams in 
 #endif
 constexpr int kReconMerge = EFX_RECON_MERGE;  // parse halves whose streams are reconstructed by ONE launch per picture index
 #ifndef EFX_GROUP_STREAMS
-#define EFX_GROUP_STREAMS 512
+#define EFX_GROUP_STREAMS 1024
 #endif
 constexpr int kGroupStreams = EFX_GROUP_STREAMS;
 constexpr double kGroupMaxSliceBytes = 640;  // a call is split into parse halves only when its slices are shorter than this on average (efx_decode_range)
@@ -112,7 +112,7 @@ struct efx_ctx {
         uint32_t* h_hint = nullptr;      // pinned: {slices, streams} of the first parse half of this batch's first decode
         hipEvent_t hint_ready = nullptr;
         bool hint_recorded = false;
-        int halves = 0;                  // parse halves its decodes run as, once decided (0: not yet)
+        int halves = 0;                  // how its decodes run, once decided (0: not yet; 1 long slices, 2 short slices)
     } up[kUploads];
     int cur_up = -1;  // batch the next efx_decode reads
     hipStream_t copy_stream = nullptr;
@@ -167,7 +167,7 @@ struct efx_ctx {
     };
     Group groups[kMaxGroups];  // reconstruction groups of the most recent efx_decode
     int n_groups = 0;
-    int last_halves = 0;       // parse halves of the most recent efx_decode (the default while an upload's slice count is on its way)
+    int last_halves = 0;       // mode of the most recent efx_decode (the default while an upload's slice count is on its way)
     int last_upload = 0;       // batch the most recent efx_decode read
     int last_n_streams = 0;    // ... its stream count and format, as they were when the decode was queued (a later upload may
     bool last_ts_input = false;  // have recycled the Upload record by the time the results are fetched)
@@ -179,7 +179,7 @@ struct efx_ctx {
     VideoTables* d_video[2] = {nullptr, nullptr};  // [0] PAL, [1] NTSC
     VideoLineTemplates* d_video_lines[2] = {nullptr, nullptr};
     SbcTables* d_sbc_tables = nullptr;
-    int parse_wg_cap = 0;  // k_parse workgroups resident per parse half when the call is split (0: no cap); EFX_PARSE_WG_CAP
+    int parse_wg_cap = 0;  // k_parse workgroups resident per parse kernel when the batch's slices are short (0: no cap); EFX_PARSE_WG_CAP
     uint32_t* d_sbc_flags = nullptr;  // per stream of an efx_sbc_decode call: 1 = decoded frame-parallel (k_sbc_check)
     size_t sbc_flags_cap = 0;
     uint64_t* d_hash = nullptr;
@@ -435,12 +435,14 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         return bail(EFX_ERR_DEVICE);
     }
     {
-        // parse workgroups resident per parse half: one for every second compute unit (two halves in flight: one per CU).
-        // Measured on 256 CUs, 1024 streams x GOP 12 (tools/exp/cap_sweep.py): no cap 8.05-8.18, 144: 8.27-8.34,
-        // 128: 8.44-8.54, 96: 7.60 M frames/s (the parse half becomes the critical path).
+        // parse workgroups resident per parse kernel when the slices are short: five for every eight compute units.
+        // Measured on 256 CUs, 1024 streams x GOP 12 (tools/exp/cap_sweep2.py, profiles/r4_schedule_sweep.md): groups of 512
+        // streams without a cap 8.05-8.18 M frames/s, capped at 128: 8.15-8.54; groups of 1024 capped at 128 ... 192:
+        // 8.57-9.06 (flat between 144 and 192 on one box, best at 176 on another); 96 and below: the parse kernel
+        // becomes the critical path.
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess)
-            ctx->parse_wg_cap = std::max(1, prop.multiProcessorCount / 2);
+            ctx->parse_wg_cap = std::max(1, prop.multiProcessorCount * 5 / 8);
         if (const char* cap = getenv("EFX_PARSE_WG_CAP"))  // (development: 0 = no cap)
             ctx->parse_wg_cap = atoi(cap);
     }
@@ -855,17 +857,21 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
         return fail(ctx, EFX_ERR_STATE, "efx_decode: no streams uploaded");
     efx_ctx::Upload& u = ctx->up[ctx->cur_up];
     const int n_all = u.n_streams, P = ctx->cfg.max_pictures, D = ctx->cfg.ring_depth;
-    // Parse halves of this call.  The first decode of an upload runs as the previous upload did (nothing is known about
-    // the new batch yet); it leaves the batch's slice count in a pinned word, and from the second decode of the same
-    // upload on the split is decided from that and stays: the launch structure of a run of calls does not depend on timing.
-    int G = 1;
+    // How the call runs depends on the batch's slices.  SHORT slices (the 12-slice pictures of SURVEY 8d: 315 bytes each):
+    // the reconstruction launches are what the call waits for -- it runs as groups of kGroupStreams streams (a batch larger
+    // than that pipelines inside the call) and a parse half is kept to `parse_wg_cap` resident workgroups, which leaves the
+    // k_recon waves beside it their LDS.  LONG slices (ffmpeg's 5-slice pictures, 1.2 kB each): the parse half is the
+    // critical path -- one group, every workgroup it can use.  The first decode of an upload runs as the previous upload did
+    // (nothing is known about the new batch yet); it leaves the batch's slice count in a pinned word, and once that has
+    // arrived the mode is decided from it and stays.  Results do not depend on the mode.
+    int mode = 1;  // 1 long slices, 2 short slices
     if (u.halves)
-        G = u.halves;
-    else if (group_count(n_all) > 1) {
+        mode = u.halves;
+    else {
         const efx_ctx::Upload& prev = ctx->up[(ctx->cur_up + kUploads - 1) % kUploads];
         const efx_ctx::Upload* src = u.hint_recorded ? &u : (prev.hint_recorded ? &prev : nullptr);
         // (never waited for: the call stays asynchronous.  While this upload's own count is still on its way the
-        // previous upload's decides; the split is fixed once the upload's own count has arrived)
+        // previous upload's decides)
         if (src == &u && hipEventQuery(u.hint_ready) != hipSuccess)
             src = prev.hint_recorded && hipEventQuery(prev.hint_ready) == hipSuccess ? &prev : nullptr;
         else if (src && hipEventQuery(src->hint_ready) != hipSuccess)
@@ -874,12 +880,13 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
         if (src) {
             const uint32_t hint_slices = src->h_hint[0], hint_streams = src->h_hint[1];
             if (hint_slices && hint_streams && (double)u.es_used * hint_streams / n_all / hint_slices < kGroupMaxSliceBytes)
-                G = group_count(n_all);
+                mode = 2;
             if (src == &u)
-                u.halves = G;
-        } else if (ctx->last_halves > 0 && ctx->last_halves <= group_count(n_all))
-            G = ctx->last_halves;
+                u.halves = mode;
+        } else if (ctx->last_halves > 0)
+            mode = ctx->last_halves;
     }
+    const int G = mode == 2 ? group_count(n_all) : 1;
     hipStream_t sr = ctx->stream;
     int timing_slot = -1;
     if (ctx->timing && !ctx->timing_ring.empty()) {
@@ -887,7 +894,7 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
         ctx->timing_groups[timing_slot] = (uint8_t)G;
         ctx->timing_leaders[timing_slot] = 0;
     }
-    ctx->last_halves = G;
+    ctx->last_halves = mode;
     ctx->last_upload = ctx->cur_up;
     ctx->last_n_streams = u.n_streams;
     ctx->last_ts_input = u.ts_input;
@@ -951,12 +958,9 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
                 EFX_HIP(hipEventRecord(te->ev[1], sp));
             const int max_slices = n * P * kMaxSlicesPerPicture;
             const int parse_waves = (max_slices + kParseLanes - 1) / kParseLanes;  // (rounded UP: one lane per slice slot)
-            // k_parse's waves pull groups of slices off a counter: the grid is how many of them are resident at a time.  When the
-            // call runs as parse halves (short slices: the reconstruction launches are what it waits for) a parse half is kept to
-            // `parse_wg_cap` workgroups, so that its LDS leaves room for the k_recon waves beside it; with long slices the parse
-            // half is the critical path and takes every workgroup it can use.
+            // k_parse's waves pull groups of slices off a counter: the grid is how many of them are resident at a time (above)
             int parse_wgs = (parse_waves + kParseWaves - 1) / kParseWaves;
-            if (G > 1 && ctx->parse_wg_cap > 0)
+            if (mode == 2 && ctx->parse_wg_cap > 0)
                 parse_wgs = std::min(parse_wgs, ctx->parse_wg_cap);
             hipLaunchKernelGGL(k_parse, dim3(parse_wgs), dim3(64 * kParseWaves), 0, sp, u.d_es,
                                descs, counters, ctx->d_tm_tables, sl.d_mbrecs, sl.d_raw, sl.d_coefs, sl.d_status, P, sl.epoch);
