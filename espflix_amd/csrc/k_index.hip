@@ -8,7 +8,8 @@
 // k_index: one workgroup of kIndexWaves waves per stream.  Lanes read 16 contiguous bytes each (1 KiB per
 // wave load, four loads in flight per lane), test 16 byte positions, and append hits to an LDS unit list in
 // stream order via wave prefix sums.  Header fields of all units are then pre-parsed lane-parallel
-// and one lane walks the (short) unit list to apply the reference's sequential state rules.
+// and the reference's sequential state rules are applied to the whole list at once as counts and
+// "most recent unit of a kind" scans.
 #include <hip/hip_runtime.h>
 
 #include "efx_internal.h"
@@ -91,7 +92,9 @@ __global__ __launch_bounds__(64 * kIndexWaves) void k_index(
 {
     __shared__ uint32_t u_off[kMaxUnitsPerStream];
     __shared__ uint32_t u_info[kMaxUnitsPerStream];
-    __shared__ uint32_t sh_misc[4];
+    __shared__ uint32_t sh_misc[5];  // pictures; first unit the reference's hunt does not reach; first sequence_end;
+                                     // first sequence header of the wrong size; status bits of the walk
+    __shared__ uint32_t w_tot[kIndexWaves][4];
     constexpr int kKbPerWave = 16, kKbPerRound = kKbPerWave * kIndexWaves;
     static_assert(kKbPerRound == 64, "one wave scans the kilobyte counts of a round: one per lane");
     __shared__ uint32_t kb_count[kKbPerRound];  // start codes per kilobyte of the round, then their exclusive prefix
@@ -204,8 +207,12 @@ __global__ __launch_bounds__(64 * kIndexWaves) void k_index(
     // ---- 2. lane-parallel header pre-parse -------------------------------------------------
     // sh_misc[1]: index of the first unit from which the reference's marker hunt does not get to the next one
     // (hunt_arrives; 0 also stands for whatever precedes the first start code)
-    if (tid == 0)
+    if (tid == 0) {
         sh_misc[1] = (n_units && !hunt_arrives(base, 0, u_off[0])) ? 0u : ~0u;
+        sh_misc[2] = ~0u;
+        sh_misc[3] = ~0u;
+        sh_misc[4] = 0;
+    }
     __syncthreads();
     for (uint32_t i = tid; i < n_units; i += 64 * kIndexWaves) {
         const uint32_t off = u_off[i];
@@ -229,8 +236,12 @@ __global__ __launch_bounds__(64 * kIndexWaves) void k_index(
             uint32_t bad = (wdt != EFX_FRAME_WIDTH || hgt != EFX_FRAME_HEIGHT);
             u_info[i] = code | (bad << 16) | (li << 17) | (ln << 18);
             consumed = 64 + 512 * (li + ln);  // player.cpp:658-678
+            if (bad)
+                atomicMin(&sh_misc[3], i);
         } else if (code == 0xB8)
             consumed = 32;  // player.cpp:680-690
+        else if (code == 0xB7)
+            atomicMin(&sh_misc[2], i);  // sequence_end: the reference pauses here (player.cpp:1324-1327)
         if (consumed != ~0u && code != 0xB7 && i + 1 < n_units) {
             // (a header longer than its unit -- truncated -- has the reference read into the next unit)
             if (off * 8 + consumed > (u_off[i + 1] - 4) * 8 || !hunt_arrives(base, off * 8 + consumed, u_off[i + 1]))
@@ -239,81 +250,131 @@ __global__ __launch_bounds__(64 * kIndexWaves) void k_index(
     }
     __syncthreads();
 
-    // ---- 3. sequential state walk (one lane; the list is a few hundred entries at most) ------
+    // ---- 3. the reference's sequential state rules, all units at once -------------------------------------------
+    // MpegDecoder::marker() applied to the unit list in order is a handful of running quantities, each a count or a
+    // "most recent unit of a kind" along the list: the picture a unit belongs to (pictures so far), the sequence header
+    // and the P picture header in force (most recent B3 / most recent type-2 picture), a slice's rank in its picture
+    // (slice rows since the most recent picture), and three places where everything stops or changes -- the first
+    // sequence_end (the reference pauses, player.cpp:1324-1327), the picture that exceeds this call's budget, the first
+    // sequence header of the wrong size.  A thread takes one unit per round of 256; counts and "most recent" inside a
+    // wave are ballots, between waves and rounds a carry through LDS.  Picture `idx` keeps its slices at
+    // [idx * kMaxSlicesPerPicture ...) of the stream's temporary list.  A picture's slice count is written by the unit
+    // that ends it (the next picture, or whatever stops the walk).  Pictures before `first_picture` (efx_decode_from: a
+    // stream longer than max_pictures is decoded in several passes) count for their state and are dropped.
     PicInfo* mypics = pics + (size_t)s * max_pictures;
     SliceTmp* myslices = slices_tmp + (size_t)s * max_pictures * kMaxSlicesPerPicture;
-    if (tid == 0) {
-        // pictures before `first_picture` (efx_decode_from: a stream longer than max_pictures is decoded in
-        // several passes) are walked for their state -- sequence matrices, the P pictures' f_code -- and dropped
-        int pic = -1 - first_picture;
-        uint32_t slice_total = 0;
-        uint32_t p_full = 0, p_r = 0;  // forward_r_size / full_pel_forward persist across pictures
-        uint32_t seq_flags = 0, seq_off = 0;
-        uint16_t nsl = 0;
-        bool dead = false;
-        const uint32_t hunt_lost_at = sh_misc[1];
-        for (uint32_t i = 0; i < n_units; i++) {
-            uint32_t info = u_info[i], code = info & 0xFF;
-            if (i >= hunt_lost_at)
-                st |= EFX_STREAM_SERIAL_HUNT;
-            if (code == 0xB7)  // sequence_end: the reference pauses here (player.cpp:1324-1327)
-                break;
-            if (code == 0xB3) {
-                seq_flags = (info >> 17) & 3;
-                seq_off = u_off[i];
-                if (info & (1u << 16)) {
-                    st |= EFX_STREAM_BAD_SIZE;
-                    dead = true;
+    {
+        const uint32_t hunt_lost_at = sh_misc[1], end_at = min(sh_misc[2], n_units), dead_at = sh_misc[3];
+        const uint64_t le = ~0ull >> (63 - lane), lt = le >> 1;
+        // carries into this round: pictures so far, most recent B3 / P picture / picture (unit index + 1, 0 = none),
+        // slice rows since the most recent picture
+        uint32_t c_pics = 0, c_b3 = 0, c_p = 0, c_seg = 0;
+        uint32_t my_st = 0;
+        for (uint32_t round = 0; round <= end_at; round += 64 * kIndexWaves) {
+            const uint32_t i = round + tid;
+            const bool real = i < end_at;  // (unit end_at -- the sequence_end, or one past the list -- only ends things)
+            const uint32_t info = real ? u_info[i] : 0xFFu, code = info & 0xFF;
+            const bool is_pic = code == 0x00, is_p = is_pic && ((info >> 8) & 7) == 2, is_b3 = code == 0xB3;
+            // slice(): rows beyond the picture are rejected (player.cpp:1255-1258); nothing after a sequence header of
+            // the wrong size is decoded
+            const bool srow = code >= 0x01 && code <= 0xAF && (int)code - 2 < kMbH && i < dead_at;
+            const uint64_t m_pic = __ballot(is_pic), m_p = __ballot(is_p), m_b3 = __ballot(is_b3), m_s = __ballot(srow);
+            const int last_pic_w = m_pic ? 63 - __clzll((long long)m_pic) : -1;  // (wave-uniform)
+            if (lane == 0) {
+                w_tot[wave][0] = (uint32_t)__popcll(m_pic);
+                w_tot[wave][1] = m_b3 ? round + wave * 64 + 64 - (uint32_t)__clzll((long long)m_b3) : 0u;
+                w_tot[wave][2] = m_p ? round + wave * 64 + 64 - (uint32_t)__clzll((long long)m_p) : 0u;
+                w_tot[wave][3] = (uint32_t)__popcll(last_pic_w >= 0 ? m_s & ~(~0ull >> (63 - last_pic_w)) : m_s) |
+                                 (last_pic_w >= 0 ? 1u << 31 : 0u);
+            }
+            __syncthreads();
+            uint32_t pics_before = c_pics, b3 = c_b3, pp = c_p, seg = c_seg;  // at the start of this wave
+#pragma unroll
+            for (int w = 0; w < kIndexWaves; w++) {
+                const uint32_t t0 = w_tot[w][0], t1 = w_tot[w][1], t2 = w_tot[w][2], t3 = w_tot[w][3];
+                if (w < wave) {
+                    pics_before += t0;
+                    b3 = t1 ? t1 : b3;
+                    pp = t2 ? t2 : pp;
+                    seg = (t3 >> 31) ? (t3 & 0xFFFF) : seg + (t3 & 0xFFFF);
                 }
-            } else if (code == 0x00) {
-                if (pic >= 0)
-                    mypics[pic].n_slices = nsl;
-                if (pic + 1 >= pic_limit) {  // (efx_decode_range: at most this many pictures per stream in this call)
-                    st |= EFX_STREAM_TRUNCATED;
-                    break;
+                c_pics += t0;
+                c_b3 = t1 ? t1 : c_b3;
+                c_p = t2 ? t2 : c_p;
+                c_seg = (t3 >> 31) ? (t3 & 0xFFFF) : c_seg + (t3 & 0xFFFF);
+            }
+            __syncthreads();  // (w_tot is written again in the next round)
+            // this unit's view: pictures before it, B3 / P picture at or before it, slice rows since the picture it is in
+            pics_before += (uint32_t)__popcll(m_pic & lt);
+            if (m_b3 & le)
+                b3 = round + wave * 64 + 64 - (uint32_t)__clzll((long long)(m_b3 & le));
+            if (m_p & le)
+                pp = round + wave * 64 + 64 - (uint32_t)__clzll((long long)(m_p & le));
+            if (m_pic & lt) {
+                const int lp = 63 - __clzll((long long)(m_pic & lt));
+                seg = (uint32_t)__popcll(m_s & lt & ~(~0ull >> (63 - lp)));
+            } else
+                seg += (uint32_t)__popcll(m_s & lt);
+            if (i > end_at)
+                continue;
+            // picture index of the picture open before this unit, and of the one a picture header here opens
+            const int open = (int)pics_before - 1 - first_picture, opens = open + 1;
+            if (pics_before && open >= pic_limit)
+                continue;  // a picture header before this unit exceeded the budget: the walk ended there
+            const bool over = is_pic && opens >= pic_limit;  // (efx_decode_range: at most pic_limit pictures per stream in this call)
+            if (is_pic || i == end_at) {
+                if (pics_before && open >= 0)
+                    mypics[open].n_slices = (uint16_t)min(seg, (uint32_t)kMaxSlicesPerPicture);
+            }
+            if (over || i == end_at) {  // exactly one unit ends the walk
+                const uint32_t n = (uint32_t)(opens > 0 ? opens : 0);
+                pic_count[s] = n;
+                sh_misc[0] = n;
+                if (over)
+                    my_st |= EFX_STREAM_TRUNCATED;
+                // the reference's hunt is lost at a unit the walk looked at (the unit that ends it included)
+                if (n_units && hunt_lost_at <= min(i, n_units - 1))
+                    my_st |= EFX_STREAM_SERIAL_HUNT;
+                if (dead_at < i)
+                    my_st |= EFX_STREAM_BAD_SIZE;
+            } else if (is_pic) {
+                if (opens >= 0) {
+                    uint32_t p_full = 0, p_r = 0;  // forward_r_size / full_pel_forward persist across pictures
+                    if (pp) {
+                        const uint32_t pinfo = u_info[pp - 1], fc = (pinfo >> 12) & 7;
+                        p_full = (pinfo >> 11) & 1;
+                        p_r = fc ? fc - 1 : 0;  // f_code 0 is forbidden; the reference would shift by -1
+                    }
+                    const uint32_t seq_flags = b3 ? (u_info[b3 - 1] >> 17) & 3 : 0u;
+                    const uint32_t type = (info >> 8) & 7;
+                    // (field by field: n_slices belongs to the unit that ends the picture)
+                    PicInfo* pi = mypics + opens;
+                    pi->first_slice = (uint32_t)opens * kMaxSlicesPerPicture;
+                    pi->type = (type == 1) ? 1 : 2;
+                    pi->full_pel = (uint8_t)p_full;
+                    pi->r_size = (uint8_t)p_r;
+                    pi->custom_q = seq_flags ? 1 : 0;
+                    pi->reserved = (uint16_t)seq_flags;
+                    pi->seq_off = b3 ? u_off[b3 - 1] : 0u;
+                    pi->start_off = u_off[i];
                 }
-                pic++;
-                nsl = 0;
-                uint32_t type = (info >> 8) & 7;
-                if (type == 2) {
-                    p_full = (info >> 11) & 1;
-                    uint32_t fc = (info >> 12) & 7;
-                    p_r = fc ? fc - 1 : 0;  // f_code 0 is forbidden; the reference would shift by -1
-                }
-                if (pic < 0)
-                    continue;
-                PicInfo pi;
-                pi.first_slice = slice_total;
-                pi.n_slices = 0;
-                pi.type = (type == 1) ? 1 : 2;
-                pi.full_pel = (uint8_t)p_full;
-                pi.r_size = (uint8_t)p_r;
-                pi.custom_q = seq_flags ? 1 : 0;
-                pi.reserved = (uint16_t)seq_flags;
-                pi.seq_off = seq_off;
-                pi.start_off = u_off[i];
-                mypics[pic] = pi;
-            } else if (code >= 0x01 && code <= 0xAF) {
-                // slice(): rows beyond the picture are rejected (player.cpp:1255-1258)
-                if (pic >= 0 && !dead && (int)code - 2 < kMbH) {
-                    if (nsl < kMaxSlicesPerPicture) {
-                        uint32_t next = (i + 1 < n_units) ? u_off[i + 1] - 4 : len;
-                        SliceTmp t;
-                        t.off = u_off[i];
-                        t.len_code = ((next - u_off[i]) << 8) | code;
-                        myslices[slice_total++] = t;
-                        nsl++;
-                    } else
-                        st |= EFX_STREAM_TRUNCATED;
-                }
+            } else if (srow && pics_before && open >= 0) {
+                if (seg < (uint32_t)kMaxSlicesPerPicture) {
+                    const uint32_t next = (i + 1 < n_units) ? u_off[i + 1] - 4 : len;
+                    SliceTmp t;
+                    t.off = u_off[i];
+                    t.len_code = ((next - u_off[i]) << 8) | code;
+                    myslices[open * kMaxSlicesPerPicture + seg] = t;
+                } else
+                    my_st |= EFX_STREAM_TRUNCATED;
             }
         }
-        if (pic >= 0)
-            mypics[pic].n_slices = nsl;
-        pic_count[s] = (uint32_t)(pic >= 0 ? pic + 1 : 0);
-        status[s] = st;
-        sh_misc[0] = (uint32_t)(pic >= 0 ? pic + 1 : 0);
+        if (my_st)
+            atomicOr(&sh_misc[4], my_st);
     }
+    __syncthreads();
+    if (tid == 0)
+        status[s] = st | sh_misc[4];
     __syncthreads();
 
     // ---- 4. custom quantiser tables (sequence header loaded matrices, player.cpp:666-673) ----
@@ -417,34 +478,51 @@ __global__ __launch_bounds__(1024) void k_slice_scan(const PicInfo* __restrict__
                                                      uint32_t* __restrict__ slice_base,
                                                      DecodeCounters* __restrict__ counters)
 {
+    // A thread owns a run of consecutive pairs: its loads (permutation -> picture count -> slice count, three dependent
+    // trips to memory) are all in flight together, one pass over the workgroup's 1024 run totals orders the runs.
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry;
+    constexpr int kRun = 4;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = n_streams * max_pictures;
     if (tid == 0)
         carry = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        int i = base + tid;
-        uint32_t v = 0;
-        if (i < n) {
-            int p = i / n_streams, s = (int)stream_perm[i - p * n_streams];
-            if ((uint32_t)p < pic_count[s])
-                v = pics[(size_t)s * max_pictures + p].n_slices;
+    for (int base = 0; base < n; base += 1024 * kRun) {
+        uint32_t v[kRun];
+#pragma unroll
+        for (int r = 0; r < kRun; r++) {
+            const int i = base + tid * kRun + r;
+            v[r] = 0;
+            if (i < n) {
+                int p = i / n_streams, s = (int)stream_perm[i - p * n_streams];
+                if ((uint32_t)p < pic_count[s])
+                    v[r] = pics[(size_t)s * max_pictures + p].n_slices;
+            }
         }
+        uint32_t mine = 0;
+#pragma unroll
+        for (int r = 0; r < kRun; r++)
+            mine += v[r];
         uint32_t tot;
-        uint32_t ex = wave_excl_scan(v, &tot);
+        uint32_t ex = wave_excl_scan(mine, &tot);
         if (lane == 63)
             wave_tot[wv] = tot;
         __syncthreads();
         uint32_t off = carry;
         for (int k = 0; k < wv; k++)
             off += wave_tot[k];
-        if (i < n)
-            slice_base[i] = off + ex;
+        uint32_t at = off + ex;
+#pragma unroll
+        for (int r = 0; r < kRun; r++) {
+            const int i = base + tid * kRun + r;
+            if (i < n)
+                slice_base[i] = at;
+            at += v[r];
+        }
         __syncthreads();
         if (tid == 1023)
-            carry = off + ex + v;
+            carry = at;
         __syncthreads();
     }
     if (tid == 0) {

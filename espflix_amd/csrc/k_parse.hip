@@ -30,7 +30,13 @@ namespace efx {
 namespace {
 
 constexpr int kRingDwords = 16;  // per-lane bitstream ring in LDS (64 bytes)
-constexpr int kRingLow = 8;      // top up when any lane of the wave has fewer dwords than this ahead
+#ifndef EFX_TRIPS_PER_TOPUP
+#define EFX_TRIPS_PER_TOPUP 4
+#endif
+constexpr int kTripsPerTopup = EFX_TRIPS_PER_TOPUP;  // trips between two looks at the ring, the stage and who is alive
+constexpr int kRingLow = kTripsPerTopup + 4;  // top up when any lane of the wave has fewer dwords than this ahead (a trip consumes less
+                                              // than a dword, the window reads two dwords ahead)
+constexpr int kStageWords = kTripsPerTopup <= 4 ? 8 : 16;  // parked stream words per lane (a power of two >= trips + 3)
 
 // Each lane owns a ring of kRingDwords big-endian dwords of ITS slice in LDS, laid out ring[k][lane] (a wave's accesses
 // hit 64 different banks).  Global memory is read in WAVE-SYNCHRONOUS top-ups: when any lane runs low every lane refills
@@ -110,17 +116,19 @@ struct BitReader {
 // lane parks its words in an eight-dword LDS ring; between two groups of trips every lane that has four or more parked
 // stores one aligned group.
 struct StageSink {
-    uint32_t* stage;  // &stage[0][lane], word k of the slice's stream at stage[(k & 7) * 64]
+    uint32_t* stage;  // &stage[0][lane], word k of the slice's stream at stage[(k % kStageWords) * 64]
     uint32_t* coefs;
     uint32_t coef_last;  // last slot of the slice's region (regions start and end on multiples of four slots)
     uint32_t flushed;    // slots below this one are in memory (a multiple of four)
-    __device__ inline void put(uint32_t slot, uint32_t w) { stage[(slot & 7) * 64] = w; }
+    __device__ inline void put(uint32_t slot, uint32_t w) { stage[(slot & (kStageWords - 1)) * 64] = w; }
     __device__ inline void commit(uint32_t, uint32_t) {}
     // between two groups of at most four trips: at most one group has filled up
     __device__ inline void drain(uint32_t next)
     {
+#pragma unroll
+        for (int rep = 0; rep < (kTripsPerTopup + 3) / 4; rep++)
         if (next - flushed >= 4) {
-            const uint32_t* g = stage + (flushed & 4) * 64;
+            const uint32_t* g = stage + (flushed & (kStageWords - 4)) * 64;
             if (flushed + 3 <= coef_last)  // (words beyond the slice's region are dropped: the slice is flagged)
                 *reinterpret_cast<uint4*>(coefs + (size_t)flushed) = make_uint4(g[0], g[64], g[128], g[192]);
             flushed += 4;
@@ -131,7 +139,7 @@ struct StageSink {
         drain(next);
         for (uint32_t k = flushed; k < next; k++)
             if (k <= coef_last)
-                coefs[k] = stage[(k & 7) * 64];
+                coefs[k] = stage[(k & (kStageWords - 1)) * 64];
     }
     __device__ inline void rewind(uint32_t, uint32_t slot)
     {
@@ -139,7 +147,7 @@ struct StageSink {
         if (slot < flushed) {
             flushed = slot & ~3u;
             for (uint32_t k = flushed; k < slot; k++)
-                stage[(k & 7) * 64] = coefs[k];
+                stage[(k & (kStageWords - 1)) * 64] = coefs[k];
         }
     }
 };
@@ -147,7 +155,7 @@ struct StageSink {
 struct SharedTables {
     TmTables t;
     uint32_t ring[kParseWaves][kRingDwords + 4][64];  // [wave][dword][lane]; rows kRingDwords ... are scratch
-    uint32_t stage[kParseWaves][8][64];               // [wave][stream word & 7][lane]
+    uint32_t stage[kParseWaves][kStageWords][64];     // [wave][stream word mod kStageWords][lane]
 };
 
 }  // namespace
@@ -211,8 +219,7 @@ __device__ __forceinline__ void parse_group(uint32_t w, const uint8_t* __restric
     // sits in a dead state and takes the wave's trips without effect.
     EFX_PROBE_STAMP(2);
     EFX_PROBE_SET(6, pic | ((d.pic_code_flags >> 16) & 3) << 8);
-    constexpr int kTripsPerTopup = 4;
-    static_assert(kTripsPerTopup + 3 <= kRingLow, "the window reads two dwords ahead");
+    static_assert(kTripsPerTopup + 3 <= kRingLow && kRingLow <= kRingDwords - 4, "the window reads two dwords ahead; a top-up adds whole groups of four");
 #ifdef EFX_PROBE
     unsigned efx_probe_trips = 0;
 #endif
