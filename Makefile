@@ -9,7 +9,7 @@ CSRC     = espflix_amd/csrc
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 OBJS     = $(CSRC)/efx_api.o $(CSRC)/k_demux.o $(CSRC)/k_index.o $(CSRC)/k_parse.o $(CSRC)/k_recon.o $(CSRC)/k_video.o $(CSRC)/k_sbc.o $(CSRC)/k_tsindex.o $(CSRC)/efx_tables.o $(CSRC)/efx_multi.o
 
-.PHONY: all lib gen oracle ref clean dropin scale
+.PHONY: all lib gen oracle ref clean dropin scale harness
 # (`scale` links librccl: built by __graft_entry__.build() and by `make scale`, not by a plain `make`)
 all: lib gen oracle
 
@@ -60,6 +60,15 @@ tools/efx_scale: tools/efx_scale.cpp include/efx.h espflix_amd/libefx.so espflix
 
 oracle:
 	$(MAKE) -C oracle port
+
+# TEST: the slice parser of k_parse (csrc/parse_tm.h + the tables of csrc/efx_tables.cpp) compiled for the host and checked,
+# record by record, against the parse trace of the test oracle (tests/test_parse_machine.py; no GPU)
+harness: tests/_build/parse_harness
+tests/_build/parse_harness: tests/parse_harness.cpp $(CSRC)/parse_tm.h $(CSRC)/efx_tables.cpp $(CSRC)/efx_internal.h oracle/efx_oracle.c oracle/efx_oracle.h
+	mkdir -p tests/_build
+	gcc -O2 -std=c99 -c oracle/efx_oracle.c -o tests/_build/efx_oracle.o
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude -I$(CSRC) -Ioracle -x hip tests/parse_harness.cpp $(CSRC)/efx_tables.cpp \
+	    -x none tests/_build/efx_oracle.o -o $@
 ref:
 	$(MAKE) -C oracle ref
 

@@ -260,6 +260,7 @@ typedef struct {
     int eos_stage; /* 0 stream, 1 serving the eos pad, 2 exhausted */
     uint8_t* es_sink;  /* optional: collect the bytes handed to the bit reader (ts_to_es) */
     size_t es_cap, es_len;
+    size_t es_bytes; /* elementary-stream bytes handed to the bit reader so far (trace only) */
     int64_t pts, last_pts;
 
     /* bit window: low `cnt` bits of `win` are unread, MSB first */
@@ -390,6 +391,8 @@ static int src_byte(dec_t* d)
 static int next_byte(dec_t* d)
 {
     int b = src_byte(d);
+    if (d->eos_stage == 0)
+        d->es_bytes++;
     if (d->es_sink && d->eos_stage == 0) {
         if (d->es_len < d->es_cap)
             d->es_sink[d->es_len] = (uint8_t)b;
@@ -858,6 +861,10 @@ static void decode_slice(dec_t* d, int code)
     d->mb_x = d->mb_width - 1; /* first advance wraps to column 0 of row code-1 */
     {
         int rejected = d->mb_y >= d->mb_height || d->bad_size || d->mb_width == 0;
+        if (d->eos_stage == 0) {
+            size_t bit = d->es_bytes * 8 - (size_t)d->cnt; /* of the first bit after the marker the hunt stopped at */
+            TRACE(EFXO_T_SLICE_AT, (int)(bit >> 3), (int)(bit & 7), 0, 0);
+        }
         TRACE(EFXO_T_SLICE, (int)d->pictures - 1, code,
               d->pic_type | (d->full_pel << 4) | (d->r_size << 8) | (rejected ? 0 : 1 << 16), d->custom_q);
     }

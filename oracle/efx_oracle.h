@@ -49,7 +49,7 @@ long efxo_decode(const uint8_t* data, size_t len, int format, int flush_last,
  *                 1 "00 xx" = xx, 2 "80 xx" = xx - 256; b = run, c = level
  *   EFXO_T_SLICE_EXTRA (after the EFXO_T_SLICE it belongs to, only when the header has any) a = number of
  *                 extra_information_slice bytes skipped (player.cpp:1261-1262), b = the last one, c = picture type */
-enum { EFXO_T_SLICE = 0, EFXO_T_MB = 1, EFXO_T_COEF = 2, EFXO_T_BLOCK = 3, EFXO_T_ESCAPE = 4, EFXO_T_SLICE_EXTRA = 5 };
+enum { EFXO_T_SLICE = 0, EFXO_T_MB = 1, EFXO_T_COEF = 2, EFXO_T_BLOCK = 3, EFXO_T_ESCAPE = 4, EFXO_T_SLICE_EXTRA = 5, EFXO_T_SLICE_AT = 6 };
 typedef void (*efxo_trace_fn)(void* user, int kind, int a, int b, int c, int e);
 void efxo_set_trace(efxo_trace_fn fn, void* user);
 
