@@ -86,7 +86,7 @@ def pmc_traffic(kernel, S, P, key="kernels"):
     the figure is the one measured on this exact workload (1024 streams x GOP 12), None otherwise.
     The summary records the digest of the kernel sources it was measured on (tools/collect_profiles.sh); when the
     sources have changed since, the provenance says so and a warning goes to stderr."""
-    for name in ("r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
+    for name in ("r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if (S, P) != (1024, 12) or not os.path.exists(path):
             continue

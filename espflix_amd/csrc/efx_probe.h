@@ -46,6 +46,20 @@ __device__ inline unsigned long long* probe_claim(unsigned tag, unsigned wave, l
         if ((threadIdx.x & 63) == 0)              \
             efx_probe_rec[i] = wall_clock64();    \
     } while (0)
+// a stamp taken only once `v` (a loaded value) is there: the wait is part of what the stamp times
+#define EFX_PROBE_STAMP_AFTER(i, v)                                  \
+    do {                                                             \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(v));      \
+        if ((threadIdx.x & 63) == 0)                                 \
+            efx_probe_rec[i] = wall_clock64();                       \
+    } while (0)
+// shader cycles between the two (s_memtime): against the 100 MHz stamps this is the clock the CU actually ran at
+#define EFX_PROBE_CYCLES_BEGIN() const long long efx_probe_c0 = clock64()
+#define EFX_PROBE_CYCLES_END(i)                                      \
+    do {                                                             \
+        if ((threadIdx.x & 63) == 0)                                 \
+            efx_probe_rec[i] = (unsigned long long)(clock64() - efx_probe_c0); \
+    } while (0)
 #define EFX_PROBE_MAX(i, v) atomicMax(&efx_probe_rec[i], (unsigned long long)(v))
 #define EFX_PROBE_SET(i, v)                       \
     do {                                          \
@@ -79,6 +93,9 @@ __device__ inline unsigned long long* probe_claim(unsigned tag, unsigned wave, l
 #define EFX_PROBE_CLAIM(tag, wave) ((void)0)
 #define EFX_PROBE_CLAIM_AT(tag, wave, seq, when) ((void)0)
 #define EFX_PROBE_STAMP(i) ((void)0)
+#define EFX_PROBE_STAMP_AFTER(i, v) ((void)0)
+#define EFX_PROBE_CYCLES_BEGIN() ((void)0)
+#define EFX_PROBE_CYCLES_END(i) ((void)0)
 #define EFX_PROBE_MAX(i, v) ((void)0)
 #define EFX_PROBE_SET(i, v) ((void)0)
 #endif

@@ -314,3 +314,4 @@ __global__ __launch_bounds__(64 * kParseWaves) void k_parse(const uint8_t* __res
 
 }  // namespace efx
 
+EFX_PROBE_READER(parse)

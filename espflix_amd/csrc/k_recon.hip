@@ -121,7 +121,7 @@ __device__ constexpr double kAan[8] = {1.0,          1.3870398453221475, 1.30656
 __device__ constexpr int premul_at(int r, int c) { return (int)(32.0 * kAan[r] * kAan[c] + 0.5); }
 
 constexpr int kBlocksPerPicture = kMbCount * 6;
-constexpr int kLaneDwords = 33;  // per-lane LDS block: 64 int16 + one dword (see k_recon)
+constexpr int kLaneDwords = 33, kLaneData = 32;  // per-lane LDS block: 64 int16 + one dword (see k_recon)
 constexpr int kLaneHalfwords = 2 * kLaneDwords;
 
 // grid = (streams, 25): blockIdx.x = stream, blockIdx.y = group of 64 consecutive 8x8 blocks of the
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
                        ((long long)(epoch & 0xFF) * 16 + pic) * (gridDim.x * gridDim.y) + blockIdx.x * gridDim.y + blockIdx.y,
                        (unsigned)(epoch & 0xFF));
     EFX_PROBE_STAMP(1);
+    EFX_PROBE_CYCLES_BEGIN();
     EFX_PROBE_SET(6, (unsigned long long)pic | (unsigned long long)(epoch & 0xFF) << 8 | (unsigned long long)stream0 << 16);
     const int b_raw = blockIdx.y * 64 + lane;
     const bool have = b_raw < kBlocksPerPicture;
@@ -187,11 +188,12 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     const uint8_t* ref = frames + ((size_t)s * ring_depth + ref_slot) * kFrameBytes;
 
     // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
-    lds[lane * kLaneDwords + 32] = scan_tab[lane];
+    lds[lane * kLaneDwords + kLaneData] = scan_tab[lane];
     const uint32_t* const qt_custom = qtab_custom + ((size_t)s * max_pictures + pic) * 64;  // (read only where a record says "custom")
 
     const uint4 rw = *reinterpret_cast<const uint4*>(mbrecs + ((size_t)s * max_pictures + pic) * kMbCount + mb);
     const uint32_t w_base = rw.x, w_cnt = rw.y, w_misc = rw.z, w_mv = rw.w;
+    EFX_PROBE_STAMP_AFTER(3, w_base);  // the record has arrived
     // a macroblock no slice covers (or an absent picture) keeps the slot's content
     const bool live = have && (w_misc >> 24) == (uint32_t)(epoch & 0xFF);
     const uint32_t flags = (w_misc >> 16) & 0xFF;
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     {
         uint32_t* z = reinterpret_cast<uint32_t*>(mine);
 #pragma unroll
-        for (int k = 0; k < 32; k++)
+        for (int k = 0; k < kLaneData; k++)
             z[k] = 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the table written above is read below by other lanes
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             const int n = e & 63;
             const int level = (o_intra && n == 0) ? (int)e >> 6 : tm_level(e);
             // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
-            uint32_t t = lds[n * kLaneDwords + 32];
+            uint32_t t = lds[n * kLaneDwords + kLaneData];
             if (f & 0x80)
                 t = qt_custom[n];
             if (o_intra && n == 0) {
@@ -432,6 +434,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const uint32_t zd = s_zd[lane];
+    EFX_PROBE_STAMP_AFTER(5, zd);  // the entries have been dealt out: the IDCT starts
     const bool zf = (zd & 0x80) != 0;  // an entry sits at scan position 0
     // intra DC value (22 bits: a slice adds at most 1584 differentials of +-255 to the predictor)
     const int dc_raw = (int)((uint32_t)(uint16_t)mine[0] | ((uint32_t)((int)(zd << 26) >> 26) << 16));
@@ -517,6 +520,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
             *reinterpret_cast<uint2*>(cur + dst0 + r * kStride) = make_uint2(lo, hi);
     }
     EFX_PROBE_STAMP(4);
+    EFX_PROBE_CYCLES_END(2);
 }
 
 // FNV-1a-64 of whole ring frames, one lane per frame (verification helper, not on the timed path)

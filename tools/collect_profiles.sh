@@ -4,7 +4,7 @@
 # --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ).  Every pass is bounded by `timeout`.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$1; mkdir -p $out
-# --timed-only + 200 steps: 4800 of the 4860 k_recon launches of the process (24 per step: two groups of 512 streams x 12
+# --timed-only + 200 steps: 2400 of the 2436 k_recon launches of the process (12 per step: one group of 1024 streams x 12
 # picture indexes) belong to the timed region, so the average rocprofv3 reports is the one bench.py measures with HIP
 # events (roofline.avg_launch_ms)
 B="python bench.py --steps 200 --warmup 3 --no-cpu-baseline --no-fixed-batch --no-other-workloads --no-video-out --timed-only"

@@ -46,10 +46,10 @@ clear()
 if mode == "serial":
     dec.decode()
 else:
-    # k_recon keeps ten launches: those of ONE hand-over epoch in the middle of a run of back-to-back calls (a slot's
-    # epoch advances once per call that uses it: three slots, two groups per call)
+    # k_recon keeps five launches of 1024 streams: the last ones of ONE hand-over epoch in the middle of a run of
+    # back-to-back calls (a slot's epoch advances once per call that uses it: three slots, one group per call)
     lib.efx_probe_window_recon.argtypes = [C.c_uint, C.c_uint]
-    lib.efx_probe_window_recon(8, 8)
+    lib.efx_probe_window_recon(5, 5)
     for _ in range(16):
         dec.decode(sync=False)
     dec.sync()
@@ -88,6 +88,15 @@ if len(parse):
 if len(recon):
     life = (r4 - r1) / 100.0
     print(f"k_recon: {len(recon)} waves recorded; lifetime us p0 p10 p50 p90 p99 p100: {pct(life)}")
+    cyc = recon[:, 2].astype(np.int64)
+    t3r = recon[:, 3].astype(np.int64)
+    t5r = recon[:, 5].astype(np.int64)
+    okc = (cyc > 0) & (t3r >= r1) & (t5r >= t3r) & (r4 >= t5r)
+    if okc.any():
+        print("  shader clock GHz (cycles / lifetime)  :", pct(cyc[okc] / (life[okc] * 1000.0)))
+        print("  start -> record arrived us            :", pct((t3r[okc] - r1[okc]) / 100.0))
+        print("  record -> entries dealt out us        :", pct((t5r[okc] - t3r[okc]) / 100.0))
+        print("  IDCT, sum with the prediction, stores :", pct((r4[okc] - t5r[okc]) / 100.0))
     tagv = recon[:, 6].astype(np.int64)
     rcu = cu_key(recon)
     pcu = cu_key(parse) if len(parse) else np.zeros(0, np.int64)
