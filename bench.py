@@ -736,7 +736,7 @@ def run(job, args):
                    "streams_per_gpu": S, "streams_total": S * world, "pictures_per_stream": P, "es_bytes_per_gpu": r["es_bytes"],
                    "mean_bytes_per_picture": r["es_bytes"] / (S * P), "parallelism": f"stream-partition x{world}",
                    "coefficients_per_gpu": r["n_coefs"], "ring_depth": 2},
-        "roofline": {"bound": "hbm", "limiter": "dependent steps of a wave's life (record -> owner search -> entry loads -> scatter -> IDCT -> stores) at 18 waves per CU; neither fewer instructions nor more occupancy shortens it (DESIGN.md section 6)", "kernel": names[2], "achieved": achieved,
+        "roofline": {"bound": "hbm", "limiter": "25 600 waves per launch living 10.6 us each (record 1.5 us -> owner search, entry loads, dequantisation 5.9 us -> IDCT, sum, stores 2.8 us) at 14 resident per CU alone and 10.8 beside the parser, plus one wave life of fill and drain per launch; with all pixel and coefficient traffic removed a launch still takes 53 of 81 us (instruction issue); profiles/r4_ablations.md, DESIGN.md section 6", "kernel": names[2], "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_launch, "avg_launch_ms": dur_s * 1e3, "launches_per_step": P * G,
@@ -754,7 +754,7 @@ def run(job, args):
                                  "launches_per_step": r["halves"],
                                  "achieved": parse_bytes / (stage_ms[1] / 1e3) / 1e9,
                                  "serial_launch_ms": float(serial_ms[1]) / r["halves"], "traffic": ptraffic,
-                                 "bound": "serial symbol chains (VALU issue), not bandwidth"}},
+                                 "bound": "serial token chain of the heaviest lane of each wave (270 ns per trip alone, 326 beside k_recon), not bandwidth"}},
         "parity_gate": {"reference": "tests/golden/bench_gop12.u64 (unmodified reference decoder, tests/golden/make_bench_golden.py)",
                         "streams_checked": r["streams_checked"], "pictures_checked_per_stream": P,
                         "when": "every picture before the timed region; pictures P-2, P-1 again after it; chain hashes of all "
