@@ -64,7 +64,6 @@ constexpr int kReconMerge = EFX_RECON_MERGE;  // parse halves whose streams are 
 #define EFX_GROUP_STREAMS 1024
 #endif
 constexpr int kGroupStreams = EFX_GROUP_STREAMS;
-constexpr double kGroupMaxSliceBytes = 640;  // a call is split into parse halves only when its slices are shorter than this on average (efx_decode_range)
 constexpr int kTimingRing = 64;   // efx_decode calls whose stage times efx_get_timing can average
 constexpr int kSlots = EFX_SLOTS;         // parse -> recon hand-over buffer sets (one being reconstructed + two being parsed)
 constexpr int kUploads = 2;       // bitstream buffers: one being decoded, one being filled
@@ -109,10 +108,6 @@ struct efx_ctx {
         hipEvent_t last_read[kParseStreams] = {};       // newest parse half that reads this buffer
         hipEvent_t ev_demux[2] = {nullptr, nullptr};
         bool demux_timed = false;
-        uint32_t* h_hint = nullptr;      // pinned: {slices, streams} of the first parse half of this batch's first decode
-        hipEvent_t hint_ready = nullptr;
-        bool hint_recorded = false;
-        int halves = 0;                  // how its decodes run, once decided (0: not yet; 1 long slices, 2 short slices)
     } up[kUploads];
     int cur_up = -1;  // batch the next efx_decode reads
     hipStream_t copy_stream = nullptr;
@@ -168,7 +163,6 @@ struct efx_ctx {
     Group groups[kMaxGroups];  // reconstruction groups of the most recent efx_decode
     int n_groups = 0;
     hipEvent_t last_recon_done = nullptr;  // end of the most recently queued reconstruction group (k_parse's cap, efx_decode_range)
-    int last_halves = 0;       // mode of the most recent efx_decode (the default while an upload's slice count is on its way)
     int last_upload = 0;       // batch the most recent efx_decode read
     int last_n_streams = 0;    // ... its stream count and format, as they were when the decode was queued (a later upload may
     bool last_ts_input = false;  // have recycled the Upload record by the time the results are fetched)
@@ -180,7 +174,7 @@ struct efx_ctx {
     VideoTables* d_video[2] = {nullptr, nullptr};  // [0] PAL, [1] NTSC
     VideoLineTemplates* d_video_lines[2] = {nullptr, nullptr};
     SbcTables* d_sbc_tables = nullptr;
-    int parse_wg_cap = 0;  // k_parse workgroups resident per parse kernel when the batch's slices are short (0: no cap); EFX_PARSE_WG_CAP
+    int parse_wg_cap = 0;  // k_parse workgroups resident per parse kernel while reconstruction launches are queued (0: no cap); EFX_PARSE_WG_CAP
     uint32_t* d_sbc_flags = nullptr;  // per stream of an efx_sbc_decode call: 1 = decoded frame-parallel (k_sbc_check)
     size_t sbc_flags_cap = 0;
     uint64_t* d_hash = nullptr;
@@ -230,14 +224,10 @@ void park_stream_set(int device, const StreamSet& set)
     g_stream_pool.emplace_back(device, set);
 }
 
-// An efx_decode call may run as G groups of about kGroupStreams streams, one after the other: each group is a complete
-// parse half + reconstruction half with its own hand-over slot, so that the parse half of the next group (and of the
-// one after) runs beside the reconstruction of this one.  Streams are independent, so the result does not depend on
-// G; the granularity of the pipeline does.  With short slices (the 12-slice pictures of SURVEY 8d: 315 bytes per
-// slice, parse half 1.1 ms whatever the batch) two groups of 512 streams take 1.60 ms where one of 1024 takes 1.70;
-// with the 1.2 kB slices of ffmpeg's 5-slice pictures a parse half is 2.5 ms long however few streams it holds, and
-// halving the streams per parse half halves the throughput.  So the call is split only when the previous call's slices
-// were short: k_slice_scan's count comes back through a pinned word, read here without waiting for it.
+// An efx_decode call that finds the GPU idle runs as G groups of about kGroupStreams streams, one after the other: each
+// group is a complete parse half + reconstruction half with its own hand-over slot, so that the parse half of the next
+// group runs beside the reconstruction of this one -- the call pipelines inside itself.  Back-to-back calls pipeline
+// against each other and run as one group (efx_decode_range).  Streams are independent: results do not depend on G.
 int group_count(int n_streams)
 {
     int g = (n_streams + kGroupStreams / 2) / kGroupStreams;
@@ -401,10 +391,6 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         A(hipHostMalloc(reinterpret_cast<void**>(&u.h_es), ctx->es_cap, hipHostMallocDefault));
         A(hipHostMalloc(reinterpret_cast<void**>(&u.h_meta), meta_bytes(n), hipHostMallocDefault));
         A(hipEventCreateWithFlags(&u.uploaded, hipEventDisableTiming));
-        A(hipEventCreateWithFlags(&u.hint_ready, hipEventDisableTiming));
-        A(hipHostMalloc(reinterpret_cast<void**>(&u.h_hint), 2 * sizeof(uint32_t), hipHostMallocDefault));
-        if (u.h_hint)
-            u.h_hint[0] = u.h_hint[1] = 0;
         for (auto& ev : u.last_read)
             A(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         if (e == hipSuccess)
@@ -436,11 +422,11 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         return bail(EFX_ERR_DEVICE);
     }
     {
-        // parse workgroups resident per parse kernel when the slices are short: five for every eight compute units.
+        // parse workgroups resident per parse kernel beside reconstruction launches: five for every eight compute units.
         // Measured on 256 CUs, 1024 streams x GOP 12 (tools/exp/cap_sweep2.py, profiles/r4_schedule_sweep.md): groups of 512
         // streams without a cap 8.05-8.18 M frames/s, capped at 128: 8.15-8.54; groups of 1024 capped at 128 ... 192:
         // 8.57-9.06 (flat between 144 and 192 on one box, best at 176 on another); 96 and below: the parse kernel
-        // becomes the critical path.
+        // becomes the critical path.  5-slice pictures (4.4 x the tokens per slice): uncapped 7.21 M, 160: 7.55 M.
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess)
             ctx->parse_wg_cap = std::max(1, prop.multiProcessorCount * 5 / 8);
@@ -521,10 +507,6 @@ void efx_destroy(efx_ctx* ctx)
             (void)hipHostFree(u.h_es);
         if (u.h_meta)
             (void)hipHostFree(u.h_meta);
-        if (u.h_hint)
-            (void)hipHostFree(u.h_hint);
-        if (u.hint_ready)
-            (void)hipEventDestroy(u.hint_ready);
         hipEvent_t evs[] = {u.uploaded, u.ev_demux[0], u.ev_demux[1]};
         for (auto ev : evs)
             if (ev)
@@ -650,10 +632,6 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
             EFX_HIP(hipEventSynchronize(ev));
     }
     u.valid = false;
-    if (u.hint_recorded)
-        EFX_HIP(hipEventSynchronize(u.hint_ready));  // (the pinned word is about to describe another batch)
-    u.hint_recorded = false;
-    u.halves = 0;
     hipStream_t st = ctx->copy_stream;
     uint8_t* d_dst = is_ts ? ctx->d_ts : u.d_es;
     // small per-stream arrays, pinned: stream_off | perm | ts_len | pkt_base
@@ -858,36 +836,15 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
         return fail(ctx, EFX_ERR_STATE, "efx_decode: no streams uploaded");
     efx_ctx::Upload& u = ctx->up[ctx->cur_up];
     const int n_all = u.n_streams, P = ctx->cfg.max_pictures, D = ctx->cfg.ring_depth;
-    // How the call runs depends on the batch's slices.  SHORT slices (the 12-slice pictures of SURVEY 8d: 315 bytes each):
-    // the reconstruction launches are what the call waits for -- it runs as groups of kGroupStreams streams (a batch larger
-    // than that pipelines inside the call) and a parse half is kept to `parse_wg_cap` resident workgroups, which leaves the
-    // k_recon waves beside it their LDS.  LONG slices (ffmpeg's 5-slice pictures, 1.2 kB each): the parse half is the
-    // critical path -- one group, every workgroup it can use.  The first decode of an upload runs as the previous upload did
-    // (nothing is known about the new batch yet); it leaves the batch's slice count in a pinned word, and once that has
-    // arrived the mode is decided from it and stays.  Results do not depend on the mode.
-    int mode = 1;  // 1 long slices, 2 short slices
-    if (u.halves)
-        mode = u.halves;
-    else {
-        const efx_ctx::Upload& prev = ctx->up[(ctx->cur_up + kUploads - 1) % kUploads];
-        const efx_ctx::Upload* src = u.hint_recorded ? &u : (prev.hint_recorded ? &prev : nullptr);
-        // (never waited for: the call stays asynchronous.  While this upload's own count is still on its way the
-        // previous upload's decides)
-        if (src == &u && hipEventQuery(u.hint_ready) != hipSuccess)
-            src = prev.hint_recorded && hipEventQuery(prev.hint_ready) == hipSuccess ? &prev : nullptr;
-        else if (src && hipEventQuery(src->hint_ready) != hipSuccess)
-            src = nullptr;
-        (void)hipGetLastError();  // (hipErrorNotReady is not an error)
-        if (src) {
-            const uint32_t hint_slices = src->h_hint[0], hint_streams = src->h_hint[1];
-            if (hint_slices && hint_streams && (double)u.es_used * hint_streams / n_all / hint_slices < kGroupMaxSliceBytes)
-                mode = 2;
-            if (src == &u)
-                u.halves = mode;
-        } else if (ctx->last_halves > 0)
-            mode = ctx->last_halves;
-    }
-    const int G = mode == 2 ? group_count(n_all) : 1;
+    // Back-to-back calls pipeline against each other -- the parse half of call n + 1 (and n + 2) runs beside the
+    // reconstruction of call n -- and then ONE group per call is best whatever the batch (4096 streams, 12-slice pictures:
+    // 9.3 M frames/s as one group, 9.15 M as four; 5-slice pictures 7.85 / 7.57 M; profiles/r4_schedule_sweep.md): fewer,
+    // fatter reconstruction launches have fewer draining tails.  A call that finds the reconstruction stream idle (one call
+    // at a time) has nothing to pipeline against but itself: it runs as groups of kGroupStreams streams, the parse half of
+    // group g + 1 beside the reconstruction of group g.  Results do not depend on the split.
+    const bool idle_at_call = !(ctx->last_recon_done && hipEventQuery(ctx->last_recon_done) == hipErrorNotReady);
+    (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+    const int G = idle_at_call ? group_count(n_all) : 1;
     hipStream_t sr = ctx->stream;
     int timing_slot = -1;
     if (ctx->timing && !ctx->timing_ring.empty()) {
@@ -895,7 +852,6 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
         ctx->timing_groups[timing_slot] = (uint8_t)G;
         ctx->timing_leaders[timing_slot] = 0;
     }
-    ctx->last_halves = mode;
     ctx->last_upload = ctx->cur_up;
     ctx->last_n_streams = u.n_streams;
     ctx->last_ts_input = u.ts_input;
@@ -950,11 +906,6 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
                                slice_base, counters);
             hipLaunchKernelGGL(k_slice_emit, dim3((n * P * kMaxSlicesPerPicture + 255) / 256), dim3(256), 0, sp, sl.d_pics,
                                sl.d_slices_tmp, sl.d_pic_count, u.d_stream_off, slice_base, n, P, u.d_stream_perm + s0, descs, sl.d_status);
-            if (g == 0 && u.h_hint) {
-                EFX_HIP(hipMemcpyAsync(u.h_hint, counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, sp));
-                EFX_HIP(hipEventRecord(u.hint_ready, sp));
-                u.hint_recorded = true;
-            }
             if (te)
                 EFX_HIP(hipEventRecord(te->ev[1], sp));
             const int max_slices = n * P * kMaxSlicesPerPicture;
@@ -966,7 +917,7 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
             // may have the chip: 0.84 instead of 1.38 ms per 1024 streams x 12 pictures.
             const bool recon_busy = ctx->last_recon_done && hipEventQuery(ctx->last_recon_done) == hipErrorNotReady;
             (void)hipGetLastError();  // (hipErrorNotReady is not an error)
-            if (mode == 2 && ctx->parse_wg_cap > 0 && recon_busy)
+            if (ctx->parse_wg_cap > 0 && recon_busy)
                 parse_wgs = std::min(parse_wgs, ctx->parse_wg_cap);
             hipLaunchKernelGGL(k_parse, dim3(parse_wgs), dim3(64 * kParseWaves), 0, sp, u.d_es,
                                descs, counters, ctx->d_tm_tables, sl.d_mbrecs, sl.d_raw, sl.d_coefs, sl.d_status, P, sl.epoch);

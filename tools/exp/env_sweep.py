@@ -12,15 +12,17 @@ if not os.environ.get("CHILD"):
 import espflix_amd as efx
 from espflix_amd import gen
 flags=int(os.environ.get("FLAGS","0"))
-b = gen.Batch(0, 1024, 12, 12, flags)
-blobs = [b.es(k) for k in range(1024)]
-dec = efx.Decoder(max_streams=1024, max_pictures=12, ring_depth=2)
+NS=int(os.environ.get("STREAMS","1024"))
+b = gen.Batch(0, NS, 12, 12, flags)
+blobs = [b.es(k) for k in range(NS)]
+dec = efx.Decoder(max_streams=NS, max_pictures=12, ring_depth=2)
 dec.upload(blobs, efx.FORMAT_ES)
 dec.decode(); dec.decode(); dec.set_timing(True)
 for _ in range(10): dec.decode()
 t = dec.timing(); ser=(t.index_ms,t.parse_ms,t.recon_ms)
 dec.set_timing(True); dec.sync(); t0=time.perf_counter()
-for _ in range(200): dec.decode(sync=False)
-dec.sync(); dt=(time.perf_counter()-t0)/200
+NIT=max(20,200*1024//NS)
+for _ in range(NIT): dec.decode(sync=False)
+dec.sync(); dt=(time.perf_counter()-t0)/NIT
 t=dec.timing()
-print('[%s] serial index %.3f parse %.3f recon %.3f | pipelined parse %.3f recon %.3f step %.3f ms = %.2f M frames/s'%(os.environ["SPEC"],*ser,t.parse_ms,t.recon_ms,dt*1e3,12288/dt/1e6))
+print('[%s] serial index %.3f parse %.3f recon %.3f | pipelined parse %.3f recon %.3f step %.3f ms = %.2f M frames/s'%(os.environ["SPEC"],*ser,t.parse_ms,t.recon_ms,dt*1e3,12*NS/dt/1e6))

@@ -1,3 +1,3 @@
-L=$GRAFT_REPO_ROOT/espflix_amd
-EFX_LIB=$L/libefx_a.so python tools/exp/env_sweep.py "EFX_PARSE_WG_CAP=0" "EFX_PARSE_WG_CAP=96" "EFX_PARSE_WG_CAP=128" "EFX_PARSE_WG_CAP=144" "EFX_PARSE_WG_CAP=160" "EFX_PARSE_WG_CAP=176" "EFX_PARSE_WG_CAP=192" "EFX_PARSE_WG_CAP=224" "EFX_PARSE_WG_CAP=256" "EFX_PARSE_WG_CAP=160"
-EFX_LIB=$L/libefx_a.so python tools/exp/env_sweep.py "FLAGS=4" "FLAGS=4 EFX_PARSE_WG_CAP=160"
+python tools/exp/env_sweep.py "T=new"
+FLAGS=36 python tools/exp/env_sweep.py "T=new36"
+timeout 700 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
