@@ -130,8 +130,9 @@ int efx_erase_frames(efx_ctx* ctx);
  * s(i) = i + 1 once a picture has latched a PES PTS, else max(0, i - f) with f the first picture of
  * the call that does: the reference does not swap its two buffers before the first PTS.  Elementary-
  * stream input counts every picture as carrying one.  ring_depth 2 is the reference's pair.
- * Streams are independent; a large batch whose slices are short runs as several groups of streams one
- * after the other (finer pipeline, efx_timing::groups) -- the results do not depend on it. */
+ * Streams are independent; a large batch decoded while the GPU is otherwise idle runs as several groups of
+ * streams one after the other (the call pipelines inside itself, efx_timing::groups), back-to-back calls as one
+ * group each -- the results do not depend on it. */
 int efx_decode(efx_ctx* ctx);
 /* The same, starting at picture `first_picture` of every uploaded stream (earlier pictures are walked
  * for their header state only): a stream with more than max_pictures pictures (EFX_STREAM_TRUNCATED)
@@ -281,8 +282,9 @@ typedef struct efx_timing {
                           stage times above are sums over them */
     uint16_t parse_halves; /* parse halves (k_index ... k_parse over a range of streams) of the newest call: they run side
                               by side on the parse streams and feed the reconstruction groups */
-    uint16_t mixed;    /* 1: the averaged calls did not all run with the newest call's structure (the first decodes of an
-                          upload run as the previous upload did): per-launch figures derived from the means are off */
+    uint16_t mixed;    /* 1: the averaged calls did not all run with the newest call's structure (a call that found the GPU
+                          idle is split into groups, one queued behind another is not): per-launch figures derived from
+                          the means are off */
 } efx_timing;
 /* Enable HIP-event timing of the decode stages (events recorded on the kernels' own streams);
  * enabling (again) starts a new averaging window. */
