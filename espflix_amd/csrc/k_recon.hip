@@ -288,12 +288,15 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     // Instead the wave's entries are dealt out one per lane: entry i belongs to the last lane whose
     // exclusive prefix count is <= i (six-step search in the prefix array), is dequantised with that
     // lane's parameters and lands in that lane's block.
+    // inclusive prefix sum over the wave in the vector pipe: inside rows of 16 lanes by DPP row shifts, then the rows' totals
+    // by row broadcasts (six instructions; six ds_bpermute round trips before)
     uint32_t incl = (uint32_t)my_cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d, 64);
-        incl += lane >= d ? o : 0u;
-    }
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);  // row_shr:1
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);  // row_shr:2
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);  // row_shr:4
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false);  // row_shr:8
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1, 3
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2, 3
     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
     const uint32_t pre = incl - (uint32_t)my_cnt;  // entries before this block in the wave (<= 64 * 64)
     const uint32_t pre_flags = pre | (flags << 16);  // flags: bit0 intra, bits 2-6 quantiser_scale, bit7 custom matrices
