@@ -41,7 +41,9 @@ __global__ void k_composite(const uint8_t*, const VideoTables*, const VideoLineT
 __global__ void k_pdm(const int16_t*, int, int, int32_t*, uint16_t*);
 __global__ void k_sbc(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int,
                       const uint32_t*);
-__global__ void k_sbc_par(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int,
+__global__ void k_sbc_par_stereo(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int,
+                                 const uint32_t*);
+__global__ void k_sbc_par_mono(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int,
                           const uint32_t*);
 __global__ void k_sbc_check(const uint8_t*, size_t, int, int, uint32_t*);
 }  // namespace efx
@@ -1440,7 +1442,11 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
     if (n_frames > 0) {
         hipLaunchKernelGGL(k_sbc_check, dim3((n_frames + 255) / 256, n_streams), dim3(256), 0, ctx->stream, frames_device, stream_stride,
                            frame_bytes, n_frames, ctx->d_sbc_flags);
-        hipLaunchKernelGGL(k_sbc_par, dim3((n_frames + 7) / 8, n_streams), dim3(256), 0, ctx->stream, frames_device, stream_stride,
+        // (one instantiation per channel count: a workgroup whose stream is of the other kind leaves at once)
+        hipLaunchKernelGGL(k_sbc_par_mono, dim3((n_frames + 7) / 8, n_streams), dim3(256), 0, ctx->stream, frames_device, stream_stride,
+                           frame_bytes, n_frames, static_cast<SbcState*>(state_device), ctx->d_sbc_tables, pcm_device, pcm_stride,
+                           ret_device, pcm_count_device, flags, ctx->d_sbc_flags);
+        hipLaunchKernelGGL(k_sbc_par_stereo, dim3((n_frames + 7) / 8, n_streams), dim3(256), 0, ctx->stream, frames_device, stream_stride,
                            frame_bytes, n_frames, static_cast<SbcState*>(state_device), ctx->d_sbc_tables, pcm_device, pcm_stride,
                            ret_device, pcm_count_device, flags, ctx->d_sbc_flags);
     }

@@ -322,26 +322,34 @@ __global__ __launch_bounds__(256) void k_sbc_check(const uint8_t* __restrict__ f
         atomicAnd(&parallel[s], 0u);
 }
 
-// grid = (chunks of kSbcChunk frames, streams), block = 256.  Same arguments and results as k_sbc.
-__global__ __launch_bounds__(256) void k_sbc_par(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
-                                                 int n_frames, SbcState* __restrict__ states,
-                                                 const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
-                                                 size_t pcm_stride, uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count,
-                                                 int flags, const uint32_t* __restrict__ parallel)
+// grid = (chunks of kSbcChunk frames, streams), block = 256.  Same arguments and results as k_sbc.  One instantiation per
+// channel count (a mono stream needs half the LDS: twice the workgroups per CU); a workgroup whose stream is of the other
+// kind leaves at once.  The frame bytes in reach are copied into LDS with coalesced dword loads first: headers, scale
+// factors and the samples' bit fields are then LDS reads (the byte loads from global memory were 45 % of a workgroup's life).
+constexpr int kSbcStageDwords = 1536;  // 6 KB: eleven frames of up to 558 bytes (16 blocks x 2 channels x 8 subbands x 16 bits + 12 is 524)
+template <int C>
+__device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
+                                             int n_frames, SbcState* __restrict__ states,
+                                             const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
+                                             size_t pcm_stride, uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count,
+                                             int flags, const uint32_t* __restrict__ parallel)
 {
     const int s = blockIdx.y, tid = threadIdx.x;
     if (!parallel[s] || n_frames <= 0)
         return;
-    __shared__ SbcTables tb;
-    __shared__ int32_t sb[kSbcFrames][16][2][8];            // dequantised samples of the frames in reach
-    __shared__ int32_t rows[2][9 + kSbcChunk * 16][16];    // matrixing outputs: nine blocks of history + the chunk's
-    __shared__ uint8_t sh_scale[kSbcFrames][2][8], sh_bits[kSbcFrames][2][8];
-    __shared__ uint16_t sh_prefix[kSbcFrames][16], sh_per_block[kSbcFrames];
-
-    const uint8_t* base = frames + (size_t)s * stream_stride;
-    const uint32_t limit = (uint32_t)n_frames * (uint32_t)frame_bytes;
-    const uint32_t g0 = base[1];
+    const uint8_t* gbase = frames + (size_t)s * stream_stride;
+    const uint32_t g0 = gbase[1];
     const int blocks = 4 * (int)(((g0 >> 4) & 3) + 1), channels = ((g0 >> 2) & 3) ? 2 : 1, per_blk = channels * 8;
+    if (channels != C)
+        return;
+    __shared__ SbcTables tb;
+    __shared__ int32_t sb[kSbcFrames][16][C][8];            // dequantised samples of the frames in reach
+    __shared__ int32_t rows[C][9 + kSbcChunk * 16][16];    // matrixing outputs: nine blocks of history + the chunk's
+    __shared__ uint8_t sh_scale[kSbcFrames][C][8], sh_bits[kSbcFrames][C][8];
+    __shared__ uint16_t sh_prefix[kSbcFrames][C * 8], sh_per_block[kSbcFrames];
+    __shared__ uint32_t sh_in[kSbcStageDwords];
+
+    const uint32_t limit = (uint32_t)n_frames * (uint32_t)frame_bytes;
     const bool probe = (flags & 1) != 0;  // decode_audio()'s frame-size probe: frame 0 is decoded once more up front
     const int f0 = blockIdx.x * kSbcChunk, f1 = min(n_frames, f0 + kSbcChunk);
     // Virtual block timeline: block vb >= 0 is block vb % blocks of frame vb / blocks; with the probe, blocks
@@ -356,13 +364,38 @@ __global__ __launch_bounds__(256) void k_sbc_par(const uint8_t* __restrict__ fra
         for (int i = tid; i < (int)(sizeof(SbcTables) / 4); i += 256)
             dst[i] = src[i];
     }
+    // the bytes of frames max(fr_lo, 0) .. f1 - 1 (contiguous in the stream): whole aligned dwords, bytes beyond the stream's
+    // frames as zeros (be_bits); a chunk too fat for the stage is read from global memory as before
+    const uint32_t lo_byte = (uint32_t)max(fr_lo, 0) * (uint32_t)frame_bytes, hi_byte = min((uint32_t)f1 * (uint32_t)frame_bytes, limit);
+    const uint32_t mis = (uint32_t)((uintptr_t)(gbase + lo_byte) & 3), n_dw = (hi_byte - lo_byte + mis + 3) / 4;
+    const bool staged = n_dw <= (uint32_t)kSbcStageDwords;
+    if (staged) {
+        const uint8_t* a0 = gbase + lo_byte - mis;  // (>= frames: the buffer starts dword-aligned)
+        for (uint32_t i = tid; i < n_dw; i += 256) {
+            uint32_t w;
+            if (i * 4 + 4 <= hi_byte - lo_byte + mis)
+                w = *reinterpret_cast<const uint32_t*>(a0 + i * 4);
+            else {  // the last dword: never past the stream's last frame byte
+                w = 0;
+                for (uint32_t b = 0; b < 4; b++)
+                    if (i * 4 + b < hi_byte - lo_byte + mis)
+                        w |= (uint32_t)a0[i * 4 + b] << (8 * b);
+            }
+            sh_in[i] = w;
+        }
+    }
+    // where frame f (max(fr_lo, 0) <= f < f1) starts: in the stage when the chunk fits it (flat loads serve both)
+    auto frame_at = [&](int f) -> const uint8_t* {
+        return staged ? reinterpret_cast<const uint8_t*>(sh_in) + ((uint32_t)f * (uint32_t)frame_bytes - lo_byte + mis)
+                      : gbase + (size_t)f * frame_bytes;
+    };
     __syncthreads();
     // ---- headers, scale factors, bit allocation: one thread per (frame, channel) ---------------------------------------
     if (tid < n_fr * 2) {
-        const int k = tid >> 1, c = tid & 1, f = max(fr_lo + k, 0);
-        const uint8_t* d = base + (size_t)f * frame_bytes;
+        const int k = tid >> 1, c = tid & (C - 1), f = max(fr_lo + k, 0);
+        const uint8_t* d = frame_at(f);
         const uint32_t avail = limit - (uint32_t)f * (uint32_t)frame_bytes;
-        if (c < channels) {
+        if ((tid & 1) < C) {
             uint8_t sc[8];
             for (int j = 0; j < 8; j++) {
                 const uint32_t i = 4 + (uint32_t)((c * 8 + j) >> 1);
@@ -392,7 +425,7 @@ __global__ __launch_bounds__(256) void k_sbc_par(const uint8_t* __restrict__ fra
     for (int i = tid; i < n_fr * blocks * per_blk; i += 256) {
         const int k = i / (blocks * per_blk), r0 = i - k * blocks * per_blk, blk = r0 / per_blk, r = r0 - blk * per_blk;
         const int f = max(fr_lo + k, 0);
-        const uint8_t* d = base + (size_t)f * frame_bytes;
+        const uint8_t* d = frame_at(f);
         const uint32_t avail = limit - (uint32_t)f * (uint32_t)frame_bytes;
         const int bits = sh_bits[k][r >> 3][r & 7];
         int32_t sample = 0;
@@ -468,7 +501,7 @@ __global__ __launch_bounds__(256) void k_sbc_par(const uint8_t* __restrict__ fra
             so->hist[c][r >> 4][r & 15] = rows[c][n_t - 9 + (r >> 4)][r & 15];
         }
         if (tid == 0) {
-            const uint8_t* d = base + (size_t)(n_frames - 1) * frame_bytes;
+            const uint8_t* d = frame_at(n_frames - 1);
             so->frequency = (d[1] >> 6) & 3;
             so->blocks = (uint8_t)blocks;
             so->channels = (uint8_t)channels;
@@ -480,6 +513,24 @@ __global__ __launch_bounds__(256) void k_sbc_par(const uint8_t* __restrict__ fra
                 pcm_count[s] = (uint32_t)n_frames * (uint32_t)frame_samples;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_sbc_par_mono(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
+                                                      int n_frames, SbcState* __restrict__ states,
+                                                      const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
+                                                      size_t pcm_stride, uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count,
+                                                      int flags, const uint32_t* __restrict__ parallel)
+{
+    sbc_par_body<1>(frames, stream_stride, frame_bytes, n_frames, states, tables, pcm, pcm_stride, ret, pcm_count, flags, parallel);
+}
+__global__ __launch_bounds__(256) void k_sbc_par_stereo(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
+                                                        int n_frames, SbcState* __restrict__ states,
+                                                        const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
+                                                        size_t pcm_stride, uint32_t* __restrict__ ret,
+                                                        uint32_t* __restrict__ pcm_count, int flags,
+                                                        const uint32_t* __restrict__ parallel)
+{
+    sbc_par_body<2>(frames, stream_stride, frame_bytes, n_frames, states, tables, pcm, pcm_stride, ret, pcm_count, flags, parallel);
 }
 
 }  // namespace efx
