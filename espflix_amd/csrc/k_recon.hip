@@ -453,6 +453,13 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     // exactly, so clearing X's low byte makes the final (x + 128) >> 8 deliver X >> 8, the shortcut.
     int v[64];
     const int half = 128;
+    if (total == 0) {
+        // (wave-uniform) no block of this wave holds a coefficient -- skipped macroblocks, static background: what the
+        // butterflies make of 64 zeros and the rounding constant is the rounding constant
+#pragma unroll
+        for (int i = 0; i < 64; i++)
+            v[i] = 128;
+    } else {
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         // column c: eight int16 from the private block, scaled by immediates, one butterfly
@@ -478,6 +485,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         idct8(v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7], half);
         asm volatile("" : "+v"(v[r * 8]), "+v"(v[r * 8 + 1]), "+v"(v[r * 8 + 2]), "+v"(v[r * 8 + 3]), "+v"(v[r * 8 + 4]),
                      "+v"(v[r * 8 + 5]), "+v"(v[r * 8 + 6]), "+v"(v[r * 8 + 7]));
+    }
     }
 
     // destination rows of the block (block(), player.cpp:1124-1131)

@@ -1,5 +1,3 @@
 L=$GRAFT_REPO_ROOT/espflix_amd
-for t in a b a b; do EFX_LIB=$L/libefx_$t.so python tools/exp/env_sweep.py "T=$t"; done
-for t in a b; do FLAGS=36 EFX_LIB=$L/libefx_$t.so python tools/exp/env_sweep.py "wide=$t"; done
-EFX_LIB=$L/libefx_pb.so timeout 200 python tools/dbg/probe_waves.py pipelined 2>&1 | grep -A6 "^k_parse"
-EFX_LIB=$L/libefx_b.so timeout 300 python -m pytest tests/test_gpu_decode.py tests/test_gpu_edge.py -m gpu -x -q 2>&1 | tail -2
+for t in a z a z; do EFX_LIB=$L/libefx_$t.so python bench.py --steps 20 --no-cpu-baseline --no-fixed-batch --no-video-out --sustained-steps 0 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.readline()); o=d['other_workloads']; print('[$t]', round(d['value']), {k:round(v['frames_per_s']) for k,v in o.items()})"; done
