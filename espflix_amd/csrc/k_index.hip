@@ -358,6 +358,11 @@ __global__ __launch_bounds__(64 * kIndexWaves) void k_index(
                     pi->seq_off = b3 ? u_off[b3 - 1] : 0u;
                     pi->start_off = u_off[i];
                 }
+            } else if (srow && !pics_before) {
+                // a slice in front of the first picture header: the reference parses it all the same -- with the P books and
+                // the constructor's state (player.cpp:354-369,1251) -- into its current frame, and usually loses its way in
+                // it; here it is dropped.  Not the reference's output any more: flagged like a derailed marker hunt.
+                my_st |= EFX_STREAM_SERIAL_HUNT;
             } else if (srow && pics_before && open >= 0) {
                 if (seg < (uint32_t)kMaxSlicesPerPicture) {
                     const uint32_t next = (i + 1 < n_units) ? u_off[i + 1] - 4 : len;

@@ -53,9 +53,17 @@ typedef enum efx_status {
                                          take 8 as the marker) would misread: non-zero bits after a header it ignores (picture \
                                          types other than I / P, player.cpp:710-717), a user_data / extension payload that is not \
                                          made of harmless 4-byte groups (player.cpp:1328-1330), bytes ahead of the first start \
-                                         code.  The reference then acts on phantom markers; this decoder indexes byte-aligned \
-                                         start codes, so its output for the stream is NOT the reference's */
-#define EFX_STREAM_SLICE_ORDER 128u   /* a picture's slice start codes do not rise strictly in bitstream order (a row coded twice,                                          rows out of raster order).  Every slice is parsed by its own lane and stops where any other                                          slice of the picture starts; of slices with the same code only the last is parsed.  The                                          reference, one serial decoder, lets whatever comes LATER in the bitstream overwrite: the                                          same frames when every such slice is complete, not when one of them is also damaged or                                          short -- the parity claim does not cover a stream with this bit */
+                                         code; also a slice start code ahead of the first picture header (the reference parses \
+                                         it with the P books and the constructor's state; dropped here).  The reference then \
+                                         acts on phantom markers; this decoder indexes byte-aligned start codes, so its output \
+                                         for the stream is NOT the reference's */
+#define EFX_STREAM_SLICE_ORDER 128u   /* a picture's slice start codes do not rise strictly in bitstream order (a row coded \
+                                         twice, rows out of raster order).  Every slice is parsed by its own lane and stops \
+                                         where any other slice of the picture starts; of slices with the same code only the \
+                                         last is parsed.  The reference, one serial decoder, lets whatever comes LATER in the \
+                                         bitstream overwrite: the same frames when every such slice is complete, not when one \
+                                         of them is also damaged or short -- the parity claim does not cover a stream with \
+                                         this bit */
 
 typedef enum efx_format {
     EFX_FORMAT_ES = 0, /* raw ISO 11172-2 video elementary stream */

@@ -321,3 +321,59 @@ def test_slices_out_of_raster_order_are_flagged(efx):
         assert bool(st & efx.STREAM_SLICE_ORDER) == flagged and (st & ~efx.STREAM_SLICE_ORDER) == 0, (name, st)
     for s2 in (swapped, twice):
         assert [int(x) for x in oracle.decode(s2, 0, True)[1]] == want
+
+
+def test_header_state_rules_at_their_edges(efx):
+    """k_index applies MpegDecoder::marker()'s sequential rules to the whole unit list at once (ballot scans); the corners
+    of those rules, each against the oracle: a sequence_end in the middle (the reference pauses there, player.cpp:1324-1327:
+    nothing behind it is decoded), slices in front of the first picture header (the reference parses them with the P books and
+    derails: dropped here and the stream flagged EFX_STREAM_SERIAL_HUNT), a sequence
+    header of the wrong size after two good pictures (what was decoded stays, nothing after it is), a second sequence
+    header + GOP in the middle (state carried on)."""
+    from espflix_amd import gen
+    es = gen.Batch(5, 1, 6, 12, 0).es(0)
+    raw = es.tobytes()
+    units = _units(es)
+    pics = [i for i, (c, _, _) in enumerate(units) if c == 0x00]
+    assert len(pics) == 6
+    cut = units[pics[3]][1]                               # byte offset of the fourth picture's start code
+    seq_hdr = raw[units[0][1]:units[1][1]]                # the sequence header unit
+    ended = np.frombuffer(raw[:cut] + b"\x00\x00\x01\xB7" + raw[cut:], dtype=np.uint8)
+    first_slice = units[pics[0] + 1]
+    orphan = np.frombuffer(raw[:units[pics[0]][1]] + raw[first_slice[1]:first_slice[2]] + raw[units[pics[0]][1]:], dtype=np.uint8)
+    bad = bytearray(seq_hdr)
+    bad[4] = 0x14                                          # horizontal_size 320
+    late_bad = np.frombuffer(raw[:units[pics[2]][1]] + bytes(bad) + raw[units[pics[2]][1]:], dtype=np.uint8)
+    reseq = np.frombuffer(raw[:cut] + seq_hdr + raw[cut:], dtype=np.uint8)
+    streams = [es, ended, orphan, late_bad, reseq]
+    res = run(efx, streams, 8)
+    for (n, st, h), s, name in zip(res, streams, ("plain", "sequence_end", "orphan slice", "late bad size", "second sequence header")):
+        on, oh, _, _ = oracle.decode(s, 0, True)
+        if name == "late bad size":
+            # the reference goes on decoding slices into a frame of the wrong geometry (undefined); here and in the oracle the
+            # stream is dead from that header on: the pictures before it are the reference's
+            assert st & efx.STREAM_BAD_SIZE and h[:2] == [int(x) for x in oh[:2]], name
+            continue
+        if name == "orphan slice":
+            assert st == efx.STREAM_SERIAL_HUNT and n == 6 and h == res[0][2], (name, st, n)
+            assert on != 6  # (the flag is not cosmetic: the reference, one serial bit reader, ends up elsewhere)
+            continue
+        assert n == on and h == [int(x) for x in oh], (name, n, on)
+        assert st == 0, (name, st)
+    assert res[1][0] == 3 and res[2][0] == 6 and res[4][0] == 6
+
+
+def test_more_slices_than_slots_in_a_picture(efx):
+    """A picture keeps kMaxSlicesPerPicture = 16 slice start codes; a seventeenth (here: rows coded again and again) is
+    dropped and the stream flagged EFX_STREAM_TRUNCATED -- the first sixteen decode as ever."""
+    from espflix_amd import gen
+    es = gen.Batch(6, 1, 2, 12, 0).es(0)
+    raw = es.tobytes()
+    units = _units(es)
+    pic = [i for i, (c, _, _) in enumerate(units) if c == 0x00][1]
+    sl = [i for i in range(pic + 1, len(units)) if 1 <= units[i][0] <= 0xAF][:12]
+    last = raw[units[sl[-1]][1]:units[sl[-1]][2]]
+    many = np.frombuffer(raw[:units[sl[-1]][2]] + last * 6 + raw[units[sl[-1]][2]:], dtype=np.uint8)   # 18 slices
+    (n, st, h), = run(efx, [many], 2)
+    assert n == 2 and (st & efx.STREAM_TRUNCATED)
+    assert h == [int(x) for x in oracle.decode(es, 0, True)[1]]   # (the repeated row decodes to the same pixels)
