@@ -345,9 +345,12 @@ def test_header_state_rules_at_their_edges(efx):
     bad[4] = 0x14                                          # horizontal_size 320
     late_bad = np.frombuffer(raw[:units[pics[2]][1]] + bytes(bad) + raw[units[pics[2]][1]:], dtype=np.uint8)
     reseq = np.frombuffer(raw[:cut] + seq_hdr + raw[cut:], dtype=np.uint8)
-    streams = [es, ended, orphan, late_bad, reseq]
+    # the I picture cut out: the first picture is a P picture predicted from the (zeroed) frame store
+    p_first = np.frombuffer(raw[:units[pics[0]][1]] + raw[units[pics[1]][1]:], dtype=np.uint8)
+    streams = [es, ended, orphan, late_bad, reseq, p_first]
     res = run(efx, streams, 8)
-    for (n, st, h), s, name in zip(res, streams, ("plain", "sequence_end", "orphan slice", "late bad size", "second sequence header")):
+    for (n, st, h), s, name in zip(res, streams, ("plain", "sequence_end", "orphan slice", "late bad size", "second sequence header",
+                                                  "P picture first")):
         on, oh, _, _ = oracle.decode(s, 0, True)
         if name == "late bad size":
             # the reference goes on decoding slices into a frame of the wrong geometry (undefined); here and in the oracle the
@@ -360,7 +363,7 @@ def test_header_state_rules_at_their_edges(efx):
             continue
         assert n == on and h == [int(x) for x in oh], (name, n, on)
         assert st == 0, (name, st)
-    assert res[1][0] == 3 and res[2][0] == 6 and res[4][0] == 6
+    assert res[1][0] == 3 and res[2][0] == 6 and res[4][0] == 6 and res[5][0] == 5
 
 
 def test_more_slices_than_slots_in_a_picture(efx):
