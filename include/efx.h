@@ -76,7 +76,10 @@ typedef struct efx_config {
     int max_streams;         /* batch capacity */
     int max_pictures;        /* pictures per stream per efx_decode() call */
     int ring_depth;          /* frames kept per stream: 2 = the reference's double buffer
-                                (MpegDecoder::_fb, src/player.h:37-40); max_pictures+1 keeps all */
+                                (MpegDecoder::_fb, src/player.h:37-40); max_pictures+1 keeps all.  A macroblock no slice of
+                                its picture covers (a slice missing from the stream) keeps what its ring slot held: with 2
+                                that is the picture two back, as in the reference; with a deeper ring something older --
+                                pictures with missing slices match the reference only at ring_depth 2 */
     size_t max_stream_bytes; /* total ES bytes per upload (0 = 16 KiB x pictures x streams) */
     void* hip_stream;        /* hipStream_t to run on, or NULL for a private stream */
 } efx_config;

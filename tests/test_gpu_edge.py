@@ -380,3 +380,57 @@ def test_more_slices_than_slots_in_a_picture(efx):
     (n, st, h), = run(efx, [many], 2)
     assert n == 2 and (st & efx.STREAM_TRUNCATED)
     assert h == [int(x) for x in oracle.decode(es, 0, True)[1]]   # (the repeated row decodes to the same pixels)
+
+
+def test_structural_mutations_are_exact_or_flagged(efx):
+    """96 streams, each with one structural mutation of its start-code units -- a unit deleted, duplicated, two units
+    swapped, the stream cut at or inside a unit, a sequence_end inserted, a run of units deleted -- over four generator
+    flavours, decoded with the reference's two-buffer ring: a stream whose status stays 0 must show the reference's last two
+    pictures exactly (uncovered macroblocks keep the picture two back, missing pictures are simply absent ...); everything else
+    must carry a status bit."""
+    import re
+    from espflix_amd import gen
+    rng = np.random.default_rng(11)
+    streams, what = [], []
+    for k in range(96):
+        fl = [0, 4, 128, 256][k % 4]
+        raw = gen.Batch(100 + k, 1, 5, 12, fl).es(0).tobytes()
+        at = [m.start() for m in re.finditer(b"\x00\x00\x01", raw)]
+        parts = [raw[p:(at[i + 1] if i + 1 < len(at) else len(raw))] for i, p in enumerate(at)]
+        codes = [raw[p + 3] for p in at]
+        op, i = int(rng.integers(0, 7)), int(rng.integers(1, len(parts) - 1))
+        if op == 0:
+            del parts[i]
+        elif op == 1:
+            parts.insert(i, parts[i])
+        elif op == 2:
+            j = int(rng.integers(1, len(parts) - 1))
+            parts[i], parts[j] = parts[j], parts[i]
+        elif op == 3:
+            parts = parts[:i] + [parts[i][:max(5, len(parts[i]) // 2)]]
+        elif op == 4:
+            parts.insert(i, b"\x00\x00\x01\xB7")
+        elif op == 5:
+            parts = parts[:i]
+        else:
+            del parts[i:i + int(rng.integers(2, 6))]
+        streams.append(np.frombuffer(raw[:at[0]] + b"".join(parts), dtype=np.uint8))
+        what.append(f"flavour {fl} op {op} at unit {codes[i]:02x}")
+    dec = efx.Decoder(len(streams), 8, 2, max_stream_bytes=sum(len(s) for s in streams) + 8192)
+    dec.upload(streams, efx.FORMAT_ES)
+    dec.decode()
+    h = dec.frame_hashes()
+    clean = 0
+    for i, s in enumerate(streams):
+        n, st = dec.picture_count(i), dec.stream_status(i)
+        if st:
+            continue
+        clean += 1
+        on, oh, _, _ = oracle.decode(s, 0, True)
+        if n == 0:
+            assert on <= 1, what[i]   # (no picture at all: the reference's final flush_picture pushes one blank frame)
+            continue
+        got = [int(h[i, dec.picture_slot(p)]) for p in range(max(0, n - 2), n)]
+        assert n == on and got == [int(x) for x in oh][max(0, on - 2):], (what[i], n, on)
+    dec.close()
+    assert clean >= 48   # (most mutations leave a stream the reference decodes without complaint)
