@@ -267,8 +267,14 @@ __device__ __forceinline__ void parse_group(uint32_t w, const uint8_t* __restric
     fx.rec_flags = ((d.pic_code_flags >> 22) & 1) ? 0x80u : 0u;  // loaded quantiser matrices: recorded per macroblock for k_recon
     fx.epoch = (uint32_t)epoch;
     uint32_t n_mbs = 0, n_coefs = 0;
-    const uint32_t st = tm_finish(L, fx, tok_base, [&](uint32_t k) { return raw[k]; }, coefs, reinterpret_cast<TmU4*>(mbrecs + rec0),
-                                  &n_mbs, &n_coefs);
+    uint32_t st = tm_finish(L, fx, tok_base, [&](uint32_t k) { return raw[k]; }, coefs, reinterpret_cast<TmU4*>(mbrecs + rec0),
+                            &n_mbs, &n_coefs);
+    // A slice ends inside its unit: the 23 zero bits that close it (slice_done(), player.cpp:1238-1249) reach at most up to the
+    // '1' of the next start code.  A lane that consumed more has parsed a start code as slice data -- a damaged slice that
+    // stayed syntactically valid; the reference, one serial bit reader, runs on from there and never sees the units it
+    // swallows: not its output any more.
+    if (br.pos - (d.es_off & 15) * 8 > d.es_len * 8 + kTmEndBits)
+        st |= EFX_STREAM_BAD_VLC;
     EFX_PROBE_MAX(4, wall_clock64());
     if (st)
         atomicOr(&status[d.stream], st);

@@ -89,6 +89,7 @@ constexpr uint32_t tm_word(int base, int peek) { return ((uint32_t)base * 8u) <<
 constexpr uint32_t kTmTypeIBit = 1u << 28;
 static_assert(((kTbTypeP * 8) & 4096) == 0 && kTbTypeI * 8 == kTbTypeP * 8 + 4096, "TYPE_I = TYPE_P + 4096 bytes");
 constexpr uint32_t kWMbaA1 = tm_word(kTbMbaA1, 8), kWPlan0 = tm_word(kTbDcY1, 8), kWDct = tm_word(kTbDct, 8);
+constexpr uint32_t kTmEndBits = 23;  // zero bits that end a slice (slice_done(), player.cpp:1238-1249)
 // why a lane stopped
 enum : uint32_t {
     kDeadEnd = 0,       // the 23 zero bits that end a slice

@@ -245,7 +245,9 @@ int main(int argc, char** argv)
         if (getenv("EFX_HARNESS_TRIPS"))
             printf("slice pic=%d code=%d type=%d trips=%ld mbs=%u bytes=%u\n", se.a, code, se.c & 15, trips - trips0, L.nmb, len);
         uint32_t nm = 0, nc = 0;
-        const uint32_t st = tm_finish(L, fx, tok_base, [&](uint32_t k) { return raw[k]; }, coefs.data(), reinterpret_cast<TmU4*>(recs.data()), &nm, &nc);
+        uint32_t st = tm_finish(L, fx, tok_base, [&](uint32_t k) { return raw[k]; }, coefs.data(), reinterpret_cast<TmU4*>(recs.data()), &nm, &nc);
+        if (br.pos - units[u].off * 8 > len * 8 + kTmEndBits)  // (k_parse: the slice's codes ran through the next start code)
+            st |= EFX_STREAM_BAD_VLC;
 
         if (const char* dump = getenv("EFX_HARNESS_DUMP"))
             if ((uint32_t)atol(dump) == units[u].off) {
