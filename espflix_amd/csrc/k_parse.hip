@@ -275,6 +275,23 @@ __device__ __forceinline__ void parse_group(uint32_t w, const uint8_t* __restric
     // swallows: not its output any more.
     if (br.pos - (d.es_off & 15) * 8 > d.es_len * 8 + kTmEndBits)
         st |= EFX_STREAM_BAD_VLC;
+    // And after a slice that ended with its 23 zero bits the reference hunts for the next marker bit by bit (run(),
+    // player.cpp:1360-1363: skip zero bits, discard 24, take 8): it arrives at the next start code only if everything the
+    // slice left unread in its unit is zero.  A damaged slice that met 23 zeros early leaves junk there, the reference takes
+    // a phantom marker out of it: flagged like every other derailed hunt.
+    if (tm_why(L.st) == kDeadEnd) {
+        const uint8_t* unit = es + d.es_off - (d.es_off & 15);  // (br.pos counts from here)
+        const uint32_t end = (d.es_off & 15) + d.es_len;
+        uint32_t at = br.pos >> 3;
+        bool junk = false;
+        if (at < end) {
+            junk = (unit[at] & (0xFFu >> (br.pos & 7))) != 0;
+            for (at++; at < end && !junk; at++)
+                junk = unit[at] != 0;
+        }
+        if (junk)
+            st |= EFX_STREAM_SERIAL_HUNT;
+    }
     EFX_PROBE_MAX(4, wall_clock64());
     if (st)
         atomicOr(&status[d.stream], st);

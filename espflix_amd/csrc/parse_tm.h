@@ -381,9 +381,11 @@ EFX_HD uint32_t tm_finish(const TmLane& L, const TmFix& fx, uint32_t tok_base, R
             }
             mb_addr++;
         }
-        if (mb_addr >= fx.mb_limit) {  // past the picture, or into the macroblocks of the next slice
-            if (fx.mb_limit == kMbCount)
-                status |= EFX_STREAM_MB_OVERRUN;
+        if (mb_addr >= fx.mb_limit) {
+            // past the picture, or into the macroblocks of the next slice: the lane stops here; the reference goes on -- it
+            // may end before the next start code (then the later slice overwrites what it wrote: the same frames) or run
+            // through it: flagged either way
+            status |= EFX_STREAM_MB_OVERRUN;
             stopped = true;
             break;
         }
@@ -475,8 +477,8 @@ EFX_HD uint32_t tm_finish(const TmLane& L, const TmFix& fx, uint32_t tok_base, R
         // player.cpp:1238-1249) met anywhere but where a macroblock would start (after stuffing)
         if (why == kDeadBadMba || (why == kDeadEnd && (((uint32_t)L.hacc >> kHaccInc) & 0x7FFFF) != 0))
             status |= EFX_STREAM_BAD_VLC;
-        if ((why == kDeadLimit || (why == kDeadBadHeader && !partial)) && fx.mb_limit == kMbCount)
-            status |= EFX_STREAM_MB_OVERRUN;  // a macroblock beyond the last one
+        if (why == kDeadLimit || (why == kDeadBadHeader && !partial))
+            status |= EFX_STREAM_MB_OVERRUN;  // a macroblock beyond the last one the slice may hold
     }
     *n_mbs_out = n_mbs;
     *n_coefs_out = n_coefs;

@@ -47,7 +47,7 @@ typedef enum efx_status {
 #define EFX_STREAM_TRUNCATED 2u       /* more pictures than max_pictures: the rest was ignored */
 #define EFX_STREAM_TOO_MANY_UNITS 4u  /* start-code index overflow */
 #define EFX_STREAM_BAD_VLC 8u         /* an invalid code ended a slice early, or a slice's codes ran through the next start code */
-#define EFX_STREAM_MB_OVERRUN 16u     /* a slice ran past the last macroblock row */
+#define EFX_STREAM_MB_OVERRUN 16u     /* a slice ran past the last macroblock row, or into the macroblocks of the next slice */
 #define EFX_STREAM_COEF_OVERRUN 32u   /* a block ran past 64 coefficients (block dropped) */
 #define EFX_STREAM_SERIAL_HUNT 64u    /* bits the reference's marker hunt (player.cpp:1360-1363: skip zero bits, DISCARD 24 bits, \
                                          take 8 as the marker) would misread: non-zero bits after a header it ignores (picture \

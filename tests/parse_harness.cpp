@@ -248,6 +248,18 @@ int main(int argc, char** argv)
         uint32_t st = tm_finish(L, fx, tok_base, [&](uint32_t k) { return raw[k]; }, coefs.data(), reinterpret_cast<TmU4*>(recs.data()), &nm, &nc);
         if (br.pos - units[u].off * 8 > len * 8 + kTmEndBits)  // (k_parse: the slice's codes ran through the next start code)
             st |= EFX_STREAM_BAD_VLC;
+        if (tm_why(L.st) == kDeadEnd) {  // (k_parse: junk between the end of the slice and the next start code)
+            const uint32_t end = units[u].off + len;
+            uint32_t at = br.pos >> 3;
+            bool junk = false;
+            if (at < end) {
+                junk = (es[at] & (0xFFu >> (br.pos & 7))) != 0;
+                for (at++; at < end && !junk; at++)
+                    junk = es[at] != 0;
+            }
+            if (junk)
+                st |= EFX_STREAM_SERIAL_HUNT;
+        }
 
         if (const char* dump = getenv("EFX_HARNESS_DUMP"))
             if ((uint32_t)atol(dump) == units[u].off) {
