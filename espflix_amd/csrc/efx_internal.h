@@ -3,13 +3,14 @@
 // Pipeline of one efx_decode():
 //   k_demux        (TS input, at upload) one workgroup per stream: 188-byte packets -> ES + PES PTS list
 //                                                                            (player.cpp:294-307,381-493)
-//   k_index        one wave per stream: start-code scan + header parse      (player.cpp:1355-1367,646-730)
+//   k_index        one workgroup per stream: start-code scan + header parse + the sequential state rules as scans
+//                                                                            (player.cpp:1355-1367,646-730)
 //   k_slice_scan   prefix sum of slice counts in picture-major order
 //   k_slice_emit   dense slice descriptors
-//   k_parse        one lane per slice: VLC parse + dequant -> macroblock records + coefficient list
-//                                                                            (player.cpp:1238-1316,999-1122,891-920)
-//   k_recon        one lane per 8x8 block, one launch per picture index: IDCT + half-pel
-//                  motion compensation + clamp + strip-layout store          (player.cpp:922-996,732-889,1151-1236)
+//   k_parse        one lane per slice, a token machine (parse_tm.h): VLC parse -> macroblock records + stream words
+//                                                                            (player.cpp:1238-1316,999-1107,891-920)
+//   k_recon        one lane per 8x8 block, one launch per picture index: dequantisation + IDCT + half-pel
+//                  motion compensation + clamp + strip-layout store          (player.cpp:1110-1121,922-996,732-889,1151-1236)
 #pragma once
 #include <cstdint>
 
@@ -90,22 +91,14 @@ struct MbRec {
 };
 static_assert(sizeof(MbRec) == 16, "MbRec must be 16 bytes");
 
-// coefficient entry: signed level << 6 | scan position (intra DC: DC value << 6); k_recon
-// dequantises and pre-multiplies (the reference's b[zz] = v * scale_dct_q[zz], player.cpp:1110-1121)
+// coefficient entry = the parser's stream word: raw code bits << 16 | table value << 6 | scan position, level by
+// tm_level() (parse_tm.h); an intra block's first entry: DC value << 6.  k_recon dequantises and pre-multiplies (the
+// reference's b[zz] = v * scale_dct_q[zz], player.cpp:1110-1121)
 
-// flat VLC look-up tables (built on the host from mpeg1_codebook.h, staged in LDS by k_parse)
+// scan / quantiser table of k_index and k_recon (the VLC tables of the slice parser are parse_tm.h's TmTables)
 struct ParseTables {
-    uint16_t dct_hi[256];    // index: top 8 bits of a 16-bit peek (codes of <= 8 bits, escape)
-    uint16_t dct_lo[1024];   // index: low 10 bits of a 16-bit peek whose top 6 bits are 0
-    uint16_t mba[2048];      // index: 11-bit peek -> len | value << 4
-    uint16_t motion[2048];   // index: 11-bit peek -> len | (code + 16) << 4
-    uint16_t cbp[512];       // index: 9-bit peek  -> len | value << 4
-    uint8_t type_p[64];      // index: 6-bit peek  -> len | value << 3
     uint32_t scan[64];       // scan position n -> zz | premul << 8 | default intra q << 16 | 16 << 24
 };
-// dct entry: bits consumed (5 bits: code + sign; 2 for end_of_block; 20 for an escape with an 8-bit
-// level) | run << 5 (5 bits) | level << 10 (6 bits); level 0 = escape, level 63 = end_of_block;
-// level 63 with 0 bits = invalid code
 
 struct DecodeCounters {
     uint32_t total_slices;

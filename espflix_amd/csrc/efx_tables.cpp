@@ -1,8 +1,9 @@
 // efx_tables.cpp -- host-side construction of the look-up tables the kernels use.
 //
-//  * ParseTables: flat VLC decode tables expanded from the ISO 11172-2 code books in
-//    mpeg1_codebook.h (the reference walks bit-serial tree tables instead, player.cpp:516-530,
-//    and a prefix-class decoder for DCT coefficients, player.cpp:548-644).
+//  * ParseTables: the zig-zag / pre-multiplier / default-matrix table of k_index and k_recon.
+//  * TmTables (build_tm_tables, below): the slice parser's token-machine tables, expanded from the ISO 11172-2 code books
+//    in mpeg1_codebook.h (the reference walks bit-serial tree tables instead, player.cpp:516-530, and a prefix-class
+//    decoder for DCT coefficients, player.cpp:548-644).
 //  * VideoTables: composite-video geometry, sync/burst levels and the chroma-phase LUT, derived
 //    with the same float/double arithmetic the reference uses at init time
 //    (video_init/pal_init/usec, video.cpp:554-630; LUT derivation gen_palettes,
@@ -16,55 +17,9 @@
 
 namespace efx {
 
-namespace {
-
-template <typename T, int N, typename F>
-void expand(T (&table)[N], int index_bits, int code, int len, F make_entry)
-{
-    // every index whose top `len` bits equal `code` maps to this code word
-    int free_bits = index_bits - len;
-    int first = code << free_bits;
-    for (int i = 0; i < (1 << free_bits); i++)
-        table[first + i] = make_entry();
-}
-
-}  // namespace
-
 void build_parse_tables(ParseTables* t)
 {
     std::memset(t, 0, sizeof(*t));
-
-    // DCT coefficients.  dct_hi covers code words of <= 8 bits (index = their 8-bit prefix);
-    // longer words all start with six zero bits and are resolved through dct_lo, indexed by
-    // bits 6..15 of a 16-bit peek.
-    // (a bit pattern that is no code word: 0 bits consumed, level 63 -- the parser's "this block ends here" mark, which
-    // end_of_block carries with 2 bits)
-    for (auto& e : t->dct_hi)
-        e = (uint16_t)(63 << 10);
-    for (auto& e : t->dct_lo)
-        e = (uint16_t)(63 << 10);
-    for (const DctCode& c : kDctCodes) {
-        uint16_t e = (uint16_t)((c.len + 1) | (c.run << 5) | (c.level << 10));  // length incl. the sign bit
-        if (c.len <= 8)
-            expand(t->dct_hi, 8, c.code, c.len, [&] { return e; });
-        else
-            expand(t->dct_lo, 10, c.code & ((1 << (c.len - 6)) - 1), c.len - 6, [&] { return e; });
-    }
-    // level 0 = escape: 6-bit code + 6-bit run + 8-bit level (the 16-bit level form adds 8, in the parser)
-    expand(t->dct_hi, 8, kDctEscapeCode, kDctEscapeLen, [&] { return (uint16_t)(kDctEscapeLen + 14); });
-    // the two codes starting with 1 (not in the first position of a non-intra block, which the
-    // parser handles before its loop): "10" = end_of_block (level 63 marks it), "11s" = (0, +-1)
-    expand(t->dct_hi, 8, 0x2, 2, [&] { return (uint16_t)(2 | (63 << 10)); });
-    expand(t->dct_hi, 8, 0x3, 2, [&] { return (uint16_t)(3 | (0 << 5) | (1 << 10)); });
-
-    for (const VlcCode& c : kMbaCodes)
-        expand(t->mba, 11, c.code, c.len, [&] { return (uint16_t)(c.len | (c.value << 4)); });
-    for (const VlcCode& c : kMotionCodes)
-        expand(t->motion, 11, c.code, c.len, [&] { return (uint16_t)(c.len | ((c.value + 16) << 4)); });
-    for (const VlcCode& c : kCbpCodes)
-        expand(t->cbp, 9, c.code, c.len, [&] { return (uint16_t)(c.len | (c.value << 4)); });
-    for (const VlcCode& c : kTypePCodes)
-        expand(t->type_p, 6, c.code, c.len, [&] { return (uint8_t)(c.len | (c.value << 3)); });
 
     // IDCT pre-multipliers round(32 s_i s_j), s_0 = 1, s_k = sqrt(2) cos(k pi / 16): the scaled
     // AAN factors the reference tabulates as scale_dct_q (player.cpp:161-170).
