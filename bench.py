@@ -672,6 +672,7 @@ def run(job, args):
     P = r["P"]
 
     # SURVEY 8d config 5 as written: the FIXED 8192-stream batch, stream k on rank floor(k*N/8192)
+    log("leg: primary done; fixed batch")
     fixed = None
     if not args.no_fixed_batch:
         if S * world == args.fixed_batch:
@@ -687,6 +688,7 @@ def run(job, args):
         fixed["partition"] = f"stream k -> rank floor(k*{world}/{args.fixed_batch})"
         fixed["scaling"] = "strong"
 
+    log("leg: other workloads")
     others = None
     if world == 1 and not args.no_other_workloads:
         others = {}
@@ -697,12 +699,14 @@ def run(job, args):
                                        **stage_report(ow, min(args.steps, 10))}
         others["vmedia_x%d" % S] = run_clip(job, args, "vmedia", S, max(2, min(args.steps, 5)))
 
+    log("leg: video out")
     video_out = None
     if world == 1 and job.device == "cuda" and not args.no_video_out:
         video_out = run_video_out(job, args, S)
 
     cpu = cpu_o3 = None
     if rank == 0 and not args.no_cpu_baseline:
+        log("leg: cpu baseline")
         cpu = cpu_baseline(r["batch0"], S, P, 1024, args.cpu_baseline_seconds)
         if job.device == "cuda":
             cpu_o3 = cpu_baseline_o3(r["batch0"], S, P, 1024, args.cpu_baseline_seconds)
