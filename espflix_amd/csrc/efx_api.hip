@@ -41,10 +41,11 @@ __global__ void k_composite(const uint8_t*, const VideoTables*, const VideoLineT
 __global__ void k_pdm(const int16_t*, int, int, int32_t*, uint16_t*);
 __global__ void k_sbc(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int,
                       const uint32_t*);
-__global__ void k_sbc_par_stereo(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int,
-                                 const uint32_t*);
-__global__ void k_sbc_par_mono(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int,
-                          const uint32_t*);
+__global__ void k_sbc_par_stereo(const uint8_t*, size_t, int, int, const SbcState*, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*,
+                                 uint32_t*, int, const uint32_t*);
+__global__ void k_sbc_par_mono(const uint8_t*, size_t, int, int, const SbcState*, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*,
+                               uint32_t*, int, const uint32_t*);
+__global__ void k_sbc_commit(SbcState*, const SbcState*, const uint32_t*);
 __global__ void k_sbc_check(const uint8_t*, size_t, int, int, uint32_t*);
 }  // namespace efx
 
@@ -178,6 +179,7 @@ struct efx_ctx {
     SbcTables* d_sbc_tables = nullptr;
     int parse_wg_cap = 0;  // k_parse workgroups resident per parse kernel while reconstruction launches are queued (0: no cap); EFX_PARSE_WG_CAP
     uint32_t* d_sbc_flags = nullptr;  // per stream of an efx_sbc_decode call: 1 = decoded frame-parallel (k_sbc_check)
+    SbcState* d_sbc_next = nullptr;   // ... the state its frame-parallel kernel leaves, put in place by k_sbc_commit
     size_t sbc_flags_cap = 0;
     uint64_t* d_hash = nullptr;
 
@@ -490,7 +492,7 @@ void efx_destroy(efx_ctx* ctx)
             (void)hipStreamSynchronize(ps);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
-    void* bufs[] = {ctx->d_tables, ctx->d_tm_tables, ctx->d_sbc_flags, ctx->d_state, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0],
+    void* bufs[] = {ctx->d_tables, ctx->d_tm_tables, ctx->d_sbc_flags, ctx->d_sbc_next, ctx->d_state, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0],
                     ctx->d_video_lines[1], ctx->d_hash, ctx->d_ts, ctx->d_sbc_tables, ctx->d_idx_info, ctx->d_ts_off, ctx->d_idx_len,
                     ctx->d_idx_base, ctx->d_idx_seq};
     for (auto& te : ctx->timing_ring)
@@ -1433,9 +1435,13 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
     if ((size_t)n_streams > ctx->sbc_flags_cap) {
         if (ctx->d_sbc_flags)
             (void)hipFree(ctx->d_sbc_flags);
+        if (ctx->d_sbc_next)
+            (void)hipFree(ctx->d_sbc_next);
         ctx->d_sbc_flags = nullptr;
+        ctx->d_sbc_next = nullptr;
         ctx->sbc_flags_cap = 0;
         EFX_HIP(dalloc(&ctx->d_sbc_flags, (size_t)n_streams));
+        EFX_HIP(dalloc(&ctx->d_sbc_next, (size_t)n_streams));
         ctx->sbc_flags_cap = (size_t)n_streams;
     }
     EFX_HIP(hipMemsetAsync(ctx->d_sbc_flags, 0xFF, (size_t)n_streams * sizeof(uint32_t), ctx->stream));
@@ -1444,11 +1450,15 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
                            frame_bytes, n_frames, ctx->d_sbc_flags);
         // (one instantiation per channel count: a workgroup whose stream is of the other kind leaves at once)
         hipLaunchKernelGGL(k_sbc_par_mono, dim3((n_frames + 7) / 8, n_streams), dim3(256), 0, ctx->stream, frames_device, stream_stride,
-                           frame_bytes, n_frames, static_cast<SbcState*>(state_device), ctx->d_sbc_tables, pcm_device, pcm_stride,
-                           ret_device, pcm_count_device, flags, ctx->d_sbc_flags);
+                           frame_bytes, n_frames, static_cast<SbcState*>(state_device), ctx->d_sbc_next, ctx->d_sbc_tables, pcm_device,
+                           pcm_stride, ret_device, pcm_count_device, flags, ctx->d_sbc_flags);
         hipLaunchKernelGGL(k_sbc_par_stereo, dim3((n_frames + 7) / 8, n_streams), dim3(256), 0, ctx->stream, frames_device, stream_stride,
-                           frame_bytes, n_frames, static_cast<SbcState*>(state_device), ctx->d_sbc_tables, pcm_device, pcm_stride,
-                           ret_device, pcm_count_device, flags, ctx->d_sbc_flags);
+                           frame_bytes, n_frames, static_cast<SbcState*>(state_device), ctx->d_sbc_next, ctx->d_sbc_tables, pcm_device,
+                           pcm_stride, ret_device, pcm_count_device, flags, ctx->d_sbc_flags);
+        // (the last chunk of a stream must not overwrite the state its first chunk is still reading: the new states wait in
+        // d_sbc_next until both kernels are through)
+        hipLaunchKernelGGL(k_sbc_commit, dim3(n_streams), dim3(256), 0, ctx->stream, static_cast<SbcState*>(state_device), ctx->d_sbc_next,
+                           ctx->d_sbc_flags);
     }
     hipLaunchKernelGGL(k_sbc, dim3(n_streams), dim3(64), 0, ctx->stream, frames_device, stream_stride, frame_bytes, n_frames,
                        static_cast<SbcState*>(state_device), ctx->d_sbc_tables, pcm_device, pcm_stride, ret_device,

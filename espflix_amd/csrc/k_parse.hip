@@ -228,6 +228,10 @@ __device__ __forceinline__ void parse_group(uint32_t w, const uint8_t* __restric
     do {
         br.topup();
         sink.drain(L.tok);
+        if (__any(tm_guard(L))) {  // (garbage only: an address increment beyond any picture)
+            win = br.window();
+            e = lookup(L.st, win);
+        }
 #pragma unroll
         for (int t = 0; t < kTripsPerTopup; t++) {
             const uint32_t win0 = win;
@@ -266,6 +270,7 @@ __device__ __forceinline__ void parse_group(uint32_t w, const uint8_t* __restric
     fx.r_size = sp.r_size;
     fx.rec_flags = ((d.pic_code_flags >> 22) & 1) ? 0x80u : 0u;  // loaded quantiser matrices: recorded per macroblock for k_recon
     fx.epoch = (uint32_t)epoch;
+    fx.coef_last = sp.coef_last;
     uint32_t n_mbs = 0, n_coefs = 0;
     uint32_t st = tm_finish(L, fx, tok_base, [&](uint32_t k) { return raw[k]; }, coefs, reinterpret_cast<TmU4*>(mbrecs + rec0),
                             &n_mbs, &n_coefs);

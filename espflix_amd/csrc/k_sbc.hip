@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void k_sbc_check(const uint8_t* __restrict__ f
 constexpr int kSbcStageDwords = 1536;  // 6 KB: eleven frames of up to 558 bytes (16 blocks x 2 channels x 8 subbands x 16 bits + 12 is 524)
 template <int C>
 __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
-                                             int n_frames, SbcState* __restrict__ states,
+                                             int n_frames, const SbcState* __restrict__ states, SbcState* __restrict__ states_next,
                                              const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
                                              size_t pcm_stride, uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count,
                                              int flags, const uint32_t* __restrict__ parallel)
@@ -486,21 +486,26 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
             ret[(size_t)s * n_frames + f0 + fl] = (framelen & 0xFFFF) | ((uint32_t)(frame_samples * 2) << 16);
         }
     // ---- the workgroup of the last frames leaves the decoder state -------------------------------------------------------------
+    // NOT in `states`: the workgroup of the stream's first frames reads the history there, in this same launch, whenever it
+    // gets to it.  The new state goes to `states_next` as a whole (what this geometry does not touch copied over) and
+    // k_sbc_commit, the next kernel on the stream, puts it in place.
     if (f1 == n_frames) {
-        SbcState* so = states + s;
+        SbcState* so = states_next + s;
         const int k_last = n_frames - 1 - fr_lo;
         __syncthreads();
         for (int i = tid; i < 256; i += 256) {
             const int blk = i >> 4, c = (i >> 3) & 1, j = i & 7;
             // (blocks beyond this geometry keep what an earlier frame left there: the reference's array is not cleared)
-            if (blk < blocks && c < channels)
-                so->sb_sample[blk][c][j] = sb[k_last][blk][c][j];
+            so->sb_sample[blk][c][j] = (blk < blocks && c < channels) ? sb[k_last][blk][c][j] : st->sb_sample[blk][c][j];
         }
-        for (int i = tid; i < channels * 144; i += 256) {
+        for (int i = tid; i < 2 * 144; i += 256) {
             const int c = i / 144, r = i - c * 144;
-            so->hist[c][r >> 4][r & 15] = rows[c][n_t - 9 + (r >> 4)][r & 15];
+            so->hist[c][r >> 4][r & 15] = c < channels ? rows[c][n_t - 9 + (r >> 4)][r & 15] : st->hist[c][r >> 4][r & 15];
         }
         if (tid == 0) {
+            so->reserved = st->reserved;
+            for (int k = 0; k < 8; k++)
+                so->pad[k] = st->pad[k];
             const uint8_t* d = frame_at(n_frames - 1);
             so->frequency = (d[1] >> 6) & 3;
             so->blocks = (uint8_t)blocks;
@@ -516,21 +521,37 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
 }
 
 __global__ __launch_bounds__(256) void k_sbc_par_mono(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
-                                                      int n_frames, SbcState* __restrict__ states,
+                                                      int n_frames, const SbcState* __restrict__ states,
+                                                      SbcState* __restrict__ states_next,
                                                       const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
                                                       size_t pcm_stride, uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count,
                                                       int flags, const uint32_t* __restrict__ parallel)
 {
-    sbc_par_body<1>(frames, stream_stride, frame_bytes, n_frames, states, tables, pcm, pcm_stride, ret, pcm_count, flags, parallel);
+    sbc_par_body<1>(frames, stream_stride, frame_bytes, n_frames, states, states_next, tables, pcm, pcm_stride, ret, pcm_count, flags, parallel);
 }
 __global__ __launch_bounds__(256) void k_sbc_par_stereo(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
-                                                        int n_frames, SbcState* __restrict__ states,
+                                                        int n_frames, const SbcState* __restrict__ states,
+                                                        SbcState* __restrict__ states_next,
                                                         const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
                                                         size_t pcm_stride, uint32_t* __restrict__ ret,
                                                         uint32_t* __restrict__ pcm_count, int flags,
                                                         const uint32_t* __restrict__ parallel)
 {
-    sbc_par_body<2>(frames, stream_stride, frame_bytes, n_frames, states, tables, pcm, pcm_stride, ret, pcm_count, flags, parallel);
+    sbc_par_body<2>(frames, stream_stride, frame_bytes, n_frames, states, states_next, tables, pcm, pcm_stride, ret, pcm_count, flags, parallel);
+}
+
+// the states k_sbc_par left in `next` take their place (grid = streams; only streams that went the frame-parallel way)
+__global__ __launch_bounds__(256) void k_sbc_commit(SbcState* __restrict__ states, const SbcState* __restrict__ next,
+                                                    const uint32_t* __restrict__ parallel)
+{
+    const int s = blockIdx.x;
+    if (!parallel[s])
+        return;
+    static_assert(sizeof(SbcState) % 4 == 0, "SbcState is copied by dwords");
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(next + s);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(states + s);
+    for (int i = threadIdx.x; i < (int)(sizeof(SbcState) / 4); i += 256)
+        dst[i] = src[i];
 }
 
 }  // namespace efx

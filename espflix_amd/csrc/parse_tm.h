@@ -71,10 +71,13 @@ EFX_HD int tm_level(uint32_t w)  // the signed level of a coefficient word (k_re
     return (w >> 31) ? v + (int)x : ((x & 1) ? -v : v);
 }
 
-// header word of a macroblock (64 bits): macroblock_type [5:0] | quantiser_scale [10:6] | address increment [27:12] |
-// macroblock_stuffing seen [30:28] | horizontal motion code + 16 [37:32], its residual [43:38] | vertical [49:44], [55:50] |
-// [63] never read
-constexpr int kHaccInc = 12, kHaccStuff = 28, kHaccMvH = 32, kHaccMvV = 44, kHaccNone = 63;
+// header word of a macroblock (64 bits): macroblock_type [5:0] | quantiser_scale [10:6] | address increment [31:12] |
+// horizontal motion code + 16 [37:32], its residual [43:38] | vertical [49:44], [55:50] | macroblock_stuffing seen [62:56] |
+// [63] never read.  Both counters that a stream can drive as far as it likes -- ISO 11172-2 allows any number of stuffing
+// codes and of address escapes, and the reference simply loops (player.cpp:1267-1275) -- sit where a carry cannot reach a
+// live field, and tm_guard() keeps them from wrapping: the stuffing count is held between 32 and 95 once it has passed 63
+// ("seen" is all that is ever read), an increment of 2^19 and more (the picture has 264 macroblocks) stops the lane.
+constexpr int kHaccInc = 12, kHaccStuff = 56, kHaccMvH = 32, kHaccMvV = 44, kHaccNone = 63;
 
 // table placement, in entries
 constexpr int kTbDcY1 = 0, kTbDcC1 = 256, kTbDctF = 512, kTbMvH1 = 768, kTbCbp1 = 1024;  // the plan's targets: 2 KB apart
@@ -163,6 +166,19 @@ EFX_HD uint32_t tm_ubfe(uint32_t v, uint32_t off, uint32_t width)
 EFX_HD uint32_t tm_ffbh(uint32_t v)  // leading zeros; 0xFFFFFFFF for 0 (v_ffbh_u32)
 {
     return v ? (uint32_t)__builtin_clz(v) : 0xFFFFFFFFu;
+}
+
+// Between two groups of trips (a group is at most 8 trips: each adds at most 33 to the increment, 1 to the stuffing
+// count): true when the lane's state changed -- the caller looks its entry up again.
+EFX_HD bool tm_guard(TmLane& L)
+{
+    uint32_t hi = (uint32_t)(L.hacc >> 32);
+    const uint32_t lo = (uint32_t)L.hacc;
+    hi -= (hi & 0x40000000u) >> 1;  // stuffing count 64 ... -> 32 ...
+    L.hacc = ((uint64_t)hi << 32) | lo;
+    const bool far = (lo >> 31) != 0 && L.st < (((uint32_t)kTbDead * 8u) << 16);
+    L.st = far ? ((((uint32_t)(kTbDead + 2 * 5) * 8u) << 16) | 31u) : L.st;  // tm_dead(kDeadLimit)
+    return far;
 }
 
 EFX_HD void tm_begin(TmLane& L, uint32_t tok_base, bool has_slice)
@@ -290,6 +306,8 @@ struct TmFix {
     uint32_t full_pel, r_size;
     uint32_t rec_flags;  // 0x80 when the picture uses loaded quantiser matrices
     uint32_t epoch;
+    uint32_t coef_last;  // last stream slot of the slice's region: pass 2 never reads a DC token from, or writes a DC value
+                         // or an MbRec for, a macroblock whose words do not all lie inside it
 };
 
 #if defined(__HIPCC__)
@@ -346,7 +364,7 @@ EFX_HD uint32_t tm_finish(const TmLane& L, const TmFix& fx, uint32_t tok_base, R
         uint32_t at = first;
         for (int b = 0; b < 6; b++) {
             const uint32_t c = count(r, b);
-            w[b] = ((r.x & 1) && c) ? coefs[at] : 0u;
+            w[b] = ((r.x & 1) && c && at <= fx.coef_last) ? coefs[at] : 0u;  // (a macroblock that ran past its region is dropped below)
             at += c == 0xFF ? 1u : c;
         }
     };
@@ -360,7 +378,7 @@ EFX_HD uint32_t tm_finish(const TmLane& L, const TmFix& fx, uint32_t tok_base, R
         const uint32_t first1 = first + words(r);
         load_dc(r1, first1, dcw1);
         const uint32_t type = r.x & 63, qf = (r.x >> 6) & 31;
-        int inc = (int)((r.x >> kHaccInc) & 0xFFFF);
+        int inc = (int)(r.x >> kHaccInc);  // (20 bits; tm_guard() stops a lane before bit 31 can carry out)
         if (k == 0)
             mb_addr += 1;  // inc_mb() ignores its argument: the first macroblock sits in column 0 (player.cpp:823-833,1277)
         else {
@@ -390,6 +408,15 @@ EFX_HD uint32_t tm_finish(const TmLane& L, const TmFix& fx, uint32_t tok_base, R
             break;
         }
         if (k == L.nmb) {  // the header that could not be read
+            status |= EFX_STREAM_BAD_VLC;
+            stopped = true;
+            break;
+        }
+        if ((r.w & kRawRanPast) || first1 > fx.coef_last + 1) {
+            // The macroblock's words outgrew the slice's region (pass 1 dropped those beyond it): a damaged slice that ran on
+            // through the start codes behind it.  Nothing of it is kept -- the slots past the region belong to the next slice
+            // in the bitstream, possibly another stream's, whose lane runs at the same time: a DC value or a shifted word
+            // written there would corrupt a stream that is not damaged.
             status |= EFX_STREAM_BAD_VLC;
             stopped = true;
             break;
@@ -475,7 +502,7 @@ EFX_HD uint32_t tm_finish(const TmLane& L, const TmFix& fx, uint32_t tok_base, R
     if (!stopped) {
         // an address increment that does not exist -- or the 23 zero bits that end a slice (slice_done(),
         // player.cpp:1238-1249) met anywhere but where a macroblock would start (after stuffing)
-        if (why == kDeadBadMba || (why == kDeadEnd && (((uint32_t)L.hacc >> kHaccInc) & 0x7FFFF) != 0))
+        if (why == kDeadBadMba || (why == kDeadEnd && (((uint32_t)L.hacc >> kHaccInc) != 0 || ((L.hacc >> kHaccStuff) & 0x7F) != 0)))
             status |= EFX_STREAM_BAD_VLC;
         if (why == kDeadLimit || (why == kDeadBadHeader && !partial))
             status |= EFX_STREAM_MB_OVERRUN;  // a macroblock beyond the last one the slice may hold

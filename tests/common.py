@@ -270,3 +270,113 @@ def interleave_audio(video_ts: bytes, seed: int) -> bytes:
     for pkt in a[ia:]:
         out += pkt
     return bytes(out)
+
+
+# ---- hand-built P pictures: macroblock_stuffing and macroblock_escape in every number (test input only) ----------------
+class _Bits:
+    def __init__(self):
+        self.out = bytearray()
+        self.acc = 0
+        self.n = 0
+
+    def put(self, value: int, bits: int):
+        for i in range(bits - 1, -1, -1):
+            self.acc = (self.acc << 1) | ((value >> i) & 1)
+            self.n += 1
+            if self.n == 8:
+                self.out.append(self.acc)
+                self.acc, self.n = 0, 0
+
+    def align(self):
+        while self.n:
+            self.put(0, 1)
+
+    def start_code(self, code: int):
+        self.align()
+        self.out += bytes([0, 0, 1, code])
+
+
+STUFFING_COUNTS = [0, 1, 7, 8, 15, 16, 17, 40, 63, 64, 65, 127, 128, 129, 255, 256, 300]
+
+
+def stuffing_es() -> bytes:
+    """One generator I picture, then three P pictures written bit by bit (ISO 11172-2 2.4.2.7, 2.4.3.6 as
+    MpegDecoder::slice reads them, player.cpp:1264-1316):
+      picture 1  twelve slices of 22 "motion only" macroblocks with small vectors in the interior; in front of chosen
+                 macroblocks -- the first of a slice included -- 1 ... 300 macroblock_stuffing codes (the reference loops
+                 over them, player.cpp:1268-1270; a decoder that counts them must not let the count carry into a live field);
+      picture 2  ONE slice for the whole picture: address increments of 68 (escape, stuffing, 1: after an escape the
+                 reference's second loop counts a stuffing code as 34, player.cpp:1271-1274), 134 (four escapes + 2), then ones;
+      picture 3  twelve slices again, every macroblock skipped except the first and the last of a slice (increment 21).
+    All vectors keep the 17 x 17 fetch inside the picture (SURVEY 8a stream constraints)."""
+    from espflix_amd import gen
+    head = gen.Batch(0, 1, 1, 12, 0).es(0).tobytes()
+    b = _Bits()
+    rng = np.random.default_rng(11)
+    MC = (0b001, 3)      # macroblock_type P: motion forward, no pattern
+    MV = {0: (0b1, 1), 1: (0b010, 3), -1: (0b011, 3), 2: (0b0010, 4), -2: (0b0011, 4)}
+    INC = {1: (0b1, 1), 2: (0b011, 3), 3: (0b010, 3), 21: (0b0000010010, 10)}  # table B-1 (21: 0000 0100 10)
+    ESC, STUFF = (0b00000001000, 11), (0b00000001111, 11)
+
+    def picture_header(tref):
+        b.start_code(0x00)
+        b.put(tref, 10)
+        b.put(2, 3)        # P
+        b.put(0xFFFF, 16)  # vbv_delay
+        b.put(0, 1)        # full_pel_forward_vector
+        b.put(1, 3)        # forward_f_code 1
+        b.put(0, 1)        # extra_bit_picture
+
+    def mb(inc_codes, dh, dv):
+        for c in inc_codes:
+            b.put(*c)
+        b.put(*MC)
+        b.put(*MV[dh])
+        b.put(*MV[dv])
+
+    # picture 1
+    picture_header(1)
+    counts = list(STUFFING_COUNTS)
+    for row in range(12):
+        b.start_code(row + 1)
+        b.put(8, 5)
+        b.put(0, 1)
+        # horizontal deltas: columns 1..10 random, 11..20 undo them (the vector is 0 again at the right edge)
+        dh = [0] * 22
+        dv = [0] * 22
+        for c in range(1, 11):
+            dh[c] = int(rng.integers(-2, 3))
+            dh[21 - c] = -dh[c]
+            if 1 <= row <= 10:
+                dv[c] = int(rng.integers(-2, 3))
+                dv[21 - c] = -dv[c]
+        for col in range(22):
+            pre = []
+            if (col * 5 + row) % 7 == 0 or (row == 3 and col == 0):
+                pre = [STUFF] * counts[(row * 22 + col) % len(counts)]
+            mb(pre + [INC[1]], dh[col], dv[col])
+    # picture 2: one slice for the whole picture
+    picture_header(2)
+    b.start_code(1)
+    b.put(6, 5)
+    b.put(0, 1)
+    mb([INC[1]], 0, 0)                 # address 0
+    mb([ESC, STUFF], 0, 0)             # + 33 + 34 = 67: after an escape a stuffing code IS the increment 34
+    mb([ESC] * 4 + [INC[2]], 0, 0)     # + 134 = 201
+    for _ in range(62):
+        mb([STUFF] * 2 + [INC[1]], 0, 0)   # ... 263
+    # picture 3: first and last macroblock of every row coded, the twenty between them skipped
+    picture_header(3)
+    for row in range(12):
+        b.start_code(row + 1)
+        b.put(10, 5)
+        b.put(0, 1)
+        mb([INC[1]], 0, 0)
+        mb([STUFF] * (row * 13) + [INC[21]], 0, 0)
+    b.align()
+    return head + bytes(b.out)
+
+
+def one_pes_per_picture(es: bytes) -> bytes:
+    """Transport stream with one PES (and PTS) per picture, the first PES also carrying the headers in front of it."""
+    return late_pts_ts(es, 0)

@@ -9,6 +9,7 @@ Everything in golden.json is an output of the reference itself:
              embedded in the reference (src/splash.h, src/vmedia.h), with and without the final
              flush_picture(1)
   synthetic  the same for generator streams (TS-wrapped) of several flavours
+  handmade   the same for streams written bit by bit in tests/common.py (macroblock_stuffing / macroblock_escape runs)
   display    FNV of video_isr() fields with _hscroll slides and the composite() overlay / progress bar
   index      FNV of the indexer's video.idx for synthetic titles and the clips
   sbc        FNV of sbc_decoder() PCM for synthetic frame configurations and the clips' PID 0x102 audio
@@ -32,7 +33,7 @@ import oracle
 from espflix_amd import gen
 
 assert oracle.have_ref(), "build oracle/_ref first (make ref)"
-out = {"clips": {}, "synthetic": {}, "composite": {}, "display": {}, "pdm": {}, "sbc": {}, "index": {}, "tables": {}}
+out = {"clips": {}, "synthetic": {}, "handmade": {}, "composite": {}, "display": {}, "pdm": {}, "sbc": {}, "index": {}, "tables": {}}
 
 for clip in ("splash", "vmedia"):
     subprocess.run([os.path.join(oracle.REF_DIR, "efx_ref_decode"), "fixture", "@" + clip,
@@ -49,6 +50,12 @@ for flags in common.SYN_FLAGS:
         h, pts, _ = oracle.ref_decode(b.ts(k), flush_last=True)
         out["synthetic"][f"{flags}:{k}"] = {"hashes": [f"{int(x):016x}" for x in h], "pts": [int(x) for x in pts],
                                             "es_fnv": f"{common.fnv_bytes(b.es(k)):016x}"}
+
+# macroblock_stuffing in every number, address escapes, stuffing behind an escape (player.cpp:1267-1275)
+es = common.stuffing_es()
+h, pts, _ = oracle.ref_decode(np.frombuffer(common.one_pes_per_picture(es), dtype=np.uint8), flush_last=True)
+out["handmade"]["stuffing"] = {"hashes": [f"{int(x):016x}" for x in h], "pts": [int(x) for x in pts],
+                               "es_fnv": f"{common.fnv_bytes(np.frombuffer(es, dtype=np.uint8)):016x}"}
 
 _, _, frames = oracle.ref_decode(gen.Batch(0, 1, 12, 12, 0).ts(0), flush_last=True, want_frames=True)
 inputs = {"lcg": common.lcg_frames(), "random": common.random_frames(7), "decoded": np.concatenate([frames[10], frames[11]])}

@@ -5,6 +5,9 @@
 // from the same header against the frames of the reference.
 //
 //   parse_harness <file> [ts]     exit 0 and "OK slices=.. macroblocks=.. entries=.. trips=.. rejected=.. unseen=.. phantom=.." or a mismatch report
+//   parse_harness --selftest      hand-built slices for what no decodable stream reaches: a slice whose words outgrow its region
+//                                 (pass 2 must not touch the next slice's slots), address escapes without end, long runs of
+//                                 macroblock_stuffing
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -47,10 +50,189 @@ struct ExpMb {
     std::vector<uint32_t> entries;
 };
 
+struct BitWriter {
+    std::vector<uint8_t> bytes;
+    int fill = 0;
+    void put(uint32_t v, int n)
+    {
+        for (int i = n - 1; i >= 0; i--) {
+            if (!fill)
+                bytes.push_back(0);
+            bytes.back() |= (uint8_t)(((v >> i) & 1) << (7 - fill));
+            fill = (fill + 1) & 7;
+        }
+    }
+};
+
+// One slice (the bits after quantiser_scale / extra_bit_slice), run exactly as the harness runs a slice of a stream.
+struct Solo {
+    std::vector<uint32_t> coefs;
+    std::vector<MbRec> recs;
+    uint32_t status = 0, n_mbs = 0, why = 0;
+    TmLane L;
+};
+Solo run_solo(const TmTables* tab, const BitWriter& bw, bool intra_picture, uint32_t region_slots, int code = 1, int mb_limit = kMbCount)
+{
+    Solo o;
+    std::vector<uint8_t> es = bw.bytes;
+    es.resize(es.size() + 64, 0);
+    const uint32_t tok_base = 64;
+    o.coefs.assign(tok_base + region_slots + 4096, 0xDEADBEEFu);
+    o.recs.assign(kMbCount, MbRec{});
+    std::vector<TmU4> raw(kMbCount + 1);
+    HostBits br{es.data(), 0};
+    TmSlice sp;
+    sp.coef_last = tok_base + region_slots - 1;
+    sp.type_bit = intra_picture ? kTmTypeIBit : 0u;
+    sp.r_size = 0;
+    sp.max_mbs = (uint32_t)(mb_limit - (code - 1) * kMbW);
+    TmFix fx{};
+    fx.code = code;
+    fx.mb_limit = mb_limit;
+    fx.qscale = 4;
+    fx.epoch = 9;
+    fx.coef_last = sp.coef_last;
+    tm_begin(o.L, tok_base, true);
+    auto store_raw = [&](uint32_t k, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { raw[k] = TmU4{a, b, c, d}; };
+    long trips = 0;
+    while (tm_alive(o.L.st) && trips < 10000000) {
+        if ((trips & 3) == 0)
+            tm_guard(o.L);
+        const uint32_t win = br.pos / 8 + 8 < es.size() ? br.window() : 0u;
+        const TmE e = tab->e[(o.L.st >> 19) + (win >> (o.L.st & 31))];
+        if (tm_trip(o.L, win, e, sp, [&](uint32_t bits, uint32_t) { br.pos += bits; }, TmDirectSink{o.coefs.data(), sp.coef_last}, store_raw))
+            br.pos -= tm_overflow(o.L, e, sp, TmDirectSink{o.coefs.data(), sp.coef_last}, store_raw);
+        trips++;
+    }
+    tm_end(o.L, sp, store_raw);
+    uint32_t nc = 0;
+    o.status = tm_finish(o.L, fx, tok_base, [&](uint32_t k) { return raw[k]; }, o.coefs.data(), reinterpret_cast<TmU4*>(o.recs.data()), &o.n_mbs, &nc);
+    o.why = tm_why(o.L.st);
+    return o;
+}
+
+int selftest()
+{
+    TmTables* tab = new TmTables;
+    build_tm_tables(tab);
+    int bad = 0;
+    auto expect = [&](bool ok, const char* what) {
+        if (!ok) {
+            fprintf(stderr, "selftest: %s\n", what);
+            bad++;
+        }
+    };
+    // ---- a slice whose words outgrow its region ---------------------------------------------------------------------------
+    // one intra macroblock of 6 blocks x (DC + three coefficients) = 24 stream words in a region of 8 slots: pass 1 drops the
+    // words beyond the region, pass 2 must not write DC values (or shift words) there -- they are the next slice's
+    {
+        BitWriter bw;
+        bw.put(1, 1);  // macroblock_address_increment 1
+        bw.put(1, 1);  // macroblock_type I: intra
+        for (int b = 0; b < 6; b++) {
+            if (b < 4)
+                bw.put(0x1, 3);  // dct_dc_size_luminance 1 ("00") + differential bit 1
+            else
+                bw.put(0x0, 2);  // dct_dc_size_chrominance 0 ("00")
+            for (int k = 0; k < 3; k++)
+                bw.put(0x6, 3);  // "11" + sign 0: run 0, level 1
+            bw.put(0x2, 2);      // end_of_block
+        }
+        Solo o = run_solo(tab, bw, true, 8);
+        expect((o.status & EFX_STREAM_BAD_VLC) != 0, "ran past its region: EFX_STREAM_BAD_VLC expected");
+        bool clean = true;
+        for (size_t i = 64 + 8; i < o.coefs.size(); i++)
+            clean = clean && o.coefs[i] == 0xDEADBEEFu;
+        expect(clean, "ran past its region: a slot beyond the region was written");
+        expect(o.recs[0].epoch == 0, "ran past its region: the macroblock must not be kept");
+        // the same macroblock in a region that holds it: kept, DC values in place
+        Solo f = run_solo(tab, bw, true, 28);
+        expect(f.status == 0 && f.n_mbs == 1 && f.recs[0].epoch == 9 && f.recs[0].cnt[0] == 4 && f.recs[0].cnt[5] == 4,
+               "one intra macroblock in a region that holds it");
+        expect(f.coefs[64] == (uint32_t)(128 + 1) << 6 && f.coefs[64 + 16] == (uint32_t)128 << 6, "DC values of the intra macroblock");
+        // an invalid code inside a block, met beyond the region: the blocks before it must not be written either
+        BitWriter bx;
+        bx.put(1, 1);
+        bx.put(1, 1);
+        for (int b = 0; b < 3; b++) {
+            bx.put(0x1, 3);
+            for (int k = 0; k < 3; k++)
+                bx.put(0x6, 3);
+            bx.put(0x2, 2);
+        }
+        bx.put(0x1, 3);
+        bx.put(0x6, 3);
+        bx.put(0x0, 12);  // twelve zero bits: no such coefficient code ... (the tail of zeros follows)
+        Solo x = run_solo(tab, bx, true, 8);
+        clean = true;
+        for (size_t i = 64 + 8; i < x.coefs.size(); i++)
+            clean = clean && x.coefs[i] == 0xDEADBEEFu;
+        expect((x.status & EFX_STREAM_BAD_VLC) != 0 && clean, "bad code beyond the region: flagged, nothing written past the region");
+    }
+    // ---- macroblock_stuffing, any number of codes (player.cpp:1268-1270 simply loops) -------------------------------------------
+    for (int n_stuff : {1, 7, 8, 15, 16, 17, 40, 63, 64, 65, 127, 128, 129, 255, 256, 300, 1000}) {
+        BitWriter bw;
+        bw.put(1, 1);    // increment 1
+        bw.put(1, 3);    // macroblock_type P "001": motion forward, no pattern
+        bw.put(1, 1);    // motion_horizontal_forward_code 0
+        bw.put(1, 1);    // motion_vertical_forward_code 0
+        for (int i = 0; i < n_stuff; i++)
+            bw.put(0xF, 11);  // macroblock_stuffing 0000 0001 111
+        bw.put(1, 1);
+        bw.put(1, 3);
+        bw.put(1, 1);
+        bw.put(1, 1);
+        Solo o = run_solo(tab, bw, false, 4096);
+        char what[96];
+        snprintf(what, sizeof what, "%d stuffing codes before a macroblock: two records, zero vectors, status 0", n_stuff);
+        expect(o.status == 0 && o.n_mbs == 2 && o.recs[1].epoch == 9 && o.recs[1].mvx == 0 && o.recs[1].mvy == 0 && o.why == kDeadEnd, what);
+        // ... and stuffing followed by the end of the slice is not where a slice may end (slice_done() is asked between
+        // macroblocks only): flagged, whatever the count
+        BitWriter be;
+        be.put(1, 1);
+        be.put(1, 3);
+        be.put(1, 1);
+        be.put(1, 1);
+        for (int i = 0; i < n_stuff; i++)
+            be.put(0xF, 11);
+        Solo z = run_solo(tab, be, false, 4096);
+        snprintf(what, sizeof what, "%d stuffing codes, then the end of the slice: EFX_STREAM_BAD_VLC", n_stuff);
+        expect((z.status & EFX_STREAM_BAD_VLC) != 0, what);
+    }
+    // ---- address escapes without end: the increment must not wrap into a small one --------------------------------------------
+    for (int n_esc : {7, 8, 2000, 40000, 70000}) {
+        BitWriter bw;
+        bw.put(1, 1);
+        bw.put(1, 3);
+        bw.put(1, 1);
+        bw.put(1, 1);
+        for (int i = 0; i < n_esc; i++)
+            bw.put(0x8, 11);  // macroblock_escape 0000 0001 000
+        bw.put(1, 1);
+        bw.put(1, 3);
+        bw.put(1, 1);
+        bw.put(1, 1);
+        Solo o = run_solo(tab, bw, false, 1u << 20);
+        char what[96];
+        snprintf(what, sizeof what, "%d address escapes: one record kept, EFX_STREAM_MB_OVERRUN", n_esc);
+        // (7 escapes + 1 = 232 more macroblocks: inside the picture; from 8 on the address lies beyond it)
+        if (n_esc == 7)
+            expect(o.status == 0 && o.n_mbs == 233 && o.recs[232].epoch == 9, "7 address escapes: macroblock 232");
+        else
+            expect((o.status & EFX_STREAM_MB_OVERRUN) != 0 && o.recs[0].epoch == 9, what);
+    }
+    delete tab;
+    if (!bad)
+        printf("SELFTEST OK\n");
+    return bad ? 1 : 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
 {
+    if (argc >= 2 && !strcmp(argv[1], "--selftest"))
+        return selftest();
     if (argc < 2) {
         fprintf(stderr, "usage: parse_harness <file> [ts]\n");
         return 2;
@@ -216,6 +398,7 @@ int main(int argc, char** argv)
         fx.r_size = sp.r_size;
         fx.rec_flags = se.e ? 0x80u : 0u;
         fx.epoch = epoch;
+        fx.coef_last = sp.coef_last;
         {
             uint32_t w = br.window();
             fx.qscale = w >> 27;
@@ -231,6 +414,8 @@ int main(int argc, char** argv)
         long guard = 0;
         const long trips0 = trips;
         while (tm_alive(L.st)) {
+            if ((trips & 3) == 0)
+                tm_guard(L);  // (k_parse: between two groups of trips)
             const uint32_t win = br.window();
             const TmE e = tab->e[(L.st >> 19) + (win >> (L.st & 31))];
             if (tm_trip(L, win, e, sp, [&](uint32_t bits, uint32_t) { br.pos += bits; }, TmDirectSink{coefs.data(), sp.coef_last}, store_raw))

@@ -61,6 +61,19 @@ def test_synthetic_vs_reference_golden(efx, flags, golden):
         assert res[k]["n"] == n and res[k]["hashes"] == [int(x) for x in h]
 
 
+def test_handmade_stuffing_and_escapes_vs_reference_golden(efx, golden):
+    """1 ... 300 macroblock_stuffing codes in front of a macroblock, address escapes, stuffing behind an escape
+    (player.cpp:1267-1275): ES and TS input against what the unmodified reference decoded."""
+    g = golden["handmade"]["stuffing"]
+    es = common.stuffing_es()
+    ts = common.one_pes_per_picture(es)
+    r = gpu_hashes(efx, [np.frombuffer(es, dtype=np.uint8)] * 3, efx.FORMAT_ES, 8)
+    for k in range(3):
+        assert r[k]["status"] == 0 and [f"{h:016x}" for h in r[k]["hashes"]] == g["hashes"]
+    r = gpu_hashes(efx, [np.frombuffer(ts, dtype=np.uint8)], efx.FORMAT_TS, 8)[0]
+    assert r["status"] == 0 and [f"{h:016x}" for h in r["hashes"]] == g["hashes"] and r["pts"] == g["pts"]
+
+
 def test_ts_input_synthetic_pts(efx, golden):
     from espflix_amd import gen
     b = gen.Batch(0, 8, 12, 12, 0)

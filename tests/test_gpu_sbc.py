@@ -146,6 +146,45 @@ def test_parallel_and_serial_paths_side_by_side(efx):
     dec.close()
 
 
+def test_state_carried_into_a_short_second_call_repeated(efx):
+    """A call of nine frames is two frame-parallel chunks -- frames 0..7 and a light tail of one -- and the tail leaves the
+    stream's state while the first chunk may not have read the filter memory yet: the state is handed over through a scratch
+    copy (k_sbc_commit), never written in the launch that reads it.  512 streams, non-zero carried-over state, the nine-frame
+    call replayed from a snapshot of that state a dozen times; also a stereo stream count and a 17-frame call."""
+    S = 512
+    for kw, ch in ((dict(freq=3, blocks=16, mode=0, alloc=0, bitpool=28), 1), (dict(freq=2, blocks=8, mode=1, alloc=0, bitpool=35), 2)):
+        fb = common.sbc_frame_bytes(kw["blocks"], ch, kw["bitpool"])
+        spf = kw["blocks"] * 8 * ch
+        n0 = 16
+        for n1 in (9, 17):
+            one = [common.sbc_frames(900 + i, n0 + n1, **kw) for i in range(8)]
+            want = [oracle.sbc_decode(o, fb)[0] for o in one]
+            stride = ((n0 + n1) * fb + 15) & ~15
+            buf = np.zeros(S * stride, dtype=np.uint8)
+            for i in range(S):
+                buf[i * stride:i * stride + one[i % 8].size] = one[i % 8]
+            dec = efx.Decoder(1, 1, 2)
+            d_fr, d_st = dec.alloc(buf.size), dec.alloc(S * efx.sbc_state_bytes())
+            d_pcm, d_cnt = dec.alloc(S * (n0 + n1) * spf * 2), dec.alloc(S * 4)
+            d_fr.upload(buf)
+            d_st.upload(np.zeros(S * efx.sbc_state_bytes(), dtype=np.uint8))
+            dec.sbc_decode(S, d_fr, stride, fb, n0, d_st, d_pcm, (n0 + n1) * spf, None, d_cnt)
+            dec.sync()
+            snapshot = d_st.download(np.uint8, S * efx.sbc_state_bytes())
+            assert snapshot.any()
+            for rep in range(12):
+                d_st.upload(snapshot)
+                dec.sbc_decode(S, d_fr.ptr + n0 * fb, stride, fb, n1, d_st, d_pcm, (n0 + n1) * spf, None, d_cnt)
+                dec.sync()
+                assert (d_cnt.download(np.uint32, S) == n1 * spf).all()
+                pcm = d_pcm.download(np.int16, S * (n0 + n1) * spf).reshape(S, -1)[:, :n1 * spf]
+                for i in range(S):
+                    assert np.array_equal(pcm[i], want[i % 8][n0 * spf:]), (ch, n1, rep, i)
+            for b in (d_fr, d_st, d_pcm, d_cnt):
+                b.free()
+            dec.close()
+
+
 def test_batch_of_streams_and_pdm_chain(efx):
     """256 streams with different content decode independently; the PCM then feeds k_pdm on the
     device (config 4's audio half: SBC -> PCM -> PDM) and matches the oracle chain."""

@@ -49,6 +49,18 @@ def test_synthetic_streams(flags, golden):
         assert hx(h2) == g["hashes"]
 
 
+def test_handmade_stuffing_and_escapes(golden):
+    """macroblock_stuffing 1 ... 300 times in front of a macroblock, address escapes, a stuffing code behind an escape
+    (= increment 34), written bit by bit (common.stuffing_es); goldens from the unmodified reference."""
+    g = golden["handmade"]["stuffing"]
+    es = np.frombuffer(common.stuffing_es(), dtype=np.uint8)
+    assert f"{common.fnv_bytes(es):016x}" == g["es_fnv"], "the hand-built stream changed: regenerate the goldens"
+    n, h, pts, _ = oracle.decode(np.frombuffer(common.one_pes_per_picture(es.tobytes()), dtype=np.uint8), 1)
+    assert hx(h) == g["hashes"] and [int(p) for p in pts] == g["pts"]
+    n2, h2, _, _ = oracle.decode(es, 0)
+    assert hx(h2) == g["hashes"]
+
+
 def test_fixture_coverage_escape_levels_and_header_quirks(clips):
     """What the two quirk flavours are FOR, checked on the oracle's parse trace (so that a change of the generator
     cannot quietly empty the fixture): flavour 64 reaches every form of the escape level of player.cpp:1092-1099 --

@@ -78,3 +78,21 @@ def test_damaged_streams(harness, tmp_path):
         for key in total:
             total[key] += r[key]
     assert total["slices"] > 1000 and total["unseen"] <= 40, total
+
+
+def test_handmade_stuffing_and_escapes(harness, tmp_path):
+    """Any number of macroblock_stuffing codes (the reference loops, player.cpp:1268-1270) and of address escapes: every
+    record -- address, vector -- equals the oracle's, no status bit (a count that carried into the motion code field gave
+    a wrong vector from 16 codes on, unflagged)."""
+    f = tmp_path / "stuffing.es"
+    f.write_bytes(common.stuffing_es())
+    p = subprocess.run([harness, str(f)], capture_output=True, text=True, timeout=300, env=dict(os.environ, EFX_HARNESS_CLEAN="1"))
+    assert p.returncode == 0 and p.stdout.startswith("OK slices=37 macroblocks=1056 "), p.stdout + p.stderr
+
+
+def test_selftest_region_overrun_stuffing_escapes(harness):
+    """Hand-built slices no decodable stream reaches (tests/parse_harness.cpp: selftest): a slice whose stream words outgrow
+    its region never touches the slots behind it in pass 2 (they are another slice's, maybe another stream's), stuffing
+    runs up to 1000 codes, address escapes up to 70 000 (the increment stops the lane instead of wrapping)."""
+    p = subprocess.run([harness, "--selftest"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "SELFTEST OK" in p.stdout, p.stdout + p.stderr
