@@ -493,6 +493,9 @@ def timed_region(job, dec, steps, warmup, overlap=True):
     return edist.max_over_ranks(elapsed, job.dist, job.device)
 
 
+_GEN_CACHE = {}  # --soak: a leg is repeated with the same streams
+
+
 def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_serial=True, sustained_steps=0):
     """Generate, gate, time one workload on this rank.  Returns a dict of rank-local + job results."""
     from espflix_amd import dist as edist
@@ -501,16 +504,22 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
     golden = load_golden(workload)
     t_gen = time.perf_counter()
     # ids are contiguous per rank (or wrapped for the small tables): generate in runs of consecutive ids
-    batches, streams = [], []
-    start = 0
-    while start < S:
-        end = start + 1
-        while end < S and ids[end] == ids[end - 1] + 1:
-            end += 1
-        b = gen.Batch(int(ids[start]), end - start, P, 12, flags, gen_threads)
-        batches.append((start, b))
-        streams.extend(b.all_es())
-        start = end
+    key = (workload, S, int(ids[0]), int(ids[-1]))
+    if key in _GEN_CACHE:
+        batches, streams = _GEN_CACHE[key]
+    else:
+        batches, streams = [], []
+        start = 0
+        while start < S:
+            end = start + 1
+            while end < S and ids[end] == ids[end - 1] + 1:
+                end += 1
+            b = gen.Batch(int(ids[start]), end - start, P, 12, flags, gen_threads)
+            batches.append((start, b))
+            streams.extend(b.all_es())
+            start = end
+        if getattr(args, "soak", None):
+            _GEN_CACHE[key] = (batches, streams)
     t_gen = time.perf_counter() - t_gen
     es_bytes = int(sum(s.size for s in streams))
     n_i = S * ((P + 11) // 12)
@@ -658,6 +667,38 @@ def stage_report(r, steps):
     return out
 
 
+SOAK_LEGS = ("primary", "fixed_batch_8192", "wide1500k", "vmedia_x1024", "video_out")
+
+
+def soak(job, args):
+    """--soak LEG N: one process, one leg of the default run, N times -- decoder contexts created and destroyed as the full
+    run does -- to chase a rare fault down to a leg (profiles/r5_fault_hunt.md; with EFX_GUARD=1 every device buffer ends on
+    an unmapped page, so an over-read faults at once instead of once in forty runs).  Every repetition is gated against the
+    reference decoder's goldens like the real leg.  No JSON line: progress goes to stderr."""
+    from espflix_amd import dist as edist
+    leg, n = args.soak[0], int(args.soak[1])
+    if leg not in SOAK_LEGS:
+        raise SystemExit(f"--soak: leg must be one of {SOAK_LEGS}")
+    S = args.streams
+    threads = max(1, usable_cores() // max(1, job.local_world))
+    t0 = time.perf_counter()
+    for i in range(n):
+        if leg == "primary":  # gate, timed region, ingest, one call at a time
+            run_workload(job, args, "gop12", S, np.arange(S), threads, 4, 1, sustained_steps=8)
+        elif leg == "fixed_batch_8192":
+            lo, hi = edist.shard_fixed(job.rank, job.world, args.fixed_batch)
+            run_workload(job, args, "gop12", hi - lo, np.arange(lo, hi), threads, 2, 1, want_serial=False)
+        elif leg == "wide1500k":
+            run_workload(job, args, "wide1500k", S, np.arange(S) % WORKLOADS["wide1500k"][2], threads, 4, 1)
+        elif leg == "vmedia_x1024":
+            run_clip(job, args, "vmedia", S, 2)
+        elif leg == "video_out":
+            args.no_cpu_baseline = True
+            run_video_out(job, args, S)
+        log(f"soak {leg}: {i + 1}/{n} clean, {time.perf_counter() - t0:.1f} s")
+    log(f"SOAK_OK {leg} {n}")
+
+
 def run(job, args):
     from espflix_amd import dist as edist
     rank, world = job.rank, job.world
@@ -802,6 +843,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-baseline-seconds", type=float, default=5.0, help="wall-time target of the CPU baseline leg")
     ap.add_argument("--sustained-steps", type=int, default=1000, help="steps of the sustained leg beside the K timed ones (0: skip)")
     ap.add_argument("--no-overlap", action="store_true", help="synchronise after every step (no cross-step pipelining)")
+    ap.add_argument("--soak", nargs=2, metavar=("LEG", "N"), help=f"repeat one leg N times in this process (legs: {', '.join(SOAK_LEGS)})")
     ap.add_argument("--timed-only", action="store_true",
                     help="profiling aid: skip the ingest and one-call-at-a-time legs so that (nearly) every kernel launch of the "
                          "process belongs to the timed region (serial_* fields then repeat the timed-region figures)")
@@ -833,6 +875,9 @@ def main():
                            max_stream_bytes=max_stream_bytes)
 
     job = Job(rank, world, dist, "cuda", make_decoder, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    if args.soak:
+        soak(job, args)
+        return
     out = run(job, args)
     if rank == 0:
         print(json.dumps(out))

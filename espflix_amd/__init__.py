@@ -23,6 +23,7 @@ STRIPS = 12
 STRIP_BYTES = 8448
 FRAME_BYTES = 101376
 
+OPT_GROUPS, OPT_PARSE_CAP, OPT_RECON_MODE, OPT_RECON_WAVES, OPT_RECON_SPINS, OPT_RECON_ITEMS = 1, 2, 3, 4, 5, 6   # efx_option
 SBC_PROBE_FIRST = 1
 FORMAT_ES = 0
 FORMAT_TS = 1
@@ -34,6 +35,7 @@ STREAM_BAD_VLC = 8
 STREAM_MB_OVERRUN = 16
 STREAM_COEF_OVERRUN = 32
 STREAM_SERIAL_HUNT = 64   # the reference would misread bits between two start codes (its marker hunt is bit-serial): see efx.h
+STREAM_INTERNAL = 256     # never expected: a lost hand-over inside the reconstruction kernel (efx.h)
 STREAM_SLICE_ORDER = 128  # slice start codes of a picture not strictly rising in bitstream order: see efx.h
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -89,6 +91,14 @@ _SYMBOLS = {
     "efx_status_string": (C.c_char_p, [C.c_int]),
     "efx_upload_streams": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t), C.c_int]),
     "efx_download_es": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "efx_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "efx_host_free": (C.c_int, [_P, _P]),
+    "efx_host_register": (C.c_int, [_P, _P, C.c_size_t]),
+    "efx_host_unregister": (C.c_int, [_P, _P]),
+    "efx_stream_layout": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "efx_upload_done": (C.c_int, [_P]),
+    "efx_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
+    "efx_get_option": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
     "efx_reset": (C.c_int, [_P]),
     "efx_erase_frames": (C.c_int, [_P]),
     "efx_play_reset": (C.c_int, [_P]),
@@ -296,6 +306,42 @@ class Decoder:
         _, ptrs, lens, n = prepared
         _check(self._ctx, self._lib.efx_upload_streams(self._ctx, n, ptrs, lens, fmt))
         self.n_streams = n
+
+    # -- in-place ingest (efx_host_alloc / efx_stream_layout / efx_upload_done) ---------------
+    def host_arena(self, nbytes: int) -> np.ndarray:
+        """Page-locked host memory of this context as a uint8 array (freed with the context)."""
+        p = _P()
+        _check(self._ctx, self._lib.efx_host_alloc(self._ctx, nbytes, C.byref(p)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+    def place_in_arena(self, arena: np.ndarray, streams):
+        """Lay a batch out in `arena` the way efx_stream_layout prescribes and return the prepared argument arrays
+        for upload_prepared(): such a batch is transferred straight from the arena, no staging copy."""
+        arrs = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray, memoryview))
+                else np.ascontiguousarray(s, dtype=np.uint8) for s in streams]
+        n = len(arrs)
+        lens = (C.c_size_t * n)(*[a.size for a in arrs])
+        off = (C.c_size_t * (n + 1))()
+        _check(self._ctx, self._lib.efx_stream_layout(n, lens, off))
+        assert off[n] <= arena.size, "arena too small for the batch"
+        base = arena.ctypes.data
+        for a, o in zip(arrs, off):
+            arena[o:o + a.size] = a
+        return arena, (_P * n)(*[base + off[i] for i in range(n)]), lens, n
+
+    def upload_done(self) -> bool:
+        r = self._lib.efx_upload_done(self._ctx)
+        if r < 0:
+            _check(self._ctx, r)
+        return bool(r)
+
+    def set_option(self, option: int, value: int):
+        _check(self._ctx, self._lib.efx_set_option(self._ctx, option, value))
+
+    def get_option(self, option: int) -> int:
+        v = C.c_int()
+        _check(self._ctx, self._lib.efx_get_option(self._ctx, option, C.byref(v)))
+        return v.value
 
     def reset(self):
         _check(self._ctx, self._lib.efx_reset(self._ctx))

@@ -35,6 +35,10 @@ __global__ void k_slice_emit(const PicInfo*, const SliceTmp*, const uint32_t*, c
 __global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const TmTables*, MbRec*, TmU4*, uint32_t*, uint32_t*,
                         int, int);
 __global__ void k_recon(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, const int32_t*, int, int);
+__global__ void k_recon_all(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, const int32_t*, int, int,
+                            int, uint32_t*, uint32_t*, int);
+__global__ void k_recon_all_eager(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, const int32_t*, int,
+                                  int, int, uint32_t*, uint32_t*, int);
 __global__ void k_frame_hash(const uint8_t*, int, uint64_t*);
 __global__ void k_fill(uint32_t*, uint32_t, size_t);
 __global__ void k_composite(const uint8_t*, const VideoTables*, const VideoLineTemplates*, FieldArgs, uint16_t*);
@@ -113,6 +117,13 @@ struct efx_ctx {
         bool demux_timed = false;
     } up[kUploads];
     int cur_up = -1;  // batch the next efx_decode reads
+    // page-locked host arenas the caller lays batches out in (efx_host_alloc / efx_host_register): base, bytes, ours to free
+    struct Arena {
+        uint8_t* base;
+        size_t bytes;
+        bool owned;
+    };
+    std::vector<Arena> arenas;
     hipStream_t copy_stream = nullptr;
     // transient TS staging on the device + the lists of efx_index_streams / efx_demux_audio
     uint8_t* d_ts = nullptr;
@@ -146,6 +157,7 @@ struct efx_ctx {
         int64_t* d_pts = nullptr;    // per (stream, picture): PTS latched at the picture header (TS input); then, per
                                      // stream, the newest PES PTS of the upload (k_index -> k_advance)
         int32_t* d_call_pos = nullptr;  // per stream: ring position of this call's first picture, first picture with a PTS
+        uint32_t* d_recon_sync = nullptr;  // k_recon_all: queue heads [0..7], spins [8], finished items per stream [16 + s]
         hipEvent_t parse_done[kReconMerge] = {}, recon_done = nullptr, wrap_cleared = nullptr;
         int epoch = 0;
         int upload = 0;  // batch this call decoded
@@ -178,6 +190,15 @@ struct efx_ctx {
     VideoLineTemplates* d_video_lines[2] = {nullptr, nullptr};
     SbcTables* d_sbc_tables = nullptr;
     int parse_wg_cap = 0;  // k_parse workgroups resident per parse kernel while reconstruction launches are queued (0: no cap); EFX_PARSE_WG_CAP
+    // launch structure (efx_set_option; the environment variables of the same names, upper case with EFX_, set the defaults)
+    int opt_groups = 0;        // reconstruction groups per call: 0 = one group behind a busy reconstruction stream, groups of
+                               // kGroupStreams streams when it is idle; n >= 1: always n
+    int opt_parse_cap = 0;     // 0 = cap the parse kernel's residency only while reconstruction is queued; 1 always; 2 never
+    int opt_recon_mode = 2;    // 0 = one k_recon launch per picture index; 1 = one persistent k_recon_all per group, a wave
+                               // signals an item when its stores have left; 2 = ... one item later (its wait is free)
+    int opt_recon_waves = 0;   // k_recon_all with opt_recon_items = 0: workgroups per compute unit (0 = 18, what its LDS admits)
+    int opt_recon_items = 16;  // k_recon_all: items a wave takes before it ends (0: until none is left)
+    int n_cus = 256;
     uint32_t* d_sbc_flags = nullptr;  // per stream of an efx_sbc_decode call: 1 = decoded frame-parallel (k_sbc_check)
     SbcState* d_sbc_next = nullptr;   // ... the state its frame-parallel kernel leaves, put in place by k_sbc_commit
     size_t sbc_flags_cap = 0;
@@ -266,10 +287,106 @@ int fail(efx_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
             return fail(ctx, EFX_ERR_DEVICE, #call, e_);           \
     } while (0)
 
+// ---- device memory ------------------------------------------------------------------------------------------------------
+// Product: hipMalloc.  With EFX_GUARD=1 (or 2) in the environment every device buffer of the library -- and every buffer
+// handed out through efx_device_alloc -- is its own virtual-memory mapping (hipMemAddressReserve / hipMemCreate / hipMemMap)
+// that ENDS on the last mapped byte of its range (mode 1; mode 2: starts on the first), with an unmapped page on either
+// side: a kernel that reads or writes one byte too far faults at once ("Memory access fault by GPU", the kernel named
+// under AMD_SERIALIZE_KERNEL=3) instead of quietly touching whatever hipMalloc's pooling put there.  A debugging aid
+// (bench.py --soak, profiles/r5_fault_hunt.md): the kernels' deliberate over-reads -- k_recon's window rows behind the
+// last frame, the parse lanes' read-ahead behind the last stream -- stay inside the slack their buffers are allocated with.
+struct GuardRec {
+    void* va;
+    size_t va_bytes, map_bytes, gran;
+    hipMemGenericAllocationHandle_t handle;
+};
+std::mutex g_guard_lock;
+std::vector<std::pair<void*, GuardRec>> g_guard_recs;
+
+int guard_mode()
+{
+    static const int mode = [] {
+        const char* e = getenv("EFX_GUARD");
+        return e ? atoi(e) : 0;
+    }();
+    return mode;
+}
+
+hipError_t guard_alloc(void** out, size_t bytes)
+{
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess)
+        return e;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess)
+        return e;
+    if (bytes == 0)
+        bytes = 16;
+    GuardRec r{};
+    r.gran = gran;
+    r.map_bytes = (bytes + gran - 1) / gran * gran;
+    r.va_bytes = r.map_bytes + 2 * gran;
+    if ((e = hipMemAddressReserve(&r.va, r.va_bytes, 0, nullptr, 0)) != hipSuccess)
+        return e;
+    if ((e = hipMemCreate(&r.handle, r.map_bytes, &prop, 0)) != hipSuccess) {
+        (void)hipMemAddressFree(r.va, r.va_bytes);
+        return e;
+    }
+    char* base = static_cast<char*>(r.va) + gran;
+    hipMemAccessDesc ad{};
+    ad.location = prop.location;
+    ad.flags = hipMemAccessFlagsProtReadWrite;
+    if ((e = hipMemMap(base, r.map_bytes, 0, r.handle, 0)) != hipSuccess || (e = hipMemSetAccess(base, r.map_bytes, &ad, 1)) != hipSuccess) {
+        (void)hipMemRelease(r.handle);
+        (void)hipMemAddressFree(r.va, r.va_bytes);
+        return e;
+    }
+    // mode 1: the buffer ends with the mapping (256-byte granules keep every alignment the kernels assume)
+    const size_t span = (bytes + 255) & ~(size_t)255;
+    void* p = guard_mode() == 2 ? base : base + (r.map_bytes - span) + (span - ((bytes + 15) & ~(size_t)15));
+    {
+        std::lock_guard<std::mutex> lk(g_guard_lock);
+        g_guard_recs.emplace_back(p, r);
+    }
+    *out = p;
+    return hipSuccess;
+}
+
+hipError_t dev_alloc(void** p, size_t bytes) { return guard_mode() ? guard_alloc(p, bytes) : hipMalloc(p, bytes); }
+
+hipError_t dev_free(void* p)
+{
+    if (!p)
+        return hipSuccess;
+    if (!guard_mode())
+        return hipFree(p);
+    GuardRec r{};
+    {
+        std::lock_guard<std::mutex> lk(g_guard_lock);
+        size_t i = 0;
+        while (i < g_guard_recs.size() && g_guard_recs[i].first != p)
+            i++;
+        if (i == g_guard_recs.size())
+            return hipFree(p);  // (not ours)
+        r = g_guard_recs[i].second;
+        g_guard_recs.erase(g_guard_recs.begin() + (ptrdiff_t)i);
+    }
+    (void)hipDeviceSynchronize();  // hipFree's implicit barrier
+    hipError_t e = hipMemUnmap(static_cast<char*>(r.va) + r.gran, r.map_bytes);
+    hipError_t e2 = hipMemRelease(r.handle);
+    hipError_t e3 = hipMemAddressFree(r.va, r.va_bytes);
+    return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : e3);
+}
+
 template <typename T>
 hipError_t dalloc(T** p, size_t n)
 {
-    return hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
+    return dev_alloc(reinterpret_cast<void**>(p), n * sizeof(T));
 }
 
 int sync_all(efx_ctx* ctx)
@@ -413,6 +530,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         A(dalloc(&sl.d_slice_base, n * P + kMaxGroups));  // (one list per parse half, each with an end entry)
         A(dalloc(&sl.d_descs, n * P * kMaxSlicesPerPicture));
         A(dalloc(&sl.d_call_pos, 2 * n));
+        A(dalloc(&sl.d_recon_sync, 16 + n));
     }
     A(dalloc(&ctx->d_frames, n * D * kFrameBytes + 8192));  // slack: k_recon's window rows may over-read the last frame
     A(dalloc(&ctx->d_video[0], 1));
@@ -432,8 +550,20 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         // 8.57-9.06 (flat between 144 and 192 on one box, best at 176 on another); 96 and below: the parse kernel
         // becomes the critical path.  5-slice pictures (4.4 x the tokens per slice): uncapped 7.21 M, 160: 7.55 M.
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess)
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
             ctx->parse_wg_cap = std::max(1, prop.multiProcessorCount * 5 / 8);
+            ctx->n_cus = std::max(1, prop.multiProcessorCount);
+        }
+        if (const char* v = getenv("EFX_GROUPS"))
+            ctx->opt_groups = atoi(v);
+        if (const char* v = getenv("EFX_FORCE_PARSE_CAP"))
+            ctx->opt_parse_cap = atoi(v);
+        if (const char* v = getenv("EFX_RECON_MODE"))
+            ctx->opt_recon_mode = atoi(v);
+        if (const char* v = getenv("EFX_RECON_WAVES"))
+            ctx->opt_recon_waves = atoi(v);
+        if (const char* v = getenv("EFX_RECON_ITEMS"))
+            ctx->opt_recon_items = atoi(v);
         if (const char* cap = getenv("EFX_PARSE_WG_CAP"))  // (development: 0 = no cap)
             ctx->parse_wg_cap = atoi(cap);
     }
@@ -492,6 +622,12 @@ void efx_destroy(efx_ctx* ctx)
             (void)hipStreamSynchronize(ps);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
+    for (auto& a : ctx->arenas) {
+        if (a.owned)
+            (void)hipHostFree(a.base);
+        else
+            (void)hipHostUnregister(a.base);
+    }
     void* bufs[] = {ctx->d_tables, ctx->d_tm_tables, ctx->d_sbc_flags, ctx->d_sbc_next, ctx->d_state, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0],
                     ctx->d_video_lines[1], ctx->d_hash, ctx->d_ts, ctx->d_sbc_tables, ctx->d_idx_info, ctx->d_ts_off, ctx->d_idx_len,
                     ctx->d_idx_base, ctx->d_idx_seq};
@@ -501,12 +637,12 @@ void efx_destroy(efx_ctx* ctx)
                 (void)hipEventDestroy(ev);
     for (void* b : bufs)
         if (b)
-            (void)hipFree(b);
+            (void)dev_free(b);
     for (auto& u : ctx->up) {
         void* ub[] = {u.d_es, u.d_stream_off, u.d_stream_perm, u.d_ts_len, u.d_pkt_base, u.d_es_len, u.d_pes_count, u.d_pes};
         for (void* b : ub)
             if (b)
-                (void)hipFree(b);
+                (void)dev_free(b);
         if (u.h_es)
             (void)hipHostFree(u.h_es);
         if (u.h_meta)
@@ -520,11 +656,11 @@ void efx_destroy(efx_ctx* ctx)
                 (void)hipEventDestroy(ev);
     }
     for (auto& sl : ctx->slot) {
-        void* sb[] = {sl.d_pic_count, sl.d_status, sl.d_counters, sl.d_mbrecs, sl.d_raw, sl.d_coefs, sl.d_pts, sl.d_call_pos,
+        void* sb[] = {sl.d_pic_count, sl.d_status, sl.d_counters, sl.d_mbrecs, sl.d_raw, sl.d_coefs, sl.d_pts, sl.d_call_pos, sl.d_recon_sync,
                       sl.d_pics,      sl.d_slices_tmp, sl.d_qtab, sl.d_slice_base, sl.d_descs};
         for (void* b : sb)
             if (b)
-                (void)hipFree(b);
+                (void)dev_free(b);
         for (auto ev : sl.parse_done)
             if (ev)
                 (void)hipEventDestroy(ev);
@@ -638,6 +774,16 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
     u.valid = false;
     hipStream_t st = ctx->copy_stream;
     uint8_t* d_dst = is_ts ? ctx->d_ts : u.d_es;
+    // in place: the batch lies in one arena exactly as the device buffer holds it (efx_stream_layout)
+    const uint8_t* arena_src = nullptr;
+    for (const auto& a : ctx->arenas)
+        if (data[0] >= a.base && data[0] + pos <= a.base + a.bytes) {
+            arena_src = data[0];
+            for (int i = 1; i < n_streams && arena_src; i++)
+                if (data[i] != data[0] + stream_off[i])
+                    arena_src = nullptr;
+            break;
+        }
     // small per-stream arrays, pinned: stream_off | perm | ts_len | pkt_base
     uint64_t* m_off = reinterpret_cast<uint64_t*>(u.h_meta);
     uint32_t* m_perm = reinterpret_cast<uint32_t*>(m_off + n_streams + 1);
@@ -668,7 +814,22 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
             }
         }
     };
-    {
+    if (arena_src) {
+        // the gaps of the layout are the library's: end-of-data tail (ES) and zero fill; then ONE transfer from caller memory
+        uint8_t* w = const_cast<uint8_t*>(arena_src);
+        for (int i = 0; i < n_streams; i++) {
+            uint8_t* at = w + stream_off[i];
+            const size_t n = len[i], padded = (size_t)(stream_off[i + 1] - stream_off[i]);
+            if (is_ts)
+                memset(at + n, 0, padded - n);
+            else {
+                memcpy(at + n, tail, kEsTailBytes);
+                memset(at + n + kEsTailBytes, 0, padded - n - kEsTailBytes);
+            }
+        }
+        if (pos)
+            EFX_HIP(hipMemcpyAsync(d_dst, arena_src, pos, hipMemcpyHostToDevice, st));
+    } else {
         unsigned hw = std::thread::hardware_concurrency();
         int groups = pos > ((size_t)4 << 20) ? (int)std::min<unsigned>(8u, std::max(1u, hw / 2)) : 1;
         groups = std::min(groups, n_streams);
@@ -741,6 +902,141 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
     u.valid = true;
     ctx->cur_up = ui;
     return EFX_OK;
+}
+
+int efx_stream_layout(int n_streams, const size_t* len, size_t* offsets)
+{
+    if (n_streams <= 0 || !len || !offsets)
+        return EFX_ERR_ARG;
+    size_t pos = 0;
+    for (int i = 0; i < n_streams; i++) {
+        offsets[i] = pos;
+        pos += (len[i] + kEsTailBytes + 15) & ~(size_t)15;  // (the rule efx_upload_streams places streams by)
+    }
+    offsets[n_streams] = pos;
+    return EFX_OK;
+}
+
+int efx_host_alloc(efx_ctx* ctx, size_t bytes, void** host_ptr)
+{
+    bind_device(ctx);
+    if (!ctx || !host_ptr || !bytes)
+        return EFX_ERR_ARG;
+    void* p = nullptr;
+    EFX_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    ctx->arenas.push_back({static_cast<uint8_t*>(p), bytes, true});
+    *host_ptr = p;
+    return EFX_OK;
+}
+
+int efx_host_register(efx_ctx* ctx, void* host_ptr, size_t bytes)
+{
+    bind_device(ctx);
+    if (!ctx || !host_ptr || !bytes)
+        return EFX_ERR_ARG;
+    EFX_HIP(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault));
+    ctx->arenas.push_back({static_cast<uint8_t*>(host_ptr), bytes, false});
+    return EFX_OK;
+}
+
+static int drop_arena(efx_ctx* ctx, void* host_ptr, bool owned)
+{
+    bind_device(ctx);
+    if (!ctx || !host_ptr)
+        return EFX_ERR_ARG;
+    for (size_t i = 0; i < ctx->arenas.size(); i++)
+        if (ctx->arenas[i].base == host_ptr && ctx->arenas[i].owned == owned) {
+            // a transfer may still be reading it
+            if (ctx->copy_stream)
+                EFX_HIP(hipStreamSynchronize(ctx->copy_stream));
+            ctx->arenas.erase(ctx->arenas.begin() + (ptrdiff_t)i);
+            if (owned)
+                EFX_HIP(hipHostFree(host_ptr));
+            else
+                EFX_HIP(hipHostUnregister(host_ptr));
+            return EFX_OK;
+        }
+    return fail(ctx, EFX_ERR_ARG, owned ? "efx_host_free: not an arena of this context" : "efx_host_unregister: not registered with this context");
+}
+
+int efx_host_free(efx_ctx* ctx, void* host_ptr) { return drop_arena(ctx, host_ptr, true); }
+int efx_host_unregister(efx_ctx* ctx, void* host_ptr) { return drop_arena(ctx, host_ptr, false); }
+
+int efx_upload_done(efx_ctx* ctx)
+{
+    bind_device(ctx);
+    if (!ctx)
+        return EFX_ERR_ARG;
+    if (ctx->cur_up < 0)
+        return 1;
+    hipError_t e = hipEventQuery(ctx->up[ctx->cur_up].uploaded);
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return e == hipSuccess ? 1 : fail(ctx, EFX_ERR_DEVICE, "efx_upload_done", e);
+}
+
+int efx_set_option(efx_ctx* ctx, int option, int value)
+{
+    if (!ctx || value < 0)
+        return EFX_ERR_ARG;
+    switch (option) {
+    case EFX_OPT_GROUPS:
+        if (value > kMaxGroups)
+            return EFX_ERR_ARG;
+        ctx->opt_groups = value;
+        return EFX_OK;
+    case EFX_OPT_PARSE_CAP:
+        if (value > 2)
+            return EFX_ERR_ARG;
+        ctx->opt_parse_cap = value;
+        return EFX_OK;
+    case EFX_OPT_RECON_MODE:
+        if (value > 2)
+            return EFX_ERR_ARG;
+        ctx->opt_recon_mode = value;
+        return EFX_OK;
+    case EFX_OPT_RECON_WAVES:
+        if (value > 64)
+            return EFX_ERR_ARG;
+        ctx->opt_recon_waves = value;
+        return EFX_OK;
+    case EFX_OPT_RECON_ITEMS:
+        ctx->opt_recon_items = value;
+        return EFX_OK;
+    default:
+        return EFX_ERR_ARG;
+    }
+}
+
+int efx_get_option(efx_ctx* ctx, int option, int* value)
+{
+    bind_device(ctx);
+    if (!ctx || !value)
+        return EFX_ERR_ARG;
+    switch (option) {
+    case EFX_OPT_GROUPS: *value = ctx->opt_groups; return EFX_OK;
+    case EFX_OPT_PARSE_CAP: *value = ctx->opt_parse_cap; return EFX_OK;
+    case EFX_OPT_RECON_MODE: *value = ctx->opt_recon_mode; return EFX_OK;
+    case EFX_OPT_RECON_WAVES: *value = ctx->opt_recon_waves; return EFX_OK;
+    case EFX_OPT_RECON_ITEMS: *value = ctx->opt_recon_items; return EFX_OK;
+    case EFX_OPT_RECON_SPINS: {
+        int r = sync_all(ctx);
+        if (r)
+            return r;
+        uint32_t total = 0;
+        for (int g = 0; g < ctx->n_groups && ctx->decoded; g++) {
+            uint32_t v = 0;
+            EFX_HIP(hipMemcpy(&v, ctx->slot[ctx->groups[g].slot].d_recon_sync + 8, sizeof(v), hipMemcpyDeviceToHost));
+            total += v;
+        }
+        *value = (int)std::min<uint32_t>(total, 0x7FFFFFFFu);
+        return EFX_OK;
+    }
+    default:
+        return EFX_ERR_ARG;
+    }
 }
 
 int efx_download_es(efx_ctx* ctx, int stream, uint8_t* dst, size_t cap, size_t* es_len)
@@ -848,7 +1144,9 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
     // group g + 1 beside the reconstruction of group g.  Results do not depend on the split.
     const bool idle_at_call = !(ctx->last_recon_done && hipEventQuery(ctx->last_recon_done) == hipErrorNotReady);
     (void)hipGetLastError();  // (hipErrorNotReady is not an error)
-    const int G = idle_at_call ? group_count(n_all) : 1;
+    // (efx_set_option pins the structure: the same call sequence then runs the same launches whatever the timing)
+    const int G = ctx->opt_groups > 0 ? std::min(std::min(ctx->opt_groups, kMaxGroups), std::max(1, n_all / 8))
+                                      : (idle_at_call ? group_count(n_all) : 1);
     hipStream_t sr = ctx->stream;
     int timing_slot = -1;
     if (ctx->timing && !ctx->timing_ring.empty()) {
@@ -919,7 +1217,8 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
             // The cap protects the reconstruction launches the parser runs beside.  When the reconstruction stream has
             // nothing queued at this moment -- one call at a time, the first call after a synchronisation -- the parser
             // may have the chip: 0.84 instead of 1.38 ms per 1024 streams x 12 pictures.
-            const bool recon_busy = ctx->last_recon_done && hipEventQuery(ctx->last_recon_done) == hipErrorNotReady;
+            const bool recon_busy = ctx->opt_parse_cap == 1 ||
+                                    (ctx->opt_parse_cap == 0 && ctx->last_recon_done && hipEventQuery(ctx->last_recon_done) == hipErrorNotReady);
             (void)hipGetLastError();  // (hipErrorNotReady is not an error)
             if (ctx->parse_wg_cap > 0 && recon_busy)
                 parse_wgs = std::min(parse_wgs, ctx->parse_wg_cap);
@@ -942,9 +1241,25 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
         hipLaunchKernelGGL(k_advance, dim3((rn + 255) / 256), dim3(256), 0, sr, ctx->d_state, sl.d_pic_count,
                            u.ts_input ? sl.d_pts : nullptr, u.ts_input ? sl.d_pts + (size_t)ctx->cfg.max_streams * P : nullptr, rs0, rn,
                            P, sl.d_call_pos);
-        for (int p = 0; p < n_pictures; p++)
-            hipLaunchKernelGGL(k_recon, dim3(rn, (kMbCount * 6 + 63) / 64), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs,
-                               ctx->d_tables->scan, sl.d_qtab, ctx->d_frames, P, D, p, sl.d_call_pos, sl.epoch, rs0);
+        constexpr int kGroupsPerPicture = (kMbCount * 6 + 63) / 64;
+        if (ctx->opt_recon_mode == 0) {
+            for (int p = 0; p < n_pictures; p++)
+                hipLaunchKernelGGL(k_recon, dim3(rn, kGroupsPerPicture), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs,
+                                   ctx->d_tables->scan, sl.d_qtab, ctx->d_frames, P, D, p, sl.d_call_pos, sl.epoch, rs0);
+        } else if (rn > 0) {
+            // ONE launch for all picture indices of the group: persistent waves pull (picture, stream, block group) items in
+            // picture-major order; a per-stream counter of finished items orders a picture behind its predecessor (k_recon.hip)
+            EFX_HIP(hipMemsetAsync(sl.d_recon_sync, 0, (16 + (size_t)rn) * sizeof(uint32_t), sr));
+            // A wave takes opt_recon_items items and ends, so that wave slots (and their LDS) keep coming free for the parse
+            // kernel of the next call; with 0 the grid is what the chip holds and the waves live until the last item.
+            const long long items = (long long)rn * kGroupsPerPicture * n_pictures;
+            const int per_cu = ctx->opt_recon_waves > 0 ? ctx->opt_recon_waves : 18;
+            const long long waves = ctx->opt_recon_items > 0 ? (items + ctx->opt_recon_items - 1) / ctx->opt_recon_items
+                                                             : std::min<long long>(items, (long long)ctx->n_cus * per_cu);
+            hipLaunchKernelGGL(ctx->opt_recon_mode == 2 ? k_recon_all : k_recon_all_eager, dim3((unsigned)waves), dim3(64), 0, sr, sl.d_mbrecs,
+                               sl.d_coefs, ctx->d_tables->scan, sl.d_qtab, ctx->d_frames, P, D, n_pictures, sl.d_call_pos, sl.epoch, rs0, rn,
+                               sl.d_recon_sync, sl.d_status, ctx->opt_recon_items);
+        }
         if (te0)
             EFX_HIP(hipEventRecord(te0->ev[3], sr));
         EFX_HIP(hipEventRecord(sl.recon_done, sr));
@@ -1259,7 +1574,7 @@ int efx_demux_audio(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, const
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);  // the host staging buffer and d_out_off are free again
-    (void)hipFree(d_out_off);
+    (void)dev_free(d_out_off);
     if (e != hipSuccess)
         return fail(ctx, EFX_ERR_DEVICE, "efx_demux_audio", e);
     return EFX_OK;
@@ -1306,7 +1621,7 @@ int efx_index_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, con
     uint32_t* d_samples = nullptr;
     EFX_HIP(dalloc(&d_samples, (size_t)n_streams * samples_cap));
     auto done = [&](int code) {
-        (void)hipFree(d_samples);
+        (void)dev_free(d_samples);
         return code;
     };
     hipError_t e = hipMemcpyAsync(ctx->d_ts, h_stage, pos, hipMemcpyHostToDevice, st);
@@ -1434,9 +1749,9 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
     // -- a rejected frame re-synthesises its predecessor's samples: a chain -- the one-wave-per-stream kernel
     if ((size_t)n_streams > ctx->sbc_flags_cap) {
         if (ctx->d_sbc_flags)
-            (void)hipFree(ctx->d_sbc_flags);
+            (void)dev_free(ctx->d_sbc_flags);
         if (ctx->d_sbc_next)
-            (void)hipFree(ctx->d_sbc_next);
+            (void)dev_free(ctx->d_sbc_next);
         ctx->d_sbc_flags = nullptr;
         ctx->d_sbc_next = nullptr;
         ctx->sbc_flags_cap = 0;
@@ -1543,7 +1858,7 @@ int efx_device_alloc(efx_ctx* ctx, size_t bytes, void** dptr)
     bind_device(ctx);
     if (!ctx || !dptr)
         return EFX_ERR_ARG;
-    EFX_HIP(hipMalloc(dptr, bytes));
+    EFX_HIP(dev_alloc(dptr, bytes));
     return EFX_OK;
 }
 
@@ -1552,7 +1867,7 @@ int efx_device_free(efx_ctx* ctx, void* dptr)
     bind_device(ctx);
     if (!ctx)
         return EFX_ERR_ARG;
-    EFX_HIP(hipFree(dptr));
+    EFX_HIP(dev_free(dptr));
     return EFX_OK;
 }
 

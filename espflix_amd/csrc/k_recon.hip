@@ -124,9 +124,7 @@ constexpr int kBlocksPerPicture = kMbCount * 6;
 constexpr int kLaneDwords = 33, kLaneData = 32;  // per-lane LDS block: 64 int16 + one dword (see k_recon)
 constexpr int kLaneHalfwords = 2 * kLaneDwords;
 
-// grid = (streams, 25): blockIdx.x = stream, blockIdx.y = group of 64 consecutive 8x8 blocks of the
-// picture in plane-row order (see below); ONE LANE PER BLOCK.  With a stream count that
-// is a multiple of 8 all blocks of a stream are dispatched to XCD (stream % 8).
+// One lane per 8x8 block, 64 consecutive blocks of a picture (in plane-row order, see below) per wave.
 //
 // The previous mapping (one wave per macroblock, 48 of 64 lanes in the butterflies, transposition
 // through LDS) was bound by VALU issue.  Here a lane owns a whole block: it dequantises its own
@@ -135,63 +133,71 @@ constexpr int kLaneHalfwords = 2 * kLaneDwords;
 // 2-D IDCT in registers, forms the prediction of its 8 x 8 pixels from nine 12-byte row fetches and
 // stores eight 8-byte rows.  No lane ever waits for another: no barrier, no shuffle, no scalar
 // bookkeeping, every lane busy.
-__global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, const uint32_t* __restrict__ coefs,
-                                              const uint32_t* __restrict__ scan_tab,
-                                              const uint32_t* __restrict__ qtab_custom, uint8_t* __restrict__ frames,
-                                              int max_pictures, int ring_depth, int pic, const int32_t* __restrict__ call_pos,
-                                              int epoch, int stream0)
-{
-    // 8640 bytes of LDS per wave (18 waves per CU; the 91 registers allow 20).  Per lane 33 dwords: 64 int16
-    // coefficients and, in the 33rd (which makes the stride odd: lanes fan out over the banks), entry `lane` of the
-    // default scan / quantiser table; the wave's prefix counts for the owner search; 64 bytes of per-block flags.
-    // What else a lane needs to know about another lane's block (first entry, quantiser) is fetched from that lane's
-    // registers (ds_bpermute).  Measured: this layout at 16 / 18 / 19 waves per CU 8.07 / 8.16 / 7.85 M frames/s
-    // (19 with the search through ds_bpermute as well), the previous one (9.7 KB, 16 waves) 7.78.
-    __shared__ uint32_t lds[64 * kLaneDwords + 32 + 16];
-    int16_t* const cfh = reinterpret_cast<int16_t*>(lds);
-    uint16_t* const s_pre = reinterpret_cast<uint16_t*>(lds + 64 * kLaneDwords);  // entries before the block in the wave
-    uint8_t* const s_zd = reinterpret_cast<uint8_t*>(lds + 64 * kLaneDwords + 32);  // bit 7: an entry sits at scan position 0;
-                                                                                    // bits 0-5: intra DC value >> 16
+//
+// kShared = the frames this wave reads were written, and the frames it writes will be read, by OTHER workgroups of the
+// SAME launch (k_recon_all): every frame access is then a write-through / L1-bypassing `sc1` buffer access (a CU's vector
+// L1 is never refreshed by another CU's stores and the XCDs' L2s are not coherent with each other:
+// MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"); the hand-over itself is the
+// per-stream counter of k_recon_all.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+constexpr int kAuxSc1 = 16;  // cache policy of the raw buffer builtins on gfx950: sc1
 
-    const int lane = threadIdx.x;
-    const int s = stream0 + blockIdx.x;
-    // (one record per wave, placed by launch: the ring holds ten launches of 512 streams)
-    EFX_PROBE_CLAIM_AT(2, blockIdx.x * gridDim.y + blockIdx.y,
-                       ((long long)(epoch & 0xFF) * 16 + pic) * (gridDim.x * gridDim.y) + blockIdx.x * gridDim.y + blockIdx.y,
-                       (unsigned)(epoch & 0xFF));
-    EFX_PROBE_STAMP(1);
-    EFX_PROBE_CYCLES_BEGIN();
-    EFX_PROBE_SET(6, (unsigned long long)pic | (unsigned long long)(epoch & 0xFF) << 8 | (unsigned long long)stream0 << 16);
-    const int b_raw = blockIdx.y * 64 + lane;
-    const bool have = b_raw < kBlocksPerPicture;
-    const int b = have ? b_raw : kBlocksPerPicture - 1;
+// which block of the picture lane `lane` of block group `g` owns: macroblock, block inside it
+struct BlockAt {
+    bool have;
+    int blk, mb;
+};
+__device__ __forceinline__ BlockAt block_at(int g, int lane)
+{
+    const int b_raw = g * 64 + lane;
+    BlockAt o;
+    o.have = b_raw < kBlocksPerPicture;
+    const int b = o.have ? b_raw : kBlocksPerPicture - 1;
     // Block order inside a picture: by macroblock row, and inside it by plane row -- the 44 upper luma
     // blocks, the 44 lower ones, the 22 "cr" and the 22 "cb" blocks -- so that the lanes of a wave
     // write (and mostly read) long contiguous runs of every frame row they touch.
     const int mbrow = b / 132, rr = b - mbrow * 132;
-    int blk, mbx;
+    int mbx;
     if (rr < 88) {
         const int h = rr >= 44, r2 = rr - 44 * h;
-        blk = 2 * h + (r2 & 1);
+        o.blk = 2 * h + (r2 & 1);
         mbx = r2 >> 1;
     } else {
         const int h = rr >= 110;
-        blk = 4 + h;
+        o.blk = 4 + h;
         mbx = rr - 88 - 22 * h;
     }
-    const int mb = mbrow * kMbW + mbx;
+    o.mb = mbrow * kMbW + mbx;
+    return o;
+}
+
+template <bool kShared, class PreStore>
+__device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const uint32_t* __restrict__ coefs,
+                                            const uint32_t* __restrict__ qt_custom, uint8_t* __restrict__ frames, int ring_depth,
+                                            int pic, int pos0, int first_pts, int epoch, int s, int g, const uint4 rw,
+                                            PreStore&& pre_store)
+{
+    int16_t* const cfh = reinterpret_cast<int16_t*>(lds);
+    uint16_t* const s_pre = reinterpret_cast<uint16_t*>(lds + 64 * kLaneDwords);  // entries before the block in the wave
+    uint8_t* const s_zd = reinterpret_cast<uint8_t*>(lds + 64 * kLaneDwords + 32);  // bit 7: an entry sits at scan position 0;
+                                                                                    // bits 0-5: intra DC value >> 16
+    const int lane = threadIdx.x;
+    const BlockAt at = block_at(g, lane);
+    const bool have = at.have;
+    const int blk = at.blk, mb = at.mb;
     // ring position of this picture (k_advance): the reference's _current / _reference alternation, player.cpp:692-702
-    const int pos0 = call_pos[2 * s], first_pts = call_pos[2 * s + 1];
     const uint32_t q = (uint32_t)pos0 + (uint32_t)(first_pts < 0 ? pic + 1 : max(0, pic - first_pts));
     const uint32_t cur_slot = q % (uint32_t)ring_depth, ref_slot = (q - 1) % (uint32_t)ring_depth;
-    uint8_t* cur = frames + ((size_t)s * ring_depth + cur_slot) * kFrameBytes;
-    const uint8_t* ref = frames + ((size_t)s * ring_depth + ref_slot) * kFrameBytes;
+    uint8_t* const ring = frames + (size_t)s * ring_depth * kFrameBytes;  // the stream's frames (wave-uniform)
+    uint8_t* cur = ring + (size_t)cur_slot * kFrameBytes;
+    const uint8_t* ref = ring + (size_t)ref_slot * kFrameBytes;
+    // (kShared) the stream's ring as a buffer: offsets are 32-bit, the cache policy rides on the instruction.  The range
+    // includes the slack behind the last frame that the window rows may over-read (the pool ends with it).
+    const __amdgpu_buffer_rsrc_t ring_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(ring, 0, (int)(ring_depth * kFrameBytes + 8192), 0x00020000);
+    const uint32_t cur_off = cur_slot * (uint32_t)kFrameBytes, ref_off = ref_slot * (uint32_t)kFrameBytes;
 
-    // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
-    lds[lane * kLaneDwords + kLaneData] = scan_tab[lane];
-    const uint32_t* const qt_custom = qtab_custom + ((size_t)s * max_pictures + pic) * 64;  // (read only where a record says "custom")
-
-    const uint4 rw = *reinterpret_cast<const uint4*>(mbrecs + ((size_t)s * max_pictures + pic) * kMbCount + mb);
     const uint32_t w_base = rw.x, w_cnt = rw.y, w_misc = rw.z, w_mv = rw.w;
     EFX_PROBE_STAMP_AFTER(3, w_base);  // the record has arrived
     // a macroblock no slice covers (or an absent picture) keeps the slot's content
@@ -244,10 +250,17 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
 #pragma unroll
             for (int r = 0; r < 9; r++) {
                 const uint32_t off = off0 + (uint32_t)(r * kStride) + ((uint32_t)r >= jump ? 8u * kStride : 0u);
-                const uint32_t* p = reinterpret_cast<const uint32_t*>(ref + off);
-                wa[r] = p[0];
-                wb[r] = p[1];
-                wc[r] = p[2];
+                if constexpr (kShared) {
+                    const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(ring_rsrc, (int)(ref_off + off), 0, kAuxSc1);
+                    wa[r] = v.x;
+                    wb[r] = v.y;
+                    wc[r] = v.z;
+                } else {
+                    const uint32_t* p = reinterpret_cast<const uint32_t*>(ref + off);
+                    wa[r] = p[0];
+                    wb[r] = p[1];
+                    wc[r] = p[2];
+                }
             }
         }
     } else {
@@ -255,13 +268,18 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         // builds its window pixel by pixel with clamped coordinates -- identical to the direct fetch
         // for the windows that are inside -- through its private LDS block (not yet in use)
         uint32_t* w32 = reinterpret_cast<uint32_t*>(mine);
+#pragma unroll 1
         for (int i = 0; i < 27; i++) {
             const int r = i / 3, d = i - r * 3;
             uint32_t word = 0;
             if (want)
+#pragma unroll 1
                 for (int k = 0; k < 4; k++) {
                     const int yy = clampi(py0 + r, 0, ph - 1), xx = clampi((px0 & ~3) + d * 4 + k, 0, pw - 1);
-                    word |= (uint32_t)ref[row_off(yy) + xx] << (k * 8);
+                    const uint32_t o = (uint32_t)(row_off(yy) + xx);
+                    const uint32_t byte = kShared ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(ring_rsrc, (int)(ref_off + o), 0, kAuxSc1)
+                                                  : (uint32_t)ref[o];
+                    word |= (byte & 0xFF) << (k * 8);
                 }
             w32[i] = word;
         }
@@ -510,6 +528,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     uint32_t flat4 = (uint32_t)(v[0] >> 8);  // intra DC-only block: replicated exactly as copy_block_dc does, unclamped and
     flat4 |= flat4 << 8;                      // unmasked (player.cpp:1175-1187)
     flat4 |= flat4 << 16;
+    pre_store();  // (k_recon_all: the place where the previous item's stores are known to have left)
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint32_t p_lo = pr_lo[r], p_hi = pr_hi[r];
@@ -527,11 +546,250 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         // prediction only (skipped macroblock, block without coefficients) / intra DC-only replica / the clamped sum
         const uint32_t lo = clamped ? w[0] : flat4;
         const uint32_t hi = clamped ? w[1] : flat4;
-        if (stored)
-            *reinterpret_cast<uint2*>(cur + dst0 + r * kStride) = make_uint2(lo, hi);
+        if (stored) {
+            if constexpr (kShared) {
+                const u32x2 v = {lo, hi};
+                __builtin_amdgcn_raw_buffer_store_b64(v, ring_rsrc, (int)(cur_off + (uint32_t)(dst0 + r * kStride)), 0, kAuxSc1);
+            } else
+                *reinterpret_cast<uint2*>(cur + dst0 + r * kStride) = make_uint2(lo, hi);
+        }
     }
+}
+
+// ---- one launch per picture index -------------------------------------------------------------------------------------------
+// grid = (streams, 25): blockIdx.x = stream, blockIdx.y = group of 64 consecutive 8x8 blocks.  With a stream count that is a
+// multiple of 8 all blocks of a stream are dispatched to XCD (stream % 8).  A P picture needs the previous picture of its
+// own stream: the launch boundary is the dependency.
+__global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, const uint32_t* __restrict__ coefs,
+                                              const uint32_t* __restrict__ scan_tab,
+                                              const uint32_t* __restrict__ qtab_custom, uint8_t* __restrict__ frames,
+                                              int max_pictures, int ring_depth, int pic, const int32_t* __restrict__ call_pos,
+                                              int epoch, int stream0)
+{
+    // 8640 bytes of LDS per wave (18 waves per CU; the 91 registers allow 20).  Per lane 33 dwords: 64 int16
+    // coefficients and, in the 33rd (which makes the stride odd: lanes fan out over the banks), entry `lane` of the
+    // default scan / quantiser table; the wave's prefix counts for the owner search; 64 bytes of per-block flags.
+    // What else a lane needs to know about another lane's block (first entry, quantiser) is fetched from that lane's
+    // registers (ds_bpermute).  Measured: this layout at 16 / 18 / 19 waves per CU 8.07 / 8.16 / 7.85 M frames/s
+    // (19 with the search through ds_bpermute as well), the previous one (9.7 KB, 16 waves) 7.78.
+    __shared__ uint32_t lds[64 * kLaneDwords + 32 + 16];
+    const int lane = threadIdx.x;
+    const int s = stream0 + blockIdx.x;
+    // (one record per wave, placed by launch: the ring holds ten launches of 512 streams)
+    EFX_PROBE_CLAIM_AT(2, blockIdx.x * gridDim.y + blockIdx.y,
+                       ((long long)(epoch & 0xFF) * 16 + pic) * (gridDim.x * gridDim.y) + blockIdx.x * gridDim.y + blockIdx.y,
+                       (unsigned)(epoch & 0xFF));
+    EFX_PROBE_STAMP(1);
+    EFX_PROBE_CYCLES_BEGIN();
+    EFX_PROBE_SET(6, (unsigned long long)pic | (unsigned long long)(epoch & 0xFF) << 8 | (unsigned long long)stream0 << 16);
+    // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
+    lds[lane * kLaneDwords + kLaneData] = scan_tab[lane];
+    const BlockAt at = block_at(blockIdx.y, lane);
+    const uint4 rw = *reinterpret_cast<const uint4*>(mbrecs + ((size_t)s * max_pictures + pic) * kMbCount + at.mb);
+    EFX_PROBE_STAMP_AFTER(3, rw.x);  // the record has arrived
+    recon_group<false>(lds, coefs, qtab_custom + ((size_t)s * max_pictures + pic) * 64, frames, ring_depth, pic, call_pos[2 * s],
+                       call_pos[2 * s + 1], epoch, s, blockIdx.y, rw, [] {});
     EFX_PROBE_STAMP(4);
     EFX_PROBE_CYCLES_END(2);
+}
+
+// ---- all pictures of a decode call in ONE launch ----------------------------------------------------------------------------
+// The per-picture launches above each pay one wave life of filling and draining (a launch of waves that live 10 us costs
+// its work plus about 10 us: 12 x that per call, profiles/r4_ablations.md section 2), and every wave starts with an exposed
+// round trip for its macroblock record.  Here the waves are persistent: the grid is what the chip holds, and a wave pulls
+// ITEMS -- (picture, stream, group of 64 blocks) -- off a counter until none is left.
+//   * Order: picture-major, so the item a P picture depends on -- the same stream's previous picture, all 25 groups of it --
+//     was handed out a whole picture's worth of items earlier.  What orders them is a per-stream counter of finished items:
+//     a wave polls done[s] >= 25 * picture (one relaxed sc1 load, issued an item ahead; a spin only near the end of
+//     small batches), and adds 1 when its stores have left (s_waitcnt vmcnt(0), then one relaxed agent-scope atomic).
+//     A wave only ever waits for items handed out BEFORE its own, each of which is in the hands of a running wave: no
+//     cycle, whatever the residency and whatever else shares the chip.
+//   * Eight queues, one per XCD: queue x holds the streams stream0 + x + 8 j, and a wave serves the queue of the XCD it runs
+//     on (HW_REG_XCC_ID) until that is empty, then helps the next one -- a stream's frames stay in one L2, and eight heads
+//     take the dequeue traffic (one head saturates at ~88 per us: MI355X_MICROARCH.md, "dequeue").  Placement is for speed
+//     only: every frame access is sc1 on both sides (recon_group<true>), correct wherever an item runs.
+//   * A wave works one item ahead of itself: the next item's index was claimed, its macroblock record and its stream's
+//     counter requested, before the current item's first instruction -- the record's round trip (1.5 of a wave's 10.6 us
+//     under load) is off the chain, and so are the dequeue and the poll.
+// sync: [0..7] queue heads, [8] debugging (spins), [16 + stream] finished items of the stream; zeroed by the host before
+// every launch.  Restates, for a whole call, the order MpegDecoder::run() gives one stream: picture after picture
+// (player.cpp:692-702).
+constexpr int kGroupsPerPicture = (kBlocksPerPicture + 63) / 64;  // 25
+constexpr uint32_t kSyncHeads = 0, kSyncSpins = 8, kSyncAbort = 9, kSyncDone = 16;
+
+struct ItemAt {
+    int pic, s, g;
+};
+
+template <bool kDeferSignal>
+__device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const MbRec* __restrict__ mbrecs,
+                                               const uint32_t* __restrict__ coefs, const uint32_t* __restrict__ scan_tab,
+                                               const uint32_t* __restrict__ qtab_custom, uint8_t* __restrict__ frames,
+                                               int max_pictures, int ring_depth, int n_pictures,
+                                               const int32_t* __restrict__ call_pos, int epoch, int stream0, int n_streams,
+                                               uint32_t* __restrict__ sync, uint32_t* __restrict__ status, int max_items)
+{
+    const int lane = threadIdx.x;
+    lds[lane * kLaneDwords + kLaneData] = scan_tab[lane];  // (once per wave: the items leave the 33rd dword alone)
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    // queue q: streams stream0 + q + 8 j, j < per_queue(q); its items in picture-major order, streams fastest
+    auto per_queue = [&](uint32_t q) { return (uint32_t)(n_streams > (int)q ? (n_streams - (int)q + 7) >> 3 : 0); };
+    auto items_of = [&](uint32_t q) { return per_queue(q) * (uint32_t)(kGroupsPerPicture * n_pictures); };
+    uint32_t q = xcc & 7, visited = 0;
+    auto decode = [&](uint32_t qq, uint32_t idx) {
+        const uint32_t nq = per_queue(qq), per_pic = nq * kGroupsPerPicture;
+        const uint32_t p = idx / per_pic, rem = idx - p * per_pic, g = rem / nq, j = rem - g * nq;
+        return ItemAt{(int)p, stream0 + (int)(qq + 8 * j), (int)g};
+    };
+    // a returning agent-scope add on the queue head, by lane 0; the value is waited for where it is used
+    auto claim_issue = [&](uint32_t qq) {
+        uint32_t v = 0;
+        if (lane == 0)
+            v = __hip_atomic_fetch_add(sync + kSyncHeads + qq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    };
+    // (rare: the end of a queue) walk the queues until one hands out an item; false when all eight are empty
+    auto claim_walk = [&](uint32_t& idx) {
+        while (visited < 8) {
+            idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)claim_issue(q));
+            if (idx < items_of(q))
+                return true;
+            q = (q + 1) & 7;
+            visited++;
+        }
+        return false;
+    };
+    auto record_of = [&](const ItemAt& it) {
+        const BlockAt at = block_at(it.g, lane);
+        return *reinterpret_cast<const uint4*>(mbrecs + ((size_t)it.s * max_pictures + it.pic) * kMbCount + at.mb);
+    };
+    auto done_of = [&](const ItemAt& it) {
+        return __hip_atomic_load(sync + kSyncDone + (uint32_t)(it.s - stream0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto signal = [&](int s_done) {
+        // the stores of the item have left the wave ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... one more finished item of its stream
+        if (lane == 0)
+            __hip_atomic_fetch_add(sync + kSyncDone + (uint32_t)(s_done - stream0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+
+    // A wave takes at most `max_items` items and ends (0: as many as there are): the grid is then items / max_items
+    // workgroups and wave slots keep coming free -- a grid of waves that live for the whole call would hold every CU's LDS
+    // until its last item, and the parse kernel of the NEXT call (which must run beside this one, efx_api.hip) would find no
+    // room.  An item that has been claimed is always processed: the claim for the item after the next goes out only while
+    // the budget has room for it.
+    uint32_t budget = max_items > 0 ? (uint32_t)max_items : 0xFFFFFFFFu;
+    uint32_t idx_a = 0;
+    if (!claim_walk(idx_a))
+        return;
+    budget--;
+    ItemAt a = decode(q, idx_a);
+    uint32_t q_b = q;
+    bool pending_b = budget > 0;
+    uint32_t claim_b = pending_b ? claim_issue(q_b) : 0u;  // the item after: resolved at the top of the loop
+    uint4 rw_a = record_of(a);
+    uint32_t done_a = done_of(a);
+    int pending_signal = -1;  // (kDeferSignal) stream of the item whose stores are still on their way
+    for (;;) {
+        // ---- the next item: index, record, its stream's counter -- all in flight under this item's work -------------------
+        bool have_b = false;
+        uint32_t idx_b = 0;
+        if (pending_b) {
+            idx_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)claim_b);
+            have_b = idx_b < items_of(q);
+            if (!have_b) {  // this queue is empty: on to the next ones
+                q = (q + 1) & 7;
+                visited++;
+                have_b = claim_walk(idx_b);
+            }
+        }
+        ItemAt b = a;
+        uint4 rw_b = rw_a;
+        uint32_t done_b = 0;
+        if (have_b) {
+            budget--;
+            b = decode(q, idx_b);
+            q_b = q;
+            pending_b = budget > 0;
+            if (pending_b)
+                claim_b = claim_issue(q_b);
+            rw_b = record_of(b);
+            done_b = done_of(b);
+        }
+        // ---- this item's predecessor: every group of the stream's previous pictures is in memory ---------------------------
+        const uint32_t need = (uint32_t)(kGroupsPerPicture * a.pic);
+        uint32_t seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)done_a);
+        if (seen < need) {
+            // (the tail of a small batch: the predecessor is still in the hands of another wave)
+            uint32_t spins = 0;
+            bool abort = false;
+            do {
+                __builtin_amdgcn_s_sleep(8);
+                seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)done_of(a));
+                if ((++spins & 1023) == 0)
+                    abort = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(sync + kSyncAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
+            } while (seen < need && !abort && spins < (1u << 19));
+            if (seen < need && lane == 0) {
+                // never observed: a lost hand-over must not hang the device -- the stream is flagged, every other wait of the
+                // launch gives up at its next look, the call ends
+                atomicOr(status + a.s, EFX_STREAM_INTERNAL);
+                __hip_atomic_store(sync + kSyncAbort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0)
+                __hip_atomic_fetch_add(sync + kSyncSpins, spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        recon_group<true>(lds, coefs, qtab_custom + ((size_t)a.s * max_pictures + a.pic) * 64, frames, ring_depth, a.pic,
+                          call_pos[2 * a.s], call_pos[2 * a.s + 1], epoch, a.s, a.g, rw_a, [&] {
+                              if constexpr (kDeferSignal) {
+                                  // Just before this item's first store: every load of this item has been consumed long ago
+                                  // (the wait costs nothing), and memory operations complete in the order they were issued
+                                  // -- so the PREVIOUS item's stores have left.  Its signal goes out here, a whole item
+                                  // late (its successor is a picture's worth of items away), instead of at its own end,
+                                  // where the wave would sit out the stores' round trip.
+                                  if (pending_signal >= 0)
+                                      signal(pending_signal);
+                              }
+                          });
+        if constexpr (kDeferSignal)
+            pending_signal = a.s;
+        else
+            signal(a.s);
+        if (!have_b)
+            break;
+        a = b;
+        rw_a = rw_b;
+        done_a = done_b;
+    }
+    if constexpr (kDeferSignal)
+        if (pending_signal >= 0)
+            signal(pending_signal);
+}
+
+#ifndef EFX_RECON_ALL_WAVES
+#define EFX_RECON_ALL_WAVES 5
+#endif
+// (two kernels, not one with a flag: the body is 20 KB of code either way)
+__global__ __launch_bounds__(64, EFX_RECON_ALL_WAVES) void k_recon_all(
+    const MbRec* __restrict__ mbrecs, const uint32_t* __restrict__ coefs, const uint32_t* __restrict__ scan_tab,
+    const uint32_t* __restrict__ qtab_custom, uint8_t* __restrict__ frames, int max_pictures, int ring_depth, int n_pictures,
+    const int32_t* __restrict__ call_pos, int epoch, int stream0, int n_streams, uint32_t* __restrict__ sync,
+    uint32_t* __restrict__ status, int max_items)
+{
+    __shared__ uint32_t lds[64 * kLaneDwords + 32 + 16];
+    recon_all_body<true>(lds, mbrecs, coefs, scan_tab, qtab_custom, frames, max_pictures, ring_depth, n_pictures, call_pos, epoch,
+                         stream0, n_streams, sync, status, max_items);
+}
+__global__ __launch_bounds__(64, EFX_RECON_ALL_WAVES) void k_recon_all_eager(
+    const MbRec* __restrict__ mbrecs, const uint32_t* __restrict__ coefs, const uint32_t* __restrict__ scan_tab,
+    const uint32_t* __restrict__ qtab_custom, uint8_t* __restrict__ frames, int max_pictures, int ring_depth, int n_pictures,
+    const int32_t* __restrict__ call_pos, int epoch, int stream0, int n_streams, uint32_t* __restrict__ sync,
+    uint32_t* __restrict__ status, int max_items)
+{
+    __shared__ uint32_t lds[64 * kLaneDwords + 32 + 16];
+    recon_all_body<false>(lds, mbrecs, coefs, scan_tab, qtab_custom, frames, max_pictures, ring_depth, n_pictures, call_pos, epoch,
+                          stream0, n_streams, sync, status, max_items);
 }
 
 // FNV-1a-64 of whole ring frames, one lane per frame (verification helper, not on the timed path)

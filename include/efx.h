@@ -65,6 +65,9 @@ typedef enum efx_status {
                                          of them is also damaged or short -- the parity claim does not cover a stream with \
                                          this bit */
 
+#define EFX_STREAM_INTERNAL 256u      /* never expected: a reconstruction wave gave up waiting for the stream's previous picture \
+                                         (k_recon_all's hand-over counter) -- the stream's frames are not to be trusted */
+
 typedef enum efx_format {
     EFX_FORMAT_ES = 0, /* raw ISO 11172-2 video elementary stream */
     EFX_FORMAT_TS = 1  /* 188-byte transport packets, video on PID 0x100 (src/player.cpp:381-493);
@@ -108,6 +111,28 @@ const char* efx_status_string(int status);
  * batch, so ingest and decode of consecutive batches overlap.  efx_decode decodes the batch uploaded
  * last. */
 int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, const size_t* len, int format);
+
+/* In-place ingest: the reference's contract is "the caller owns the Buffer, the decoder reads it where it lies"
+ * (class Buffer, src/streamer.h:139-143; filled by the app in decode_next, src/espflix.cpp:723-737, read by
+ * MpegDecoder::more, src/player.cpp:459-493).  Its batch form: an ARENA of page-locked, device-visible host memory
+ * (efx_host_alloc, or the caller's own memory made so by efx_host_register) in which the caller lays the streams of
+ * a batch out the way the device buffer holds them -- stream i at offsets[i] of efx_stream_layout(), i.e. 16-byte
+ * aligned starts with room behind every stream for the end-of-data tail.  efx_upload_streams recognises such a batch
+ * (every data[i] == data[0] + offsets[i], all of it inside one arena): it writes the tails and the zero fill INTO the gaps
+ * the layout leaves (the only bytes of the arena the library ever writes), and the H2D transfer reads the caller's
+ * memory directly -- no staging copy, one transfer.  The caller keeps ownership throughout and must leave the batch's
+ * bytes alone until efx_upload_done() says the transfer no longer reads them; any other pointer pattern takes the
+ * staged path above. */
+int efx_host_alloc(efx_ctx* ctx, size_t bytes, void** host_ptr);
+int efx_host_free(efx_ctx* ctx, void* host_ptr);
+int efx_host_register(efx_ctx* ctx, void* host_ptr, size_t bytes);
+int efx_host_unregister(efx_ctx* ctx, void* host_ptr);
+/* offsets[0 .. n_streams]: where stream i of the given lengths starts inside an arena (offsets[0] = 0), offsets[n_streams] =
+ * bytes the batch occupies.  Host only. */
+int efx_stream_layout(int n_streams, const size_t* len, size_t* offsets);
+/* 1: the most recent efx_upload_streams no longer reads caller memory (always so for the staged path once the call has
+ * returned); 0: its transfer is still in flight; negative: error. */
+int efx_upload_done(efx_ctx* ctx);
 /* The elementary stream the decoder sees for `stream` (what MpegDecoder::more() feeds the bit
  * reader, src/player.cpp:459-493), without the end-of-data tail: *es_len receives its length,
  * up to `cap` bytes are copied to dst (dst may be NULL when cap is 0). */
@@ -301,6 +326,23 @@ typedef struct efx_timing {
  * enabling (again) starts a new averaging window. */
 int efx_set_timing(efx_ctx* ctx, int enable);
 int efx_get_timing(efx_ctx* ctx, efx_timing* out);
+
+/* Launch structure.  Results never depend on it; by default part of it follows what the GPU is doing when a call is
+ * queued (a call that finds the reconstruction stream idle is split into groups and its parse kernel is not capped), so the
+ * same call sequence can run as different launches from run to run.  Benchmarks and tests pin it. */
+typedef enum efx_option {
+    EFX_OPT_GROUPS = 1,      /* reconstruction groups per efx_decode: 0 = automatic (above), n >= 1 = always n */
+    EFX_OPT_PARSE_CAP = 2,   /* k_parse's residency cap: 0 = only while reconstruction is queued, 1 = always, 2 = never */
+    EFX_OPT_RECON_MODE = 3,  /* 0 = one k_recon launch per picture index; 1 = one persistent launch per group (k_recon_all), an
+                                item signalled when its stores have left; 2 = ... signalled one item later (default) */
+    EFX_OPT_RECON_WAVES = 4, /* k_recon_all with EFX_OPT_RECON_ITEMS = 0: workgroups (waves) per compute unit; 0 = default (18) */
+    EFX_OPT_RECON_ITEMS = 6, /* k_recon_all: items -- (picture, stream, 64 blocks) -- a wave takes before it ends and frees its
+                                slot (default 16); 0 = as many as there are (a grid of what the chip holds) */
+    EFX_OPT_RECON_SPINS = 5  /* read only: polls the reconstruction waves of the most recent call spent waiting for a predecessor
+                                picture (synchronises) */
+} efx_option;
+int efx_set_option(efx_ctx* ctx, int option, int value);
+int efx_get_option(efx_ctx* ctx, int option, int* value);
 
 /* -- several devices of one node ----------------------------------------------------------------- */
 /* The reference decodes one stream on one core; its batch form here shards by STREAM and nothing else (SURVEY.md 8e,
