@@ -532,13 +532,24 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
 
     dec.upload(streams, 0)  # bitstreams resident in HBM from here on
     dec.set_timing(True)
+    # The launch structure is pinned for the timed steps (efx_set_option): one reconstruction group per call and a parse
+    # kernel that keeps to its residency cap -- what back-to-back calls run as anyway, except that the FIRST call after a
+    # synchronisation finds the GPU idle and would be split and uncapped: K calls, one structure, per-launch figures exact.
+    pinned = hasattr(dec, "set_option") and not args.no_overlap
+    if pinned:
+        import espflix_amd as efx
+        dec.set_option(efx.OPT_GROUPS, 1)
+        dec.set_option(efx.OPT_PARSE_CAP, 1)
     elapsed = timed_region(job, dec, steps, warmup, overlap=not args.no_overlap)
     t = dec.timing()
     stage_ms = np.array([t.index_ms, t.parse_ms, t.recon_ms])
     timed_calls = t.timed_calls
-    groups = max(1, int(getattr(t, "groups", 1)))  # reconstruction groups: one k_recon launch per group and picture index
+    groups = max(1, int(getattr(t, "groups", 1)))  # reconstruction groups of a call
     halves = max(1, int(getattr(t, "parse_halves", groups)))  # parse halves: one k_index ... k_parse sequence each
-    if getattr(t, "mixed", 0):
+    # reconstruction kernel launches per call: one k_recon per group and picture index, or one k_recon_all per group
+    recon_launches = int(getattr(t, "recon_launches", 0)) or P * groups
+    mixed = int(getattr(t, "mixed", 0))
+    if mixed:
         log("warning: the timed calls did not all run with the same launch structure: per-launch figures are approximate")
 
     # the double buffer now holds pictures P-2 and P-1 of every stream: compare them with the reference again
@@ -578,29 +589,47 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
     # into the bitstream buffer the running decode does not read) and decodes it; upload n+1 overlaps decode n
     ingest = None
     if want_serial and not args.timed_only:
-        prep = dec.prepare_upload(streams)
         isteps = max(4, min(steps, 20))
-        for _ in range(2):
-            dec.upload_prepared(prep, 0)
-            dec.decode(sync=False)
-        dec.sync()
-        job.barrier()
-        t0 = time.perf_counter()
-        for _ in range(isteps):
-            dec.upload_prepared(prep, 0)
-            dec.decode(sync=False)
-        dec.sync()
-        job.barrier()
-        dt = edist.max_over_ranks(time.perf_counter() - t0, job.dist, job.device)
-        hashes = dec.frame_hashes()
-        for p in (P - 2, P - 1):
-            if p >= 0 and not np.array_equal(hashes[:, dec.picture_slot(p)], got[:, p]):
-                raise SystemExit(f"parity gate ({workload}, ingest leg): picture {p} differs from the reference decoder")
-        ingest = {"pcie_inclusive_frames_per_s": totals[0] * isteps / dt, "ms_per_step": dt / isteps * 1e3, "steps": isteps,
-                  "what": "efx_upload_streams from pageable host buffers (threaded staging copy into pinned memory, H2D on the "
-                          "copy stream) + efx_decode per step, two bitstream buffers: the upload of step n+1 runs under the "
-                          "decode of step n"}
 
+        def ingest_leg(prep, what):
+            for _ in range(2):
+                dec.upload_prepared(prep, 0)
+                dec.decode(sync=False)
+            dec.sync()
+            job.barrier()
+            t0 = time.perf_counter()
+            for _ in range(isteps):
+                dec.upload_prepared(prep, 0)
+                dec.decode(sync=False)
+            dec.sync()
+            job.barrier()
+            dt = edist.max_over_ranks(time.perf_counter() - t0, job.dist, job.device)
+            hashes = dec.frame_hashes()
+            for p in (P - 2, P - 1):
+                if p >= 0 and not np.array_equal(hashes[:, dec.picture_slot(p)], got[:, p]):
+                    raise SystemExit(f"parity gate ({workload}, ingest leg, {what}): picture {p} differs from the reference decoder")
+            return {"pcie_inclusive_frames_per_s": totals[0] * isteps / dt, "ms_per_step": dt / isteps * 1e3}
+
+        # (a) in place: the batch lies in a page-locked arena of the context in the device layout (efx_host_alloc,
+        # efx_stream_layout) and every step's H2D reads it where it lies -- a service that receives into such memory pays PCIe
+        # and nothing else; (b) the staged path: pageable buffers copied into the library's pinned staging memory first
+        ingest = {"steps": isteps}
+        if hasattr(dec, "host_arena"):
+            arena = dec.host_arena(es_bytes + 32 * S + 4096)
+            ingest.update(ingest_leg(dec.place_in_arena(arena, streams), "in place"))
+            ingest["what"] = ("efx_upload_streams of a batch that lies in page-locked caller memory in the device layout (efx_host_alloc + "
+                              "efx_stream_layout): ONE H2D per step straight from the caller's bytes on the copy stream, no staging copy; "
+                              "+ efx_decode per step, two bitstream buffers: the upload of step n+1 runs under the decode of step n")
+            ingest["staged_from_pageable_memory"] = ingest_leg(dec.prepare_upload(streams), "staged")
+            ingest["staged_from_pageable_memory"]["what"] = ("the same from pageable host buffers: threaded staging copy into the library's "
+                                                             "pinned memory, then H2D")
+        else:
+            ingest.update(ingest_leg(dec.prepare_upload(streams), "staged"))
+            ingest["what"] = "efx_upload_streams + efx_decode per step"
+
+    if pinned:
+        dec.set_option(efx.OPT_GROUPS, 0)
+        dec.set_option(efx.OPT_PARSE_CAP, 0)
     serial_ms = None
     if want_serial and args.timed_only:
         serial_ms = [float(x) for x in stage_ms]
@@ -617,6 +646,7 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
         csum = int(np.bitwise_xor.reduce(chains * edist.GOLDEN)) if chains.size else 0
     return {"workload": workload, "S": S, "P": P, "es_bytes": es_bytes, "n_i": n_i, "n_p": n_p, "elapsed": elapsed,
             "stage_ms": stage_ms, "serial_ms": serial_ms, "timed_calls": timed_calls, "groups": groups, "halves": halves, "n_coefs": int(n_coefs),
+            "recon_launches": recon_launches, "mixed": mixed, "pinned": bool(pinned),
             "gen_seconds": t_gen, "batch0": batches[0][1], "ingest": ingest, "sustained": sustained, "job_pictures": totals[0], "job_es_bytes": totals[1],
             "checksum": csum, "streams_checked": int(chains.size), "first_id": int(ids[0]), "last_id": int(ids[-1])}
 
@@ -763,13 +793,17 @@ def run(job, args):
     # The roofline object is k_recon's: it is the kernel that moves SURVEY 8d's algorithmic bytes (the
     # frames); k_parse, which only reads the bitstream and writes 4 B per coefficient + 16 B per
     # macroblock, is reported next to it.
-    # libefx runs a call as G groups of streams, one k_recon launch per group and picture index: P * G launches per step
+    # libefx runs a call as G groups of streams; a group is reconstructed by ONE launch (k_recon_all: every picture index, the
+    # pictures of a stream ordered by a per-stream counter) or by one k_recon launch per picture index (EFX_OPT_RECON_MODE 0)
     G = r["groups"]
-    alg_launch = alg / (P * G)
-    dur_s = stage_ms[2] / 1e3 / (P * G)
+    L = r.get("recon_launches") or P * G
+    recon_kernel = "k_recon_all" if L == G else "k_recon"
+    names[2] = f"{recon_kernel} x{L // G}" if L == G else names[2]
+    alg_launch = alg / L
+    dur_s = stage_ms[2] / 1e3 / L
     achieved = alg_launch / dur_s / 1e9
     parse_bytes = r["es_bytes"] + 4 * r["n_coefs"] + 16 * S * P * 264
-    traffic, traffic_src = pmc_traffic("efx::k_recon", S, P)
+    traffic, traffic_src = pmc_traffic("efx::" + recon_kernel, S, P)
     ptraffic, _ = pmc_traffic("efx::k_parse", S, P)
     serial_ms = r["serial_ms"]
     out = {
@@ -784,8 +818,9 @@ def run(job, args):
         "roofline": {"bound": "hbm", "limiter": "25 600 waves per launch living 10.6 us each (record 1.5 us -> owner search, entry loads, dequantisation 5.9 us -> IDCT, sum, stores 2.8 us) at 14 resident per CU alone and 10.8 beside the parser, plus one wave life of fill and drain per launch; with all pixel and coefficient traffic removed a launch still takes 53 of 81 us (instruction issue); profiles/r4_ablations.md, DESIGN.md section 6", "kernel": names[2], "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": alg_launch, "avg_launch_ms": dur_s * 1e3, "launches_per_step": P * G,
-                     "streams_per_launch": S // G,
+                     "algorithmic_bytes_per_launch": alg_launch, "avg_launch_ms": dur_s * 1e3, "launches_per_step": L,
+                     "streams_per_launch": S // G, "pictures_per_launch": P * G // L,
+                     "launch_structure": {"pinned": r.get("pinned", False), "mixed": r.get("mixed", 0), "groups": G, "parse_halves": r["halves"]},
                      "whole_step_achieved_GBs": alg / (r["elapsed"] / steps) / 1e9,
                      "whole_step_frac": alg / (r["elapsed"] / steps) / 1e9 / HBM_PEAK_GBS,
                      "stage_ms": dict(zip(names, [float(x) for x in stage_ms])),
@@ -865,6 +900,18 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: espflix_amd has no CPU path")
     torch.cuda.set_device(local_rank)
+    # one process per GPU: this rank's threads (and the pinned staging memory its decoder contexts will first touch) go to the
+    # NUMA node its device hangs off -- at 8 ranks per node the ingest leg is a host-memory problem (espflix_amd/dist.py)
+    numa = None
+    if os.environ.get("EFX_NUMA", "1") != "0":
+        try:
+            from espflix_amd import dist as edist
+            pr = torch.cuda.get_device_properties(local_rank)
+            bus = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            numa = dict(edist.bind_rank_to_device_node(bus), pci=bus)
+            log(f"NUMA: device {local_rank} at {bus}: {numa}")
+        except Exception as e:  # (placement is for speed only)
+            log(f"NUMA: not bound ({e})")
     dist = None
     if world > 1 or os.environ.get("EFX_BENCH_FORCE_DIST"):  # (the variable: the RCCL code path with a single rank, for testing)
         import torch.distributed as dist
@@ -880,6 +927,7 @@ def main():
         return
     out = run(job, args)
     if rank == 0:
+        out["config"]["numa"] = numa
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:

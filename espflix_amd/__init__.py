@@ -79,7 +79,7 @@ class _Timing(C.Structure):
     _fields_ = [("index_ms", C.c_float), ("parse_ms", C.c_float), ("recon_ms", C.c_float), ("total_ms", C.c_float),
                 ("pictures", C.c_uint64), ("slices", C.c_uint64), ("coefficients", C.c_uint64), ("es_bytes", C.c_uint64),
                 ("demux_ms", C.c_float), ("timed_calls", C.c_uint32), ("ts_bytes", C.c_uint64), ("groups", C.c_uint32),
-                ("parse_halves", C.c_uint16), ("mixed", C.c_uint16)]
+                ("parse_halves", C.c_uint16), ("mixed", C.c_uint16), ("recon_launches", C.c_uint32)]
 
 
 # every symbol include/efx.h declares: (name, restype, argtypes)
@@ -97,6 +97,7 @@ _SYMBOLS = {
     "efx_host_unregister": (C.c_int, [_P, _P]),
     "efx_stream_layout": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "efx_upload_done": (C.c_int, [_P]),
+    "efx_debug_poke": (C.c_int, [_P, _P, C.c_size_t, C.c_longlong]),
     "efx_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
     "efx_get_option": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
     "efx_reset": (C.c_int, [_P]),
@@ -130,6 +131,9 @@ _SYMBOLS = {
     "efx_set_timing": (C.c_int, [_P, C.c_int]),
     "efx_get_timing": (C.c_int, [_P, C.POINTER(_Timing)]),
     "efx_partition_first": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "efx_numa_node_of_pci": (C.c_int, [C.c_char_p]),
+    "efx_numa_cpus_of_node": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "efx_numa_bind_thread": (C.c_int, [C.c_int]),
     "efx_multi_create": (C.c_int, [C.POINTER(_Config), C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
     "efx_multi_destroy": (None, [_P]),
     "efx_multi_device_count": (C.c_int, [_P]),
@@ -228,6 +232,7 @@ class Timing:
     groups: int = 1  # reconstruction groups of the newest call: one k_recon launch per group and picture index
     parse_halves: int = 1  # parse halves of the newest call (side by side on the parse streams)
     mixed: int = 0   # 1: the averaged calls did not all run with that structure
+    recon_launches: int = 0  # reconstruction kernel launches of the newest call (groups x pictures, or groups with k_recon_all)
 
 
 class DeviceBuffer:
@@ -493,13 +498,29 @@ class Decoder:
         t = _Timing()
         _check(self._ctx, self._lib.efx_get_timing(self._ctx, C.byref(t)))
         return Timing(t.index_ms, t.parse_ms, t.recon_ms, t.total_ms, t.pictures, t.slices, t.coefficients, t.es_bytes,
-                      t.demux_ms, t.ts_bytes, t.timed_calls, max(1, t.groups), max(1, t.parse_halves), t.mixed)
+                      t.demux_ms, t.ts_bytes, t.timed_calls, max(1, t.groups), max(1, t.parse_halves), t.mixed, t.recon_launches)
 
 
 def partition_first(total: int, parts: int, part: int) -> int:
     """First stream of part `part` when `total` streams are dealt to `parts` devices (efx_partition_first): stream k lives on
     device floor(k * parts / total).  Host-only."""
     return load_library().efx_partition_first(total, parts, part)
+
+
+def numa_node_of_pci(bus_id: str) -> int:
+    """NUMA node sysfs publishes for a PCI device (efx_numa_node_of_pci; -1: unknown).  Host-only."""
+    return load_library().efx_numa_node_of_pci(bus_id.encode())
+
+
+def numa_cpus_of_node(node: int):
+    buf = (C.c_int * 4096)()
+    n = load_library().efx_numa_cpus_of_node(node, buf, 4096)
+    return [buf[i] for i in range(min(n, 4096))]
+
+
+def numa_bind_thread(node: int) -> int:
+    """Bind the calling thread to the CPUs of `node` that it may already use; returns how many (0: mask left alone)."""
+    return load_library().efx_numa_bind_thread(node)
 
 
 class MultiDecoder:

@@ -184,6 +184,7 @@ struct efx_ctx {
     uint64_t subcalls = 0;     // reconstruction groups launched so far: group k uses slot k % kSlots
     uint64_t parse_calls = 0;  // parse halves launched so far: half k runs on parse stream k % kParseStreams
     uint8_t timing_groups[kTimingRing] = {};    // parse halves of the timed call
+    uint16_t timing_launches[kTimingRing] = {};  // reconstruction kernel launches of the timed call
     uint16_t timing_leaders[kTimingRing] = {};  // bit h: half h is the first of its reconstruction group (carries ev[3], ev[4])
     hipStream_t parse_streams[kParseStreams] = {};
     VideoTables* d_video[2] = {nullptr, nullptr};  // [0] PAL, [1] NTSC
@@ -307,7 +308,11 @@ int guard_mode()
 {
     static const int mode = [] {
         const char* e = getenv("EFX_GUARD");
-        return e ? atoi(e) : 0;
+        const int m = e ? atoi(e) : 0;
+        if (m)
+            fprintf(stderr, "libefx: EFX_GUARD=%d -- every device buffer is its own mapping between two unmapped pages (%s-aligned)\n", m,
+                    m == 2 ? "start" : "end");
+        return m;
     }();
     return mode;
 }
@@ -1153,6 +1158,7 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
         timing_slot = (int)(ctx->timed_calls++ % kTimingRing);
         ctx->timing_groups[timing_slot] = (uint8_t)G;
         ctx->timing_leaders[timing_slot] = 0;
+        ctx->timing_launches[timing_slot] = (uint16_t)(((G + kReconMerge - 1) / kReconMerge) * (ctx->opt_recon_mode == 0 ? n_pictures : 1));
     }
     ctx->last_upload = ctx->cur_up;
     ctx->last_n_streams = u.n_streams;
@@ -1833,7 +1839,8 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out)
         if (k == 0) {  // the launch structure of the newest call
             t.groups = (uint32_t)n_leaders;
             t.parse_halves = (uint32_t)G;
-        } else if (t.groups != (uint32_t)n_leaders || t.parse_halves != (uint32_t)G)
+            t.recon_launches = ctx->timing_launches[call];
+        } else if (t.groups != (uint32_t)n_leaders || t.parse_halves != (uint32_t)G || t.recon_launches != ctx->timing_launches[call])
             t.mixed = 1;
     }
     t.timed_calls = (uint32_t)n_timed;
@@ -1852,6 +1859,21 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out)
     return EFX_OK;
 }
 
+
+// EFX_GUARD's own check (tools/guard_selftest.py): one word written `offset_bytes` past the end (or, negative, before the
+// start) of a device buffer.  Under the guard-page allocator a positive offset of 16 or more (the end alignment) faults;
+// without it the write lands in whatever lies there -- never call this outside that test.
+int efx_debug_poke(efx_ctx* ctx, void* dptr, size_t bytes, long long offset_bytes)
+{
+    bind_device(ctx);
+    if (!ctx || !dptr)
+        return EFX_ERR_ARG;
+    char* at = offset_bytes >= 0 ? static_cast<char*>(dptr) + ((bytes + 15) & ~(size_t)15) + offset_bytes : static_cast<char*>(dptr) + offset_bytes;
+    hipLaunchKernelGGL(k_fill, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<uint32_t*>(at), 0xDEADBEEFu, (size_t)1);
+    EFX_HIP(hipGetLastError());
+    EFX_HIP(hipStreamSynchronize(ctx->stream));
+    return EFX_OK;
+}
 
 int efx_device_alloc(efx_ctx* ctx, size_t bytes, void** dptr)
 {

@@ -3,7 +3,12 @@
 // single-device caller would make it do, through the same C-ABI.
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -32,8 +37,66 @@ struct efx_multi {
 
 namespace {
 
+// ---- NUMA placement of a device's host side ---------------------------------------------------------------------------------
+// At eight devices per node the ingest path is a host-memory problem: every context stages (or reads in place) tens of
+// megabytes per step, and a staging buffer or a worker thread on the other socket pays the inter-socket link twice.  The
+// kernel publishes a PCI device's node in sysfs; the thread that drives a device (and therefore first-touches its pinned
+// staging memory) is bound to that node's CPUs before it creates the context.  EFX_SYSFS_ROOT relocates the tree
+// (tests/test_numa.py runs this against a fake one), EFX_NUMA=0 turns the binding off.
+std::string sysfs_root()
+{
+    const char* r = getenv("EFX_SYSFS_ROOT");
+    return r ? std::string(r) : std::string();
+}
+
+bool read_line(const std::string& path, std::string* out)
+{
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f)
+        return false;
+    char buf[4096];
+    const bool ok = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!ok)
+        return false;
+    size_t n = strlen(buf);
+    while (n && (buf[n - 1] == '\n' || buf[n - 1] == ' '))
+        buf[--n] = 0;
+    *out = buf;
+    return true;
+}
+
+// "0-15,32-47" -> cpu numbers
+std::vector<int> parse_cpulist(const std::string& s)
+{
+    std::vector<int> out;
+    const char* p = s.c_str();
+    while (*p) {
+        char* e = nullptr;
+        long a = strtol(p, &e, 10);
+        if (e == p)
+            break;
+        long b = a;
+        p = e;
+        if (*p == '-') {
+            b = strtol(p + 1, &e, 10);
+            p = e;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            out.push_back((int)c);
+        if (*p == ',')
+            p++;
+    }
+    return out;
+}
+
 void worker_main(efx_multi::Worker* w)
 {
+    if (!(getenv("EFX_NUMA") && atoi(getenv("EFX_NUMA")) == 0)) {
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, w->device) == hipSuccess)
+            (void)efx_numa_bind_thread(efx_numa_node_of_pci(bus));
+    }
     (void)hipSetDevice(w->device);  // the HIP context of this thread: every efx_* call on w->ctx runs here
     std::unique_lock<std::mutex> lk(w->mu);
     for (;;) {
@@ -77,6 +140,56 @@ int fan_out(efx_multi* m, const std::function<int(int, efx_multi::Worker*)>& f)
 }  // namespace
 
 extern "C" {
+
+int efx_numa_node_of_pci(const char* pci_bus_id)
+{
+    if (!pci_bus_id || !*pci_bus_id)
+        return -1;
+    std::string id(pci_bus_id);
+    for (char& c : id)
+        c = (char)tolower((unsigned char)c);
+    if (id.size() == 7)  // "c1:00.0" -> "0000:c1:00.0"
+        id = "0000:" + id;
+    std::string line;
+    if (!read_line(sysfs_root() + "/sys/bus/pci/devices/" + id + "/numa_node", &line))
+        return -1;
+    return atoi(line.c_str());  // (-1 on single-node machines)
+}
+
+int efx_numa_cpus_of_node(int node, int* cpus, int cap)
+{
+    if (node < 0)
+        return 0;
+    std::string line;
+    if (!read_line(sysfs_root() + "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", &line))
+        return 0;
+    const std::vector<int> v = parse_cpulist(line);
+    for (size_t i = 0; i < v.size() && cpus && (int)i < cap; i++)
+        cpus[i] = v[i];
+    return (int)v.size();
+}
+
+int efx_numa_bind_thread(int node)
+{
+    int cpus[CPU_SETSIZE];
+    const int n = efx_numa_cpus_of_node(node, cpus, CPU_SETSIZE);
+    if (n <= 0)
+        return 0;
+    // only CPUs this thread may use already (a container's cpuset): an empty intersection leaves the mask alone
+    cpu_set_t now, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof now, &now) != 0)
+        return 0;
+    int kept = 0;
+    for (int i = 0; i < n && i < CPU_SETSIZE; i++)
+        if (CPU_ISSET(cpus[i], &now)) {
+            CPU_SET(cpus[i], &want);
+            kept++;
+        }
+    if (!kept || sched_setaffinity(0, sizeof want, &want) != 0)
+        return 0;
+    return kept;
+}
 
 int efx_partition_first(int total, int parts, int part)
 {

@@ -139,6 +139,15 @@ constexpr int kLaneHalfwords = 2 * kLaneDwords;
 // L1 is never refreshed by another CU's stores and the XCDs' L2s are not coherent with each other:
 // MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"); the hand-over itself is the
 // per-stream counter of k_recon_all.
+#ifndef EFX_RECON_STORE
+#define EFX_RECON_STORE 0  // k_recon (one launch per picture index): plain 8-byte row stores
+#endif
+#ifndef EFX_RA_LOAD
+#define EFX_RA_LOAD 1      // k_recon_all: sc1 loads of the reference frame
+#endif
+#ifndef EFX_RA_STORE
+#define EFX_RA_STORE 2     // k_recon_all: sc1 16-byte stores by lane pairs
+#endif
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 constexpr int kAuxSc1 = 16;  // cache policy of the raw buffer builtins on gfx950: sc1
@@ -172,7 +181,12 @@ __device__ __forceinline__ BlockAt block_at(int g, int lane)
     return o;
 }
 
-template <bool kShared, class PreStore>
+// kLoad: 0 = plain loads of the reference frame, 1 = sc1 buffer loads (bypass this CU's L1).
+// kStore: 0 = plain 8-byte row stores, 1 = the same as sc1 (write-through) stores, 2 = sc1 16-byte stores: the lanes of a wave
+// come in pairs that own horizontally adjacent blocks (even lane: the left / even one), so the pair's two 8-byte row segments are
+// one aligned 16-byte unit -- the even lane stores rows 0-3 of both blocks, the odd lane rows 4-7 (a write-through store is one
+// fabric write whatever its size: per byte an 8-byte one costs 2.7 x a 16-byte one, MI355X_MICROARCH.md), 3 = plain 16-byte.
+template <int kLoad, int kStore, class PreStore>
 __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const uint32_t* __restrict__ coefs,
                                             const uint32_t* __restrict__ qt_custom, uint8_t* __restrict__ frames, int ring_depth,
                                             int pic, int pos0, int first_pts, int epoch, int s, int g, const uint4 rw,
@@ -250,7 +264,7 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
 #pragma unroll
             for (int r = 0; r < 9; r++) {
                 const uint32_t off = off0 + (uint32_t)(r * kStride) + ((uint32_t)r >= jump ? 8u * kStride : 0u);
-                if constexpr (kShared) {
+                if constexpr (kLoad == 1) {
                     const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(ring_rsrc, (int)(ref_off + off), 0, kAuxSc1);
                     wa[r] = v.x;
                     wb[r] = v.y;
@@ -277,8 +291,8 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
                 for (int k = 0; k < 4; k++) {
                     const int yy = clampi(py0 + r, 0, ph - 1), xx = clampi((px0 & ~3) + d * 4 + k, 0, pw - 1);
                     const uint32_t o = (uint32_t)(row_off(yy) + xx);
-                    const uint32_t byte = kShared ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(ring_rsrc, (int)(ref_off + o), 0, kAuxSc1)
-                                                  : (uint32_t)ref[o];
+                    const uint32_t byte = kLoad == 1 ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(ring_rsrc, (int)(ref_off + o), 0, kAuxSc1)
+                                                     : (uint32_t)ref[o];
                     word |= (byte & 0xFF) << (k * 8);
                 }
             w32[i] = word;
@@ -529,6 +543,7 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
     flat4 |= flat4 << 8;                      // unmasked (player.cpp:1175-1187)
     flat4 |= flat4 << 16;
     pre_store();  // (k_recon_all: the place where the previous item's stores are known to have left)
+    uint32_t out_lo[8], out_hi[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint32_t p_lo = pr_lo[r], p_hi = pr_hi[r];
@@ -544,14 +559,52 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
             w[h] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 0x06040200u);
         }
         // prediction only (skipped macroblock, block without coefficients) / intra DC-only replica / the clamped sum
-        const uint32_t lo = clamped ? w[0] : flat4;
-        const uint32_t hi = clamped ? w[1] : flat4;
-        if (stored) {
-            if constexpr (kShared) {
-                const u32x2 v = {lo, hi};
-                __builtin_amdgcn_raw_buffer_store_b64(v, ring_rsrc, (int)(cur_off + (uint32_t)(dst0 + r * kStride)), 0, kAuxSc1);
-            } else
-                *reinterpret_cast<uint2*>(cur + dst0 + r * kStride) = make_uint2(lo, hi);
+        out_lo[r] = clamped ? w[0] : flat4;
+        out_hi[r] = clamped ? w[1] : flat4;
+        if constexpr (kStore < 2) {
+            if (stored) {
+                if constexpr (kStore == 1) {
+                    const u32x2 o2 = {out_lo[r], out_hi[r]};
+                    __builtin_amdgcn_raw_buffer_store_b64(o2, ring_rsrc, (int)(cur_off + (uint32_t)(dst0 + r * kStride)), 0, kAuxSc1);
+                } else
+                    *reinterpret_cast<uint2*>(cur + dst0 + r * kStride) = make_uint2(out_lo[r], out_hi[r]);
+            }
+        }
+    }
+    if constexpr (kStore >= 2) {
+        // lanes 2k, 2k + 1 own the left and the right half of a 16-byte aligned unit of every row they write (block_at: luma
+        // blocks alternate left / right, chroma blocks run along the macroblock row and a row of them starts on an even lane)
+        const bool odd = lane & 1;
+        const bool partner_stored = __builtin_amdgcn_update_dpp(0, (int)stored, 0xB1, 0xF, 0xF, false) != 0;  // quad_perm [1,0,3,2]
+        const bool both = stored && partner_stored;
+        const uint32_t unit0 = cur_off + (uint32_t)dst0 - (odd ? 8u : 0u) + (odd ? 4u * kStride : 0u);  // first row this lane stores
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // what the partner needs from this lane: the even lane's rows 4-7, the odd lane's rows 0-3
+            const uint32_t give_lo = odd ? out_lo[k] : out_lo[4 + k], give_hi = odd ? out_hi[k] : out_hi[4 + k];
+            const uint32_t got_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give_lo, 0xB1, 0xF, 0xF, false);
+            const uint32_t got_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give_hi, 0xB1, 0xF, 0xF, false);
+            const uint32_t own_lo = odd ? out_lo[4 + k] : out_lo[k], own_hi = odd ? out_hi[4 + k] : out_hi[k];
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 unit = {odd ? got_lo : own_lo, odd ? got_hi : own_hi, odd ? own_lo : got_lo, odd ? own_hi : got_hi};
+            if (both) {
+                if constexpr (kStore == 2)
+                    __builtin_amdgcn_raw_buffer_store_b128(unit, ring_rsrc, (int)(unit0 + (uint32_t)(k * kStride)), 0, kAuxSc1);
+                else
+                    *reinterpret_cast<uint4*>(ring + unit0 + (uint32_t)(k * kStride)) = make_uint4(unit.x, unit.y, unit.z, unit.w);
+            }
+        }
+        if (__any(stored && !partner_stored)) {  // (damaged or incomplete pictures only: a block whose neighbour is not written)
+            if (stored && !partner_stored) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const u32x2 o2 = {out_lo[r], out_hi[r]};
+                    if constexpr (kStore == 2)
+                        __builtin_amdgcn_raw_buffer_store_b64(o2, ring_rsrc, (int)(cur_off + (uint32_t)(dst0 + r * kStride)), 0, kAuxSc1);
+                    else
+                        *reinterpret_cast<uint2*>(cur + dst0 + r * kStride) = make_uint2(out_lo[r], out_hi[r]);
+                }
+            }
         }
     }
 }
@@ -587,7 +640,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     const BlockAt at = block_at(blockIdx.y, lane);
     const uint4 rw = *reinterpret_cast<const uint4*>(mbrecs + ((size_t)s * max_pictures + pic) * kMbCount + at.mb);
     EFX_PROBE_STAMP_AFTER(3, rw.x);  // the record has arrived
-    recon_group<false>(lds, coefs, qtab_custom + ((size_t)s * max_pictures + pic) * 64, frames, ring_depth, pic, call_pos[2 * s],
+    recon_group<0, EFX_RECON_STORE>(lds, coefs, qtab_custom + ((size_t)s * max_pictures + pic) * 64, frames, ring_depth, pic, call_pos[2 * s],
                        call_pos[2 * s + 1], epoch, s, blockIdx.y, rw, [] {});
     EFX_PROBE_STAMP(4);
     EFX_PROBE_CYCLES_END(2);
@@ -722,7 +775,14 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
         const uint32_t need = (uint32_t)(kGroupsPerPicture * a.pic);
         uint32_t seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)done_a);
         if (seen < need) {
-            // (the tail of a small batch: the predecessor is still in the hands of another wave)
+            // (the tail of a small batch: the predecessor is still in the hands of another wave -- or of THIS one: the item
+            // whose signal is still held back may be what this item waits for)
+            if constexpr (kDeferSignal) {
+                if (pending_signal >= 0) {
+                    signal(pending_signal);
+                    pending_signal = -1;
+                }
+            }
             uint32_t spins = 0;
             bool abort = false;
             do {
@@ -740,7 +800,7 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
             if (lane == 0)
                 __hip_atomic_fetch_add(sync + kSyncSpins, spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        recon_group<true>(lds, coefs, qtab_custom + ((size_t)a.s * max_pictures + a.pic) * 64, frames, ring_depth, a.pic,
+        recon_group<EFX_RA_LOAD, EFX_RA_STORE>(lds, coefs, qtab_custom + ((size_t)a.s * max_pictures + a.pic) * 64, frames, ring_depth, a.pic,
                           call_pos[2 * a.s], call_pos[2 * a.s + 1], epoch, a.s, a.g, rw_a, [&] {
                               if constexpr (kDeferSignal) {
                                   // Just before this item's first store: every load of this item has been consumed long ago

@@ -89,3 +89,14 @@ def sum_over_ranks(values, dist, device):
     t = torch.tensor([int(x) for x in values], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [int(x) for x in t.tolist()]
+
+
+def bind_rank_to_device_node(pci_bus_id: str) -> dict:
+    """One process per GPU: bind this rank (its main thread -- threads it starts later inherit the mask, libefx's staging
+    copy threads included) to the CPUs of the NUMA node its device hangs off, BEFORE the decoder context allocates its pinned
+    staging memory (first touch puts it on that node).  At 8 ranks per node the PCIe-inclusive path moves ~35 GB/s per
+    rank through host memory; a rank on the wrong socket pays the inter-socket link for every byte.  Returns what was done;
+    a no-op where sysfs knows no node for the device or none of the node's CPUs belong to this process."""
+    import espflix_amd as efx
+    node = efx.numa_node_of_pci(pci_bus_id)
+    return {"node": node, "cpus_bound": efx.numa_bind_thread(node) if node >= 0 else 0}

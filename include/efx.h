@@ -321,6 +321,8 @@ typedef struct efx_timing {
     uint16_t mixed;    /* 1: the averaged calls did not all run with the newest call's structure (a call that found the GPU
                           idle is split into groups, one queued behind another is not): per-launch figures derived from
                           the means are off */
+    uint32_t recon_launches; /* reconstruction kernel launches of the newest call: groups x pictures with one k_recon launch per
+                                picture index, groups with one k_recon_all per group (EFX_OPT_RECON_MODE) */
 } efx_timing;
 /* Enable HIP-event timing of the decode stages (events recorded on the kernels' own streams);
  * enabling (again) starts a new averaging window. */
@@ -341,6 +343,11 @@ typedef enum efx_option {
     EFX_OPT_RECON_SPINS = 5  /* read only: polls the reconstruction waves of the most recent call spent waiting for a predecessor
                                 picture (synchronises) */
 } efx_option;
+/* Debugging aid of the guard-page allocator (EFX_GUARD=1 / 2 in the environment: every device buffer of the library and of
+ * efx_device_alloc becomes its own mapping that ends -- mode 2: starts -- on an unmapped page, so that a kernel reading or
+ * writing past a buffer faults at once): writes one word `offset_bytes` past the end (negative: before the start) of a
+ * buffer.  tools/guard_selftest.py uses it to show that the allocator catches what it is there to catch. */
+int efx_debug_poke(efx_ctx* ctx, void* dptr, size_t bytes, long long offset_bytes);
 int efx_set_option(efx_ctx* ctx, int option, int value);
 int efx_get_option(efx_ctx* ctx, int option, int* value);
 
@@ -354,6 +361,16 @@ int efx_get_option(efx_ctx* ctx, int option, int* value);
  * r's for everything this section does not wrap (composite fields, PDM, timing ...), to be used from the caller's
  * thread only while no efx_multi_* call is in flight.  What MpegDecoder::run() is to one stream
  * (src/player.cpp:1355-1367) efx_multi_decode is to a node's worth of them. */
+/* NUMA placement of a device's host side (host only, no device call): the node sysfs publishes for a PCI device
+ * ("0000:c1:00.0", as hipDeviceGetPCIBusId prints it; -1 = unknown / single node), that node's CPUs, and binding the
+ * CALLING thread to them (returns how many CPUs the new mask holds, 0 = left alone: unknown node, or none of its CPUs are
+ * available to this process).  efx_multi_create binds each device's worker thread this way before the thread creates its
+ * context -- its pinned staging buffers are then first touched on the device's own node -- unless EFX_NUMA=0.  A
+ * one-process-per-GPU launcher calls efx_numa_bind_thread itself before efx_create (bench.py does, per rank). */
+int efx_numa_node_of_pci(const char* pci_bus_id);
+int efx_numa_cpus_of_node(int node, int* cpus, int cap);
+int efx_numa_bind_thread(int node);
+
 typedef struct efx_multi efx_multi;
 /* first stream of part `part` when `total` streams are dealt to `parts` devices: ceil(part * total / parts); part ==
  * parts gives total.  Pure function (no device needed): the partition the multi-device calls and bench.py use. */

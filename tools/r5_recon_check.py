@@ -20,6 +20,14 @@ from espflix_amd import gen
 P = 12
 golden = np.fromfile(os.path.join(ROOT, "tests", "golden", "bench_gop12.u64"), dtype="<u8").reshape(8192, P)
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+LIBS = [x for x in os.environ.get("EFX_CHECK_LIBS", "").split(",") if x]  # e.g. "b,c,d": espflix_amd/libefx_<x>.so, after the default
+
+
+def use_lib(tag):
+    """Switch the ctypes binding to another build of the library (its own globals; contexts of the old one are closed)."""
+    efx._lib = None
+    efx.LIB_PATH = os.path.join(ROOT, "espflix_amd", f"libefx_{tag}.so" if tag else "libefx.so")
+    efx.load_library()
 
 
 def check(dec, streams, ids, what):
@@ -42,58 +50,62 @@ def main():
     streams = b.all_es()
     es_bytes = sum(s.size for s in streams)
     ok_all = True
-    for mode in (0, 1, 2):
-        # ---- parity: every picture kept ------------------------------------------------------------------------------
-        for n in (256, 1, 3, 8, 40):
-            dec = efx.Decoder(n, P, P + 1, max_stream_bytes=sum(s.size for s in streams[:n]) + 4096)
-            dec.set_option(efx.OPT_RECON_MODE, mode)
-            ok, spins = check(dec, streams[:n], np.arange(n), f"mode {mode}, {n} streams, ring {P + 1}")
-            ok_all &= ok
-            print(json.dumps({"mode": mode, "streams": n, "parity": ok, "spins": spins}), flush=True)
-            dec.close()
-        # ---- 1024 streams, the reference's two frame buffers: repeated calls, then timing ---------------------------------
-        for items in ((16,) if (mode == 0 or quick) else ((16,) if mode == 1 else (16, 4, 8, 32, 64, 0))):
-            dec = efx.Decoder(1024, P, 2, max_stream_bytes=es_bytes + 64 * 1024)
-            dec.set_option(efx.OPT_RECON_MODE, mode)
-            dec.set_option(efx.OPT_RECON_ITEMS, items)
-            dec.upload(streams, 0)
-            for _ in range(3):
-                dec.decode(sync=False)
-            dec.sync()
-            h = dec.frame_hashes()
-            ok = all((h[:, dec.picture_slot(p)] == golden[:1024, p]).all() for p in (P - 2, P - 1))
-            ok &= not any(dec.stream_status(i) for i in range(1024))
-            ok_all &= ok
-            dec.set_timing(True)
-            for _ in range(5):
-                dec.decode(sync=True)
-            ts = dec.timing()
-            # back to back, pinned structure (one group, capped parser) and the automatic one
-            res = {}
-            for name, groups, cap in (("auto", 0, 0), ("pinned", 1, 1)):
-                dec.set_option(efx.OPT_GROUPS, groups)
-                dec.set_option(efx.OPT_PARSE_CAP, cap)
-                for _ in range(5):
+    for tag in [""] + LIBS:
+      use_lib(tag)
+      full = not quick and tag == ""
+      print(json.dumps({"library": efx.LIB_PATH}), flush=True)
+      for mode in ((0, 1, 2) if tag in ("", "f") else (1, 2)):
+            # ---- parity: every picture kept ------------------------------------------------------------------------------
+            for n in ((256, 1, 3, 8, 40) if full or tag == '' else (256, 8)):
+                dec = efx.Decoder(n, P, P + 1, max_stream_bytes=sum(s.size for s in streams[:n]) + 4096)
+                dec.set_option(efx.OPT_RECON_MODE, mode)
+                ok, spins = check(dec, streams[:n], np.arange(n), f"mode {mode}, {n} streams, ring {P + 1}")
+                ok_all &= ok or tag != ""
+                print(json.dumps({"lib": tag, "mode": mode, "streams": n, "parity": ok, "spins": spins}), flush=True)
+                dec.close()
+            # ---- 1024 streams, the reference's two frame buffers: repeated calls, then timing ---------------------------------
+            for items in ((16,) if (mode == 0 or not full) else ((16,) if mode == 1 else (16, 4, 8, 32, 64, 0))):
+                dec = efx.Decoder(1024, P, 2, max_stream_bytes=es_bytes + 64 * 1024)
+                dec.set_option(efx.OPT_RECON_MODE, mode)
+                dec.set_option(efx.OPT_RECON_ITEMS, items)
+                dec.upload(streams, 0)
+                for _ in range(3):
                     dec.decode(sync=False)
                 dec.sync()
+                h = dec.frame_hashes()
+                ok = all((h[:, dec.picture_slot(p)] == golden[:1024, p]).all() for p in (P - 2, P - 1))
+                ok &= not any(dec.stream_status(i) for i in range(1024))
+                ok_all &= ok or tag != ""
                 dec.set_timing(True)
-                t0 = time.perf_counter()
-                for _ in range(40):
-                    dec.decode(sync=False)
-                dec.sync()
-                dt = time.perf_counter() - t0
-                tp = dec.timing()
-                res[name] = {"ms_per_step": dt / 40 * 1e3, "Mfps": 1024 * P * 40 / dt / 1e6, "recon_ms": tp.recon_ms, "parse_ms": tp.parse_ms,
-                             "mixed": tp.mixed}
-            dec.set_option(efx.OPT_GROUPS, 0)
-            dec.set_option(efx.OPT_PARSE_CAP, 0)
-            h = dec.frame_hashes()
-            ok2 = all((h[:, dec.picture_slot(p)] == golden[:1024, p]).all() for p in (P - 2, P - 1))
-            ok_all &= ok2
-            print(json.dumps({"mode": mode, "items_per_wave": items, "parity_after_repeats": bool(ok), "parity_after_timing": bool(ok2),
-                              "serial_ms": {"index": ts.index_ms, "parse": ts.parse_ms, "recon": ts.recon_ms},
-                              "spins": dec.get_option(efx.OPT_RECON_SPINS), "back_to_back": res}), flush=True)
-            dec.close()
+                for _ in range(5):
+                    dec.decode(sync=True)
+                ts = dec.timing()
+                # back to back, pinned structure (one group, capped parser) and the automatic one
+                res = {}
+                for name, groups, cap in (("auto", 0, 0), ("pinned", 1, 1)):
+                    dec.set_option(efx.OPT_GROUPS, groups)
+                    dec.set_option(efx.OPT_PARSE_CAP, cap)
+                    for _ in range(5):
+                        dec.decode(sync=False)
+                    dec.sync()
+                    dec.set_timing(True)
+                    t0 = time.perf_counter()
+                    for _ in range(40):
+                        dec.decode(sync=False)
+                    dec.sync()
+                    dt = time.perf_counter() - t0
+                    tp = dec.timing()
+                    res[name] = {"ms_per_step": dt / 40 * 1e3, "Mfps": 1024 * P * 40 / dt / 1e6, "recon_ms": tp.recon_ms, "parse_ms": tp.parse_ms,
+                                 "mixed": tp.mixed}
+                dec.set_option(efx.OPT_GROUPS, 0)
+                dec.set_option(efx.OPT_PARSE_CAP, 0)
+                h = dec.frame_hashes()
+                ok2 = all((h[:, dec.picture_slot(p)] == golden[:1024, p]).all() for p in (P - 2, P - 1))
+                ok_all &= ok2 or tag != ""
+                print(json.dumps({"lib": tag, "mode": mode, "items_per_wave": items, "parity_after_repeats": bool(ok), "parity_after_timing": bool(ok2),
+                                  "serial_ms": {"index": ts.index_ms, "parse": ts.parse_ms, "recon": ts.recon_ms},
+                                  "spins": dec.get_option(efx.OPT_RECON_SPINS), "back_to_back": res}), flush=True)
+                dec.close()
     print(json.dumps({"ALL_OK": bool(ok_all)}), flush=True)
     return 0 if ok_all else 1
 
