@@ -68,3 +68,20 @@ def test_stream_partition_is_the_one_of_the_scaling_job():
             for k in range(firsts[r], firsts[r + 1]):
                 assert k * parts // total == r
     assert efx.partition_first(10, 0, 0) == -1 and efx.partition_first(-1, 2, 0) == -1
+
+
+def test_stream_layout_is_the_upload_rule():
+    """efx_stream_layout (host only): where a caller lays the streams of a batch out in a page-locked arena so that
+    efx_upload_streams transfers them in place -- 16-byte aligned starts, room for the 9-byte end-of-data tail behind each."""
+    import ctypes as C
+    lib = efx.load_library()
+    lens = [0, 1, 6, 7, 8, 23, 4096, 45001]
+    arr = (C.c_size_t * len(lens))(*lens)
+    off = (C.c_size_t * (len(lens) + 1))()
+    assert lib.efx_stream_layout(len(lens), arr, off) == 0
+    pos = 0
+    for i, n in enumerate(lens):
+        assert off[i] == pos and pos % 16 == 0
+        pos += (n + 9 + 15) // 16 * 16
+    assert off[len(lens)] == pos
+    assert lib.efx_stream_layout(0, arr, off) != 0

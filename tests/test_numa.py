@@ -66,3 +66,24 @@ def test_bench_rank_binding_helper(tmp_path):
         """).splitlines()
     assert out[0] == f"{{'node': 3, 'cpus_bound': 1}} [{avail[-1]}]"
     assert out[1] == "{'node': -1, 'cpus_bound': 0}"
+
+
+def test_scale_harness_dry_run_eight_devices(tmp_path):
+    """tools/efx_scale --dry-run: the 8-device job's partition (stream k on device floor(k * 8 / 8192))
+    and the NUMA node each device's host thread would be bound to, without touching a device."""
+    exe = os.path.join(ROOT, "tools", "efx_scale")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", ROOT, "scale"], check=True, capture_output=True)
+    devs = [f"0000:{0x05 + 0x10 * i:02x}:00.0" for i in range(8)]
+    make_tree(tmp_path, {0: ("0-47", devs[:4]), 1: ("48-95", devs[4:])})
+    p = subprocess.run([exe, "--dry-run", "1", "--devices", "8", "--streams", "1024", "--pci", ",".join(devs)], capture_output=True, text=True,
+                       env=dict(os.environ, EFX_SYSFS_ROOT=str(tmp_path)), timeout=60)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = p.stdout.splitlines()
+    assert lines[-1] == "DRY_RUN devices=8 streams_total=8192 covered=8192"
+    for r in range(8):
+        assert lines[r].startswith(f"device {r}: streams [{r * 1024}, {(r + 1) * 1024}) = 1024,")
+        assert f"numa node {0 if r < 4 else 1}, 48 cpus" in lines[r]
+    # an uneven job: 3 devices
+    p = subprocess.run([exe, "--dry-run", "1", "--devices", "3", "--streams", "1000"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and p.stdout.splitlines()[-1] == "DRY_RUN devices=3 streams_total=3000 covered=3000"

@@ -2,6 +2,9 @@
 // "host code stays C/C++" for the node-level job that bench.py runs under torch.distributed.
 //
 //   tools/efx_scale [--devices N] [--streams S] [--steps K] [--warmup W] [--golden tests/golden/bench_gop12.u64]
+//   tools/efx_scale --dry-run 1 --devices N [--streams S]      no device is touched: prints which streams each of N devices
+//                                                              would decode (efx_partition_first) and where its host thread
+//                                                              would be bound (efx_numa_*, given --pci id0,id1,...)
 //
 // N devices (default: all visible), S synthetic GOP(12) streams per device (ids 0 .. N*S-1, SURVEY.md 8d config 3 / 5:
 // stream k on device floor(k*N/(N*S))), one efx_multi (a context and a host thread per device), no collective on the
@@ -41,15 +44,43 @@ uint64_t efxgen_fnv1a64(const uint8_t* p, uint64_t n, uint64_t h);
 
 int main(int argc, char** argv)
 {
-    int n_dev = 0, S = 1024, steps = 20, warmup = 3;
+    int n_dev = 0, S = 1024, steps = 20, warmup = 3, dry_run = 0;
     const int P = 12;
-    std::string golden;
+    std::string golden, pci;
     for (int i = 1; i + 1 < argc; i += 2) {
+        if (!strcmp(argv[i], "--dry-run")) dry_run = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--pci")) pci = argv[i + 1];
         if (!strcmp(argv[i], "--devices")) n_dev = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--streams")) S = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--steps")) steps = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--warmup")) warmup = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--golden")) golden = argv[i + 1];
+    }
+    if (dry_run) {
+        // the job's partition and placement, without a device: what an 8-GPU node would be asked to do
+        if (n_dev <= 0 || S <= 0) {
+            fprintf(stderr, "efx_scale --dry-run: give --devices N\n");
+            return 1;
+        }
+        const int total = n_dev * S;
+        std::vector<std::string> ids;
+        for (size_t a = 0; a < pci.size();) {
+            const size_t b = pci.find(',', a);
+            ids.push_back(pci.substr(a, b == std::string::npos ? std::string::npos : b - a));
+            a = b == std::string::npos ? pci.size() : b + 1;
+        }
+        int covered = 0;
+        for (int r = 0; r < n_dev; r++) {
+            const int first = efx_partition_first(total, n_dev, r), end = efx_partition_first(total, n_dev, r + 1);
+            const int node = r < (int)ids.size() ? efx_numa_node_of_pci(ids[r].c_str()) : -1;
+            printf("device %d: streams [%d, %d) = %d, first id on it %d (floor(k*%d/%d) = %d), numa node %d, %d cpus\n", r, first, end,
+                   end - first, first, n_dev, total, (int)((long long)first * n_dev / total), node, efx_numa_cpus_of_node(node, nullptr, 0));
+            if ((long long)first * n_dev / total != r || end - first > S)
+                return 1;
+            covered += end - first;
+        }
+        printf("DRY_RUN devices=%d streams_total=%d covered=%d\n", n_dev, total, covered);
+        return covered == total ? 0 : 1;
     }
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
