@@ -98,6 +98,7 @@ _SYMBOLS = {
     "efx_stream_layout": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "efx_upload_done": (C.c_int, [_P]),
     "efx_debug_poke": (C.c_int, [_P, _P, C.c_size_t, C.c_longlong]),
+    "efx_debug_recon_stats": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "efx_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
     "efx_get_option": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
     "efx_reset": (C.c_int, [_P]),
@@ -342,6 +343,12 @@ class Decoder:
 
     def set_option(self, option: int, value: int):
         _check(self._ctx, self._lib.efx_set_option(self._ctx, option, value))
+
+    def recon_stats(self):
+        """Header words of k_recon_all's hand-over buffer after the most recent call (development aid)."""
+        out = (C.c_uint32 * 64)()
+        _check(self._ctx, self._lib.efx_debug_recon_stats(self._ctx, out))
+        return list(out)
 
     def get_option(self, option: int) -> int:
         v = C.c_int()

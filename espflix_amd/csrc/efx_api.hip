@@ -21,9 +21,13 @@
 
 namespace efx {
 // kernels (k_demux.hip, k_index.hip, k_parse.hip, k_recon.hip, k_video.hip)
-__global__ void k_demux(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, uint8_t*, uint32_t*, PesEntry*,
-                        uint32_t*);
-__global__ void k_demux_audio(const uint8_t*, const uint64_t*, const uint32_t*, uint8_t*, const uint64_t*, uint32_t*);
+struct DemuxChunk;
+__global__ void k_demux_scan(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, DemuxChunk*);
+__global__ void k_demux_offsets(const uint32_t*, const uint32_t*, DemuxChunk*, uint8_t*, const uint64_t*, uint32_t*, uint32_t*);
+__global__ void k_demux(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, const DemuxChunk*, uint8_t*, PesEntry*);
+__global__ void k_demux_audio_scan(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, DemuxChunk*);
+__global__ void k_demux_audio_offsets(const uint32_t*, const uint32_t*, DemuxChunk*, uint32_t*);
+__global__ void k_demux_audio(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, const DemuxChunk*, uint8_t*, const uint64_t*);
 __global__ void k_ts_sequences(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, PesEntry*, IdxInfo*);
 __global__ void k_idx_bins(const PesEntry*, const uint32_t*, const IdxInfo*, uint32_t, uint32_t*, size_t);
 __global__ void k_index(const uint8_t*, const uint64_t*, int, PicInfo*, SliceTmp*, uint32_t*, uint32_t*, uint32_t*,
@@ -74,6 +78,8 @@ constexpr int kGroupStreams = EFX_GROUP_STREAMS;
 constexpr int kTimingRing = 64;   // efx_decode calls whose stage times efx_get_timing can average
 constexpr int kSlots = EFX_SLOTS;         // parse -> recon hand-over buffer sets (one being reconstructed + two being parsed)
 constexpr int kUploads = 2;       // bitstream buffers: one being decoded, one being filled
+// k_recon_all's hand-over words: 64 lines of 128 bytes (queue heads, spins, abort, development statistics), then one line per stream
+constexpr size_t kReconSyncWords(size_t streams) { return (64 + streams) * 32; }
 
 struct efx_ctx {
     efx_config cfg{};
@@ -127,6 +133,7 @@ struct efx_ctx {
     hipStream_t copy_stream = nullptr;
     // transient TS staging on the device + the lists of efx_index_streams / efx_demux_audio
     uint8_t* d_ts = nullptr;
+    DemuxChunk* d_demux_chunks = nullptr;  // k_demux's per-chunk totals / bases (16 bytes each; one demux runs at a time)
     size_t pes_cap = 0;
     IdxInfo* d_idx_info = nullptr;
     uint64_t* d_ts_off = nullptr;
@@ -157,7 +164,7 @@ struct efx_ctx {
         int64_t* d_pts = nullptr;    // per (stream, picture): PTS latched at the picture header (TS input); then, per
                                      // stream, the newest PES PTS of the upload (k_index -> k_advance)
         int32_t* d_call_pos = nullptr;  // per stream: ring position of this call's first picture, first picture with a PTS
-        uint32_t* d_recon_sync = nullptr;  // k_recon_all: queue heads [0..7], spins [8], finished items per stream [16 + s]
+        uint32_t* d_recon_sync = nullptr;  // k_recon_all: queue heads, spins, abort, finished items per stream -- a 128-byte line each
         hipEvent_t parse_done[kReconMerge] = {}, recon_done = nullptr, wrap_cleared = nullptr;
         int epoch = 0;
         int upload = 0;  // batch this call decoded
@@ -535,7 +542,7 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
         A(dalloc(&sl.d_slice_base, n * P + kMaxGroups));  // (one list per parse half, each with an end entry)
         A(dalloc(&sl.d_descs, n * P * kMaxSlicesPerPicture));
         A(dalloc(&sl.d_call_pos, 2 * n));
-        A(dalloc(&sl.d_recon_sync, 16 + n));
+        A(dalloc(&sl.d_recon_sync, kReconSyncWords(n)));
     }
     A(dalloc(&ctx->d_frames, n * D * kFrameBytes + 8192));  // slack: k_recon's window rows may over-read the last frame
     A(dalloc(&ctx->d_video[0], 1));
@@ -634,7 +641,7 @@ void efx_destroy(efx_ctx* ctx)
             (void)hipHostUnregister(a.base);
     }
     void* bufs[] = {ctx->d_tables, ctx->d_tm_tables, ctx->d_sbc_flags, ctx->d_sbc_next, ctx->d_state, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0],
-                    ctx->d_video_lines[1], ctx->d_hash, ctx->d_ts, ctx->d_sbc_tables, ctx->d_idx_info, ctx->d_ts_off, ctx->d_idx_len,
+                    ctx->d_video_lines[1], ctx->d_hash, ctx->d_ts, ctx->d_demux_chunks, ctx->d_sbc_tables, ctx->d_idx_info, ctx->d_ts_off, ctx->d_idx_len,
                     ctx->d_idx_base, ctx->d_idx_seq};
     for (auto& te : ctx->timing_ring)
         for (auto& ev : te.ev)
@@ -710,6 +717,8 @@ static int ensure_ts_buffers(efx_ctx* ctx)
     const size_t n_max = (size_t)ctx->cfg.max_streams;
     ctx->pes_cap = ctx->es_cap / 188 + n_max;
     hipError_t e = dalloc(&ctx->d_ts, ctx->es_cap);
+    if (e == hipSuccess)
+        e = dev_alloc(reinterpret_cast<void**>(&ctx->d_demux_chunks), (ctx->pes_cap / 128 + n_max + 2) * 16);
     for (auto& u : ctx->up) {
         if (e == hipSuccess) e = dalloc(&u.d_ts_len, n_max);
         if (e == hipSuccess) e = dalloc(&u.d_pkt_base, n_max);
@@ -886,8 +895,19 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
         // MpegDecoder::more()/demux() for the whole batch (player.cpp:381-493)
         if (ctx->timing)
             EFX_HIP(hipEventRecord(u.ev_demux[0], st));
-        hipLaunchKernelGGL(k_demux, dim3(n_streams), dim3(256), 0, st, ctx->d_ts, u.d_stream_off, u.d_ts_len, u.d_pkt_base, u.d_es,
-                           u.d_es_len, u.d_pes, u.d_pes_count);
+        {
+            // chunk-parallel: per-chunk totals, the chain across a stream's chunks (and the end-of-data tail), the gather
+            size_t max_len = 0;
+            for (int i = 0; i < n_streams; i++)
+                max_len = std::max(max_len, len[i]);
+            const unsigned chunks = (unsigned)std::max<size_t>(1, (max_len / 188 + 127) / 128);
+            hipLaunchKernelGGL(k_demux_scan, dim3(chunks, n_streams), dim3(256), 0, st, ctx->d_ts, u.d_stream_off, u.d_ts_len, u.d_pkt_base,
+                               ctx->d_demux_chunks);
+            hipLaunchKernelGGL(k_demux_offsets, dim3(n_streams), dim3(64), 0, st, u.d_ts_len, u.d_pkt_base, ctx->d_demux_chunks, u.d_es,
+                               u.d_stream_off, u.d_es_len, u.d_pes_count);
+            hipLaunchKernelGGL(k_demux, dim3(chunks, n_streams), dim3(256), 0, st, ctx->d_ts, u.d_stream_off, u.d_ts_len, u.d_pkt_base,
+                               ctx->d_demux_chunks, u.d_es, u.d_pes);
+        }
         if (ctx->timing) {
             EFX_HIP(hipEventRecord(u.ev_demux[1], st));
             u.demux_timed = true;
@@ -1033,7 +1053,7 @@ int efx_get_option(efx_ctx* ctx, int option, int* value)
         uint32_t total = 0;
         for (int g = 0; g < ctx->n_groups && ctx->decoded; g++) {
             uint32_t v = 0;
-            EFX_HIP(hipMemcpy(&v, ctx->slot[ctx->groups[g].slot].d_recon_sync + 8, sizeof(v), hipMemcpyDeviceToHost));
+            EFX_HIP(hipMemcpy(&v, ctx->slot[ctx->groups[g].slot].d_recon_sync + 8 * 32, sizeof(v), hipMemcpyDeviceToHost));
             total += v;
         }
         *value = (int)std::min<uint32_t>(total, 0x7FFFFFFFu);
@@ -1255,7 +1275,7 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
         } else if (rn > 0) {
             // ONE launch for all picture indices of the group: persistent waves pull (picture, stream, block group) items in
             // picture-major order; a per-stream counter of finished items orders a picture behind its predecessor (k_recon.hip)
-            EFX_HIP(hipMemsetAsync(sl.d_recon_sync, 0, (16 + (size_t)rn) * sizeof(uint32_t), sr));
+            EFX_HIP(hipMemsetAsync(sl.d_recon_sync, 0, kReconSyncWords((size_t)rn) * sizeof(uint32_t), sr));
             // A wave takes opt_recon_items items and ends, so that wave slots (and their LDS) keep coming free for the parse
             // kernel of the next call; with 0 the grid is what the chip holds and the waves live until the last item.
             const long long items = (long long)rn * kGroupsPerPicture * n_pictures;
@@ -1547,9 +1567,12 @@ int efx_demux_audio(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, const
         return r;
     uint8_t* const h_stage = ctx->up[0].h_es;
     std::vector<uint64_t> off((size_t)n_streams + 1), out_off((size_t)n_streams + 1);
-    std::vector<uint32_t> tlen(n_streams);
-    size_t pos = 0;
+    std::vector<uint32_t> tlen(n_streams), pbase(n_streams);
+    size_t pos = 0, packets = 0, max_len = 0;
     for (int i = 0; i < n_streams; i++) {
+        pbase[i] = (uint32_t)packets;
+        packets += len[i] / 188;
+        max_len = std::max(max_len, len[i]);
         if (!ts[i] && len[i])
             return fail(ctx, EFX_ERR_ARG, "efx_demux_audio: null stream");
         if (len[i] > stride)
@@ -1567,6 +1590,8 @@ int efx_demux_audio(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, const
     }
     off[n_streams] = pos;
     out_off[n_streams] = (uint64_t)n_streams * stride;
+    if (packets > ctx->pes_cap)
+        return fail(ctx, EFX_ERR_CAPACITY, "efx_demux_audio: more packets than the context's transport-stream capacity");
     hipStream_t st = ctx->stream;
     uint64_t* d_out_off = nullptr;
     EFX_HIP(dalloc(&d_out_off, (size_t)n_streams + 1));
@@ -1574,9 +1599,15 @@ int efx_demux_audio(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, const
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_ts_off, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_out_off, out_off.data(), out_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_idx_len, tlen.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_idx_base, pbase.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_demux_audio, dim3(n_streams), dim3(256), 0, st, ctx->d_ts, ctx->d_ts_off, ctx->d_idx_len,
-                           audio_device, d_out_off, audio_len_device);
+        const unsigned chunks = (unsigned)std::max<size_t>(1, (max_len / 188 + 127) / 128);
+        hipLaunchKernelGGL(k_demux_audio_scan, dim3(chunks, n_streams), dim3(256), 0, st, ctx->d_ts, ctx->d_ts_off, ctx->d_idx_len, ctx->d_idx_base,
+                           ctx->d_demux_chunks);
+        hipLaunchKernelGGL(k_demux_audio_offsets, dim3(n_streams), dim3(64), 0, st, ctx->d_idx_len, ctx->d_idx_base, ctx->d_demux_chunks,
+                           audio_len_device);
+        hipLaunchKernelGGL(k_demux_audio, dim3(chunks, n_streams), dim3(256), 0, st, ctx->d_ts, ctx->d_ts_off, ctx->d_idx_len, ctx->d_idx_base,
+                           ctx->d_demux_chunks, audio_device, d_out_off);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);  // the host staging buffer and d_out_off are free again
@@ -1860,18 +1891,36 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out)
 }
 
 
-// EFX_GUARD's own check (tools/guard_selftest.py): one word written `offset_bytes` past the end (or, negative, before the
-// start) of a device buffer.  Under the guard-page allocator a positive offset of 16 or more (the end alignment) faults;
-// without it the write lands in whatever lies there -- never call this outside that test.
+// EFX_GUARD's own check (tools/guard_selftest.py): one word written at `offset_bytes` from the start of a device buffer
+// (negative: in front of it).  Under the guard-page allocator the first 16-byte unit behind the buffer (mode 1) / any byte in
+// front of it (mode 2) faults; without it the write lands in whatever lies there -- never call this outside that test.
 int efx_debug_poke(efx_ctx* ctx, void* dptr, size_t bytes, long long offset_bytes)
 {
     bind_device(ctx);
     if (!ctx || !dptr)
         return EFX_ERR_ARG;
-    char* at = offset_bytes >= 0 ? static_cast<char*>(dptr) + ((bytes + 15) & ~(size_t)15) + offset_bytes : static_cast<char*>(dptr) + offset_bytes;
+    (void)bytes;
+    char* at = static_cast<char*>(dptr) + offset_bytes;
     hipLaunchKernelGGL(k_fill, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<uint32_t*>(at), 0xDEADBEEFu, (size_t)1);
     EFX_HIP(hipGetLastError());
     EFX_HIP(hipStreamSynchronize(ctx->stream));
+    return EFX_OK;
+}
+
+// development: the header lines of k_recon_all's hand-over words after the most recent call (word 0 of each of the 64 lines;
+// lines 16 ... carry per-phase times only in an -DEFX_RA_STATS build: tools/r5_recon_check.py)
+int efx_debug_recon_stats(efx_ctx* ctx, uint32_t out[64])
+{
+    bind_device(ctx);
+    if (!ctx || !out || !ctx->decoded || ctx->n_groups < 1)
+        return EFX_ERR_ARG;
+    int r = sync_all(ctx);
+    if (r)
+        return r;
+    std::vector<uint32_t> all(64 * 32);
+    EFX_HIP(hipMemcpy(all.data(), ctx->slot[ctx->groups[ctx->n_groups - 1].slot].d_recon_sync, all.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 64; k++)
+        out[k] = all[(size_t)k * 32];
     return EFX_OK;
 }
 

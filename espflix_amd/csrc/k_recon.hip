@@ -664,11 +664,23 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
 //   * A wave works one item ahead of itself: the next item's index was claimed, its macroblock record and its stream's
 //     counter requested, before the current item's first instruction -- the record's round trip (1.5 of a wave's 10.6 us
 //     under load) is off the chain, and so are the dequeue and the poll.
-// sync: [0..7] queue heads, [8] debugging (spins), [16 + stream] finished items of the stream; zeroed by the host before
-// every launch.  Restates, for a whole call, the order MpegDecoder::run() gives one stream: picture after picture
+// sync: queue heads, a spin count (diagnostics), an abort word, and per stream the count of its finished items -- EVERY word
+// in its own 128-byte line: agent-scope atomics on one line take their turns at the memory side (~88 per us per line,
+// MI355X_MICROARCH.md "dequeue"); with the eight heads in one line the whole launch ran at that rate, 5.7 instead of
+// 0.9 ms per 307 200 items.  Zeroed by the host before every launch.  Restates, for a whole call, the order MpegDecoder::run() gives one stream: picture after picture
 // (player.cpp:692-702).
 constexpr int kGroupsPerPicture = (kBlocksPerPicture + 63) / 64;  // 25
-constexpr uint32_t kSyncHeads = 0, kSyncSpins = 8, kSyncAbort = 9, kSyncDone = 16;
+constexpr uint32_t kSyncLine = 32;  // words per line
+constexpr uint32_t kSyncHeads = 0, kSyncSpins = 8 * kSyncLine, kSyncAbort = 9 * kSyncLine, kSyncDone = 64 * kSyncLine;
+#ifdef EFX_RA_STATS
+// (development build: where a wave's time goes, summed over the launch -- lines 16 ... of the header, one word per line;
+// read through efx_debug_recon_stats, tools/r5_recon_check.py)
+constexpr uint32_t kSyncStats = 16 * kSyncLine;
+enum { kStWaves, kStItems, kStForeign, kStClaim, kStDep, kStBody, kStSignal, kStLife, kStXcc0 /* .. +7 */, kStCount = kStXcc0 + 8 };
+#define EFX_RA_T() wall_clock64()
+#else
+#define EFX_RA_T() 0ull
+#endif
 
 struct ItemAt {
     int pic, s, g;
@@ -699,7 +711,7 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
     auto claim_issue = [&](uint32_t qq) {
         uint32_t v = 0;
         if (lane == 0)
-            v = __hip_atomic_fetch_add(sync + kSyncHeads + qq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __hip_atomic_fetch_add(sync + kSyncHeads + qq * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return v;
     };
     // (rare: the end of a queue) walk the queues until one hands out an item; false when all eight are empty
@@ -718,14 +730,14 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
         return *reinterpret_cast<const uint4*>(mbrecs + ((size_t)it.s * max_pictures + it.pic) * kMbCount + at.mb);
     };
     auto done_of = [&](const ItemAt& it) {
-        return __hip_atomic_load(sync + kSyncDone + (uint32_t)(it.s - stream0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __hip_atomic_load(sync + kSyncDone + (uint32_t)(it.s - stream0) * kSyncLine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto signal = [&](int s_done) {
         // the stores of the item have left the wave ...
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ... one more finished item of its stream
         if (lane == 0)
-            __hip_atomic_fetch_add(sync + kSyncDone + (uint32_t)(s_done - stream0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(sync + kSyncDone + (uint32_t)(s_done - stream0) * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     // A wave takes at most `max_items` items and ends (0: as many as there are): the grid is then items / max_items
@@ -734,6 +746,9 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
     // room.  An item that has been claimed is always processed: the claim for the item after the next goes out only while
     // the budget has room for it.
     uint32_t budget = max_items > 0 ? (uint32_t)max_items : 0xFFFFFFFFu;
+    [[maybe_unused]] const unsigned long long st_begin = EFX_RA_T();
+    [[maybe_unused]] unsigned long long st_claim = 0, st_dep = 0, st_body = 0, st_signal = 0;
+    [[maybe_unused]] uint32_t st_items = 0, st_foreign = 0;
     uint32_t idx_a = 0;
     if (!claim_walk(idx_a))
         return;
@@ -747,6 +762,7 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
     int pending_signal = -1;  // (kDeferSignal) stream of the item whose stores are still on their way
     for (;;) {
         // ---- the next item: index, record, its stream's counter -- all in flight under this item's work -------------------
+        [[maybe_unused]] const unsigned long long st_t0 = EFX_RA_T();
         bool have_b = false;
         uint32_t idx_b = 0;
         if (pending_b) {
@@ -772,6 +788,7 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
             done_b = done_of(b);
         }
         // ---- this item's predecessor: every group of the stream's previous pictures is in memory ---------------------------
+        [[maybe_unused]] const unsigned long long st_t1 = EFX_RA_T();
         const uint32_t need = (uint32_t)(kGroupsPerPicture * a.pic);
         uint32_t seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)done_a);
         if (seen < need) {
@@ -800,6 +817,7 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
             if (lane == 0)
                 __hip_atomic_fetch_add(sync + kSyncSpins, spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        [[maybe_unused]] const unsigned long long st_t2 = EFX_RA_T();
         recon_group<EFX_RA_LOAD, EFX_RA_STORE>(lds, coefs, qtab_custom + ((size_t)a.s * max_pictures + a.pic) * 64, frames, ring_depth, a.pic,
                           call_pos[2 * a.s], call_pos[2 * a.s + 1], epoch, a.s, a.g, rw_a, [&] {
                               if constexpr (kDeferSignal) {
@@ -812,10 +830,22 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
                                       signal(pending_signal);
                               }
                           });
+        [[maybe_unused]] const unsigned long long st_t3 = EFX_RA_T();
         if constexpr (kDeferSignal)
             pending_signal = a.s;
         else
             signal(a.s);
+#ifdef EFX_RA_STATS
+        {
+            const unsigned long long st_t4 = EFX_RA_T();
+            st_claim += st_t1 - st_t0;
+            st_dep += st_t2 - st_t1;
+            st_body += st_t3 - st_t2;
+            st_signal += st_t4 - st_t3;
+            st_items++;
+            st_foreign += (uint32_t)((a.s - stream0) & 7) != (xcc & 7);
+        }
+#endif
         if (!have_b)
             break;
         a = b;
@@ -825,6 +855,22 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
     if constexpr (kDeferSignal)
         if (pending_signal >= 0)
             signal(pending_signal);
+#ifdef EFX_RA_STATS
+    if (lane == 0) {
+        auto add = [&](int k, unsigned long long v) {
+            __hip_atomic_fetch_add(sync + kSyncStats + (uint32_t)k * kSyncLine, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        add(kStWaves, 1);
+        add(kStItems, st_items);
+        add(kStForeign, st_foreign);
+        add(kStClaim, st_claim >> 2);  // (100 MHz ticks / 4 = units of 40 ns)
+        add(kStDep, st_dep >> 2);
+        add(kStBody, st_body >> 2);
+        add(kStSignal, st_signal >> 2);
+        add(kStLife, (EFX_RA_T() - st_begin) >> 2);
+        add(kStXcc0 + (int)(xcc & 7), 1);
+    }
+#endif
 }
 
 #ifndef EFX_RECON_ALL_WAVES

@@ -345,9 +345,12 @@ typedef enum efx_option {
 } efx_option;
 /* Debugging aid of the guard-page allocator (EFX_GUARD=1 / 2 in the environment: every device buffer of the library and of
  * efx_device_alloc becomes its own mapping that ends -- mode 2: starts -- on an unmapped page, so that a kernel reading or
- * writing past a buffer faults at once): writes one word `offset_bytes` past the end (negative: before the start) of a
- * buffer.  tools/guard_selftest.py uses it to show that the allocator catches what it is there to catch. */
+ * writing past a buffer faults at once): writes one word at `offset_bytes` from the start of a buffer (negative: in front of
+ * it).  tools/guard_selftest.py uses it to show that the allocator catches what it is there to catch. */
 int efx_debug_poke(efx_ctx* ctx, void* dptr, size_t bytes, long long offset_bytes);
+/* Debugging aid: word 0 of each of the 64 header lines of k_recon_all's hand-over words after the most recent call (queue
+ * heads 0-7, spins 8, abort 9; 16 ... per-phase wave times in a -DEFX_RA_STATS build). */
+int efx_debug_recon_stats(efx_ctx* ctx, uint32_t out[64]);
 int efx_set_option(efx_ctx* ctx, int option, int value);
 int efx_get_option(efx_ctx* ctx, int option, int* value);
 

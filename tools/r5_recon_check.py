@@ -102,6 +102,15 @@ def main():
                 h = dec.frame_hashes()
                 ok2 = all((h[:, dec.picture_slot(p)] == golden[:1024, p]).all() for p in (P - 2, P - 1))
                 ok_all &= ok2 or tag != ""
+                st = dec.recon_stats() if mode else None
+                if st and st[16]:
+                    # -DEFX_RA_STATS build: phase times of the most recent call's waves, units of 40 ns summed over the launch
+                    w, it = st[16], max(1, st[17])
+                    print(json.dumps({"lib": tag, "mode": mode, "stats_of_last_call": {
+                        "waves": w, "items": st[17], "items_on_a_foreign_xcd": st[18],
+                        "us_per_item": {"claim": st[19] * 0.04 / it, "dependency_wait": st[20] * 0.04 / it, "body": st[21] * 0.04 / it,
+                                        "signal": st[22] * 0.04 / it},
+                        "mean_wave_life_us": st[23] * 0.04 / w, "waves_by_xcc": st[24:32]}}), flush=True)
                 print(json.dumps({"lib": tag, "mode": mode, "items_per_wave": items, "parity_after_repeats": bool(ok), "parity_after_timing": bool(ok2),
                                   "serial_ms": {"index": ts.index_ms, "parse": ts.parse_ms, "recon": ts.recon_ms},
                                   "spins": dec.get_option(efx.OPT_RECON_SPINS), "back_to_back": res}), flush=True)
