@@ -16,6 +16,9 @@ all: lib gen oracle
 lib: espflix_amd/libefx.so
 gen: espflix_amd/gen/libefx_gen.so
 
+# k_recon.hip: the atomic optimizer would turn k_recon_all's one-lane dequeue into "atomic, wait, readfirstlane" on the spot --
+# the wait is the point of issuing the claim an item ahead (the value is consumed at the pre-store drain)
+$(CSRC)/k_recon.o: HIPFLAGS += -mllvm -amdgpu-atomic-optimizer-strategy=None
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/efx_internal.h $(CSRC)/parse_tm.h $(CSRC)/efx_probe.h include/efx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/efx_tables.o: $(CSRC)/efx_tables.cpp $(CSRC)/efx_internal.h $(CSRC)/parse_tm.h $(CSRC)/mpeg1_codebook.h

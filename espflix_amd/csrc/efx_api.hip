@@ -41,8 +41,7 @@ __global__ void k_parse(const uint8_t*, const SliceDesc*, DecodeCounters*, const
 __global__ void k_recon(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, const int32_t*, int, int);
 __global__ void k_recon_all(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, const int32_t*, int, int,
                             int, uint32_t*, uint32_t*, int);
-__global__ void k_recon_all_eager(const MbRec*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*, int, int, int, const int32_t*, int,
-                                  int, int, uint32_t*, uint32_t*, int);
+
 __global__ void k_frame_hash(const uint8_t*, int, uint64_t*);
 __global__ void k_fill(uint32_t*, uint32_t, size_t);
 __global__ void k_composite(const uint8_t*, const VideoTables*, const VideoLineTemplates*, FieldArgs, uint16_t*);
@@ -202,8 +201,7 @@ struct efx_ctx {
     int opt_groups = 0;        // reconstruction groups per call: 0 = one group behind a busy reconstruction stream, groups of
                                // kGroupStreams streams when it is idle; n >= 1: always n
     int opt_parse_cap = 0;     // 0 = cap the parse kernel's residency only while reconstruction is queued; 1 always; 2 never
-    int opt_recon_mode = 2;    // 0 = one k_recon launch per picture index; 1 = one persistent k_recon_all per group, a wave
-                               // signals an item when its stores have left; 2 = ... one item later (its wait is free)
+    int opt_recon_mode = 2;    // 0 = one k_recon launch per picture index; 1, 2 = one k_recon_all launch per group
     int opt_recon_waves = 0;   // k_recon_all with opt_recon_items = 0: workgroups per compute unit (0 = 18, what its LDS admits)
     int opt_recon_items = 16;  // k_recon_all: items a wave takes before it ends (0: until none is left)
     int n_cus = 256;
@@ -780,14 +778,7 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
     // half (two calls back) and its staging memory by its own H2D transfer
     const int ui = (ctx->cur_up + 1) % kUploads;
     efx_ctx::Upload& u = ctx->up[ui];
-    if (u.valid) {
-        EFX_HIP(hipEventSynchronize(u.uploaded));
-        for (auto ev : u.last_read)
-            EFX_HIP(hipEventSynchronize(ev));
-    }
-    u.valid = false;
     hipStream_t st = ctx->copy_stream;
-    uint8_t* d_dst = is_ts ? ctx->d_ts : u.d_es;
     // in place: the batch lies in one arena exactly as the device buffer holds it (efx_stream_layout)
     const uint8_t* arena_src = nullptr;
     for (const auto& a : ctx->arenas)
@@ -798,6 +789,22 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
                     arena_src = nullptr;
             break;
         }
+    if (u.valid) {
+        // this record's pinned metadata (and, staged path, its staging buffer) are about to be rewritten by the host: its own
+        // previous transfer must have read them -- two uploads ago, long done
+        EFX_HIP(hipEventSynchronize(u.uploaded));
+        // the DEVICE buffer is free once the parse halves that read its previous batch are through: the in-place path lets the
+        // copy stream wait for them (the host goes on queueing -- a host that waited here kept one parse half fewer in flight);
+        // the staged path keeps the host wait it always had (its staging copy is the long part anyway)
+        for (auto ev : u.last_read) {
+            if (arena_src)
+                EFX_HIP(hipStreamWaitEvent(st, ev, 0));
+            else
+                EFX_HIP(hipEventSynchronize(ev));
+        }
+    }
+    u.valid = false;
+    uint8_t* d_dst = is_ts ? ctx->d_ts : u.d_es;
     // small per-stream arrays, pinned: stream_off | perm | ts_len | pkt_base
     uint64_t* m_off = reinterpret_cast<uint64_t*>(u.h_meta);
     uint32_t* m_perm = reinterpret_cast<uint32_t*>(m_off + n_streams + 1);
@@ -1282,7 +1289,7 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
             const int per_cu = ctx->opt_recon_waves > 0 ? ctx->opt_recon_waves : 18;
             const long long waves = ctx->opt_recon_items > 0 ? (items + ctx->opt_recon_items - 1) / ctx->opt_recon_items
                                                              : std::min<long long>(items, (long long)ctx->n_cus * per_cu);
-            hipLaunchKernelGGL(ctx->opt_recon_mode == 2 ? k_recon_all : k_recon_all_eager, dim3((unsigned)waves), dim3(64), 0, sr, sl.d_mbrecs,
+            hipLaunchKernelGGL(k_recon_all, dim3((unsigned)waves), dim3(64), 0, sr, sl.d_mbrecs,
                                sl.d_coefs, ctx->d_tables->scan, sl.d_qtab, ctx->d_frames, P, D, n_pictures, sl.d_call_pos, sl.epoch, rs0, rn,
                                sl.d_recon_sync, sl.d_status, ctx->opt_recon_items);
         }
@@ -1515,8 +1522,8 @@ int efx_composite_fields_ex(efx_ctx* ctx, const efx_field_opts* o, uint16_t* dst
     }
     a.overlay_scale = scale;
     a.overlay_progress = o->overlay_progress;
-    const int lines = o->ntsc ? 262 : 312;
-    const int blocks = o->n_streams * ((lines + kCompositeLinesPerBlock - 1) / kCompositeLinesPerBlock);
+    const int lines = o->ntsc ? 262 : 312, groups = (o->ntsc ? 912 : 1136) / 8;  // (video_init / pal_init, video.cpp:554-630)
+    const int blocks = o->n_streams * ((lines * groups + kCompositeItemsPerBlock - 1) / kCompositeItemsPerBlock);
     hipLaunchKernelGGL(k_composite, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_frames, ctx->d_video[o->ntsc ? 1 : 0],
                        ctx->d_video_lines[o->ntsc ? 1 : 0], a, dst_device);
     EFX_HIP(hipGetLastError());

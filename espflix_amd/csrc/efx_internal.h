@@ -121,7 +121,7 @@ struct VideoTables {
 // Every sample of a field that is not picture or overlay: whole lines as video_isr leaves them in
 // the DMA buffers (sync, burst, black; vertical blanking; the PAL half-line syncs), one template per
 // line kind.  k_composite copies 16 bytes from here instead of re-deriving eight samples.
-constexpr int kCompositeLinesPerBlock = 16;  // scan lines one k_composite workgroup renders
+constexpr int kCompositeItemsPerBlock = 2048;  // 8-sample groups one k_composite workgroup renders (8 passes of 256 threads)
 constexpr int kLineTemplates = 6;      // 0/1 normal line (PAL: _line_counter odd / even), 2 NTSC vertical blanking, 3..5 PAL sync types 0, 2, 3
 constexpr int kLineTemplateWidth = 1152;  // >= 1136 samples, 16-byte multiple
 struct VideoLineTemplates {

@@ -661,9 +661,9 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
 //     on (HW_REG_XCC_ID) until that is empty, then helps the next one -- a stream's frames stay in one L2, and eight heads
 //     take the dequeue traffic (one head saturates at ~88 per us: MI355X_MICROARCH.md, "dequeue").  Placement is for speed
 //     only: every frame access is sc1 on both sides (recon_group<true>), correct wherever an item runs.
-//   * A wave works one item ahead of itself: the next item's index was claimed, its macroblock record and its stream's
-//     counter requested, before the current item's first instruction -- the record's round trip (1.5 of a wave's 10.6 us
-//     under load) is off the chain, and so are the dequeue and the poll.
+//   * A wave works ahead of itself: the next item's macroblock record and its stream's counter are requested, and the index
+//     of the item after that is claimed, before the current item's first instruction -- the record's round trip (1.5 of a
+//     wave's 10.6 us under load) is off the chain, and so are the dequeue and the poll.
 // sync: queue heads, a spin count (diagnostics), an abort word, and per stream the count of its finished items -- EVERY word
 // in its own 128-byte line: agent-scope atomics on one line take their turns at the memory side (~88 per us per line,
 // MI355X_MICROARCH.md "dequeue"); with the eight heads in one line the whole launch ran at that rate, 5.7 instead of
@@ -686,7 +686,6 @@ struct ItemAt {
     int pic, s, g;
 };
 
-template <bool kDeferSignal>
 __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const MbRec* __restrict__ mbrecs,
                                                const uint32_t* __restrict__ coefs, const uint32_t* __restrict__ scan_tab,
                                                const uint32_t* __restrict__ qtab_custom, uint8_t* __restrict__ frames,
@@ -698,13 +697,16 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
     lds[lane * kLaneDwords + kLaneData] = scan_tab[lane];  // (once per wave: the items leave the 33rd dword alone)
     uint32_t xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    // queue q: streams stream0 + q + 8 j, j < per_queue(q); its items in picture-major order, streams fastest
+    // queue q: streams stream0 + q + 8 j, j < per_queue(q); its items picture by picture, inside a picture stream by stream, a
+    // stream's 25 groups together: the last group of a stream's picture p and the first of its picture p + 1 are a whole
+    // picture of the queue apart (with the streams innermost they were per_queue(q) items apart -- fewer than the waves in
+    // flight: every picture began with a wait)
     auto per_queue = [&](uint32_t q) { return (uint32_t)(n_streams > (int)q ? (n_streams - (int)q + 7) >> 3 : 0); };
     auto items_of = [&](uint32_t q) { return per_queue(q) * (uint32_t)(kGroupsPerPicture * n_pictures); };
     uint32_t q = xcc & 7, visited = 0;
     auto decode = [&](uint32_t qq, uint32_t idx) {
-        const uint32_t nq = per_queue(qq), per_pic = nq * kGroupsPerPicture;
-        const uint32_t p = idx / per_pic, rem = idx - p * per_pic, g = rem / nq, j = rem - g * nq;
+        const uint32_t per_pic = per_queue(qq) * kGroupsPerPicture;
+        const uint32_t p = idx / per_pic, rem = idx - p * per_pic, j = rem / kGroupsPerPicture, g = rem - j * kGroupsPerPicture;
         return ItemAt{(int)p, stream0 + (int)(qq + 8 * j), (int)g};
     };
     // a returning agent-scope add on the queue head, by lane 0; the value is waited for where it is used
@@ -714,7 +716,8 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
             v = __hip_atomic_fetch_add(sync + kSyncHeads + qq * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return v;
     };
-    // (rare: the end of a queue) walk the queues until one hands out an item; false when all eight are empty
+    // walk the queues until one hands out an item (a synchronous claim: the start of a wave, the end of a queue); false when
+    // all eight are empty
     auto claim_walk = [&](uint32_t& idx) {
         while (visited < 8) {
             idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)claim_issue(q));
@@ -732,83 +735,74 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
     auto done_of = [&](const ItemAt& it) {
         return __hip_atomic_load(sync + kSyncDone + (uint32_t)(it.s - stream0) * kSyncLine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    auto signal = [&](int s_done) {
-        // the stores of the item have left the wave ...
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // ... one more finished item of its stream
+    auto signal = [&](int s_done) {  // one more finished item of the stream (the caller knows that its stores have left)
         if (lane == 0)
             __hip_atomic_fetch_add(sync + kSyncDone + (uint32_t)(s_done - stream0) * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    auto drain = [] { __builtin_amdgcn_s_waitcnt(0x0F70); };  // s_waitcnt vmcnt(0), as a builtin: the compiler's own bookkeeping
+                                                               // learns that every load and atomic issued so far has returned
 
     // A wave takes at most `max_items` items and ends (0: as many as there are): the grid is then items / max_items
     // workgroups and wave slots keep coming free -- a grid of waves that live for the whole call would hold every CU's LDS
     // until its last item, and the parse kernel of the NEXT call (which must run beside this one, efx_api.hip) would find no
-    // room.  An item that has been claimed is always processed: the claim for the item after the next goes out only while
-    // the budget has room for it.
+    // room.  An item that has been claimed is always processed: claims go out only while the budget has room.
+    //
+    // The pipeline of a wave, three items deep: A is worked on; B's macroblock record and its stream's counter were requested
+    // at the top of A's turn; C's index is being claimed.  ALL of that is waited for at ONE place -- just before A's first store,
+    // where every load of A has long been consumed and the wait is free -- and there the hand-over signal of the item BEFORE A
+    // goes out too (memory operations complete in issue order: its stores have left).  A wait anywhere else would sit out A's
+    // stores: the counter of outstanding memory operations cannot tell an old atomic from a new store.
     uint32_t budget = max_items > 0 ? (uint32_t)max_items : 0xFFFFFFFFu;
     [[maybe_unused]] const unsigned long long st_begin = EFX_RA_T();
-    [[maybe_unused]] unsigned long long st_claim = 0, st_dep = 0, st_body = 0, st_signal = 0;
+    [[maybe_unused]] unsigned long long st_top = 0, st_dep = 0, st_body = 0;
     [[maybe_unused]] uint32_t st_items = 0, st_foreign = 0;
-    uint32_t idx_a = 0;
-    if (!claim_walk(idx_a))
+    uint32_t idx = 0;
+    if (!claim_walk(idx))
         return;
     budget--;
-    ItemAt a = decode(q, idx_a);
-    uint32_t q_b = q;
-    bool pending_b = budget > 0;
-    uint32_t claim_b = pending_b ? claim_issue(q_b) : 0u;  // the item after: resolved at the top of the loop
+    ItemAt a = decode(q, idx);
+    bool have_b = budget > 0 && claim_walk(idx);
+    ItemAt b = a;
+    if (have_b) {
+        budget--;
+        b = decode(q, idx);
+    }
     uint4 rw_a = record_of(a);
-    uint32_t done_a = done_of(a);
-    int pending_signal = -1;  // (kDeferSignal) stream of the item whose stores are still on their way
+    uint32_t seen_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)done_of(a));
+    int pending_signal = -1;  // stream of the item whose stores are still on their way
     for (;;) {
-        // ---- the next item: index, record, its stream's counter -- all in flight under this item's work -------------------
         [[maybe_unused]] const unsigned long long st_t0 = EFX_RA_T();
-        bool have_b = false;
-        uint32_t idx_b = 0;
-        if (pending_b) {
-            idx_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)claim_b);
-            have_b = idx_b < items_of(q);
-            if (!have_b) {  // this queue is empty: on to the next ones
-                q = (q + 1) & 7;
-                visited++;
-                have_b = claim_walk(idx_b);
-            }
-        }
-        ItemAt b = a;
+        // ---- requests for the items behind this one (consumed at this item's pre-store point) -----------------------------------
         uint4 rw_b = rw_a;
-        uint32_t done_b = 0;
+        uint32_t done_b = 0, claim_c = 0;
+        const uint32_t q_c = q;
+        const bool pending_c = have_b && budget > 0;
         if (have_b) {
-            budget--;
-            b = decode(q, idx_b);
-            q_b = q;
-            pending_b = budget > 0;
-            if (pending_b)
-                claim_b = claim_issue(q_b);
             rw_b = record_of(b);
             done_b = done_of(b);
         }
+        if (pending_c)
+            claim_c = claim_issue(q_c);
         // ---- this item's predecessor: every group of the stream's previous pictures is in memory ---------------------------
         [[maybe_unused]] const unsigned long long st_t1 = EFX_RA_T();
         const uint32_t need = (uint32_t)(kGroupsPerPicture * a.pic);
-        uint32_t seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)done_a);
-        if (seen < need) {
+        if (seen_a < need) {
             // (the tail of a small batch: the predecessor is still in the hands of another wave -- or of THIS one: the item
             // whose signal is still held back may be what this item waits for)
-            if constexpr (kDeferSignal) {
-                if (pending_signal >= 0) {
-                    signal(pending_signal);
-                    pending_signal = -1;
-                }
+            if (pending_signal >= 0) {
+                drain();
+                signal(pending_signal);
+                pending_signal = -1;
             }
             uint32_t spins = 0;
             bool abort = false;
             do {
                 __builtin_amdgcn_s_sleep(8);
-                seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)done_of(a));
+                seen_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)done_of(a));
                 if ((++spins & 1023) == 0)
                     abort = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(sync + kSyncAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
-            } while (seen < need && !abort && spins < (1u << 19));
-            if (seen < need && lane == 0) {
+            } while (seen_a < need && !abort && spins < (1u << 19));
+            if (seen_a < need && lane == 0) {
                 // never observed: a lost hand-over must not hang the device -- the stream is flagged, every other wait of the
                 // launch gives up at its next look, the call ends
                 atomicOr(status + a.s, EFX_STREAM_INTERNAL);
@@ -818,43 +812,54 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
                 __hip_atomic_fetch_add(sync + kSyncSpins, spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         [[maybe_unused]] const unsigned long long st_t2 = EFX_RA_T();
+        uint32_t seen_b = 0, idx_c = 0;
         recon_group<EFX_RA_LOAD, EFX_RA_STORE>(lds, coefs, qtab_custom + ((size_t)a.s * max_pictures + a.pic) * 64, frames, ring_depth, a.pic,
-                          call_pos[2 * a.s], call_pos[2 * a.s + 1], epoch, a.s, a.g, rw_a, [&] {
-                              if constexpr (kDeferSignal) {
-                                  // Just before this item's first store: every load of this item has been consumed long ago
-                                  // (the wait costs nothing), and memory operations complete in the order they were issued
-                                  // -- so the PREVIOUS item's stores have left.  Its signal goes out here, a whole item
-                                  // late (its successor is a picture's worth of items away), instead of at its own end,
-                                  // where the wave would sit out the stores' round trip.
-                                  if (pending_signal >= 0)
-                                      signal(pending_signal);
-                              }
-                          });
-        [[maybe_unused]] const unsigned long long st_t3 = EFX_RA_T();
-        if constexpr (kDeferSignal)
-            pending_signal = a.s;
-        else
-            signal(a.s);
+                                               call_pos[2 * a.s], call_pos[2 * a.s + 1], epoch, a.s, a.g, rw_a, [&] {
+                                                   drain();
+                                                   if (pending_signal >= 0)
+                                                       signal(pending_signal);
+                                                   seen_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)done_b);
+                                                   idx_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)claim_c);
+                                               });
+        pending_signal = a.s;
 #ifdef EFX_RA_STATS
         {
-            const unsigned long long st_t4 = EFX_RA_T();
-            st_claim += st_t1 - st_t0;
+            const unsigned long long st_t3 = EFX_RA_T();
+            st_top += st_t1 - st_t0;
             st_dep += st_t2 - st_t1;
             st_body += st_t3 - st_t2;
-            st_signal += st_t4 - st_t3;
             st_items++;
             st_foreign += (uint32_t)((a.s - stream0) & 7) != (xcc & 7);
         }
 #endif
         if (!have_b)
             break;
+        // ---- rotate: B becomes the item worked on, C (if its claim found one) the item behind it --------------------------
+        bool have_c = false;
+        ItemAt c = b;
+        if (pending_c) {
+            have_c = idx_c < items_of(q_c);
+            if (!have_c) {  // that queue is empty: on to the next ones (synchronous, a handful of times per wave at most)
+                if (q == q_c) {
+                    q = (q + 1) & 7;
+                    visited++;
+                }
+                have_c = claim_walk(idx_c);
+            }
+            if (have_c) {
+                budget--;
+                c = decode(q, idx_c);
+            }
+        }
         a = b;
         rw_a = rw_b;
-        done_a = done_b;
+        seen_a = seen_b;
+        b = c;
+        have_b = have_c;
     }
-    if constexpr (kDeferSignal)
-        if (pending_signal >= 0)
-            signal(pending_signal);
+    drain();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last item's stores)
+    signal(pending_signal);
 #ifdef EFX_RA_STATS
     if (lane == 0) {
         auto add = [&](int k, unsigned long long v) {
@@ -863,10 +868,9 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
         add(kStWaves, 1);
         add(kStItems, st_items);
         add(kStForeign, st_foreign);
-        add(kStClaim, st_claim >> 2);  // (100 MHz ticks / 4 = units of 40 ns)
+        add(kStClaim, st_top >> 2);  // (100 MHz ticks / 4 = units of 40 ns)
         add(kStDep, st_dep >> 2);
         add(kStBody, st_body >> 2);
-        add(kStSignal, st_signal >> 2);
         add(kStLife, (EFX_RA_T() - st_begin) >> 2);
         add(kStXcc0 + (int)(xcc & 7), 1);
     }
@@ -874,9 +878,9 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
 }
 
 #ifndef EFX_RECON_ALL_WAVES
-#define EFX_RECON_ALL_WAVES 5
+#define EFX_RECON_ALL_WAVES 4  // waves per SIMD the register allocation aims at: 4 (123 registers, nothing spilled; with 5 the
+                               // 96 registers spill 14 and the launch is a quarter slower) -- 16 waves per CU
 #endif
-// (two kernels, not one with a flag: the body is 20 KB of code either way)
 __global__ __launch_bounds__(64, EFX_RECON_ALL_WAVES) void k_recon_all(
     const MbRec* __restrict__ mbrecs, const uint32_t* __restrict__ coefs, const uint32_t* __restrict__ scan_tab,
     const uint32_t* __restrict__ qtab_custom, uint8_t* __restrict__ frames, int max_pictures, int ring_depth, int n_pictures,
@@ -884,18 +888,8 @@ __global__ __launch_bounds__(64, EFX_RECON_ALL_WAVES) void k_recon_all(
     uint32_t* __restrict__ status, int max_items)
 {
     __shared__ uint32_t lds[64 * kLaneDwords + 32 + 16];
-    recon_all_body<true>(lds, mbrecs, coefs, scan_tab, qtab_custom, frames, max_pictures, ring_depth, n_pictures, call_pos, epoch,
-                         stream0, n_streams, sync, status, max_items);
-}
-__global__ __launch_bounds__(64, EFX_RECON_ALL_WAVES) void k_recon_all_eager(
-    const MbRec* __restrict__ mbrecs, const uint32_t* __restrict__ coefs, const uint32_t* __restrict__ scan_tab,
-    const uint32_t* __restrict__ qtab_custom, uint8_t* __restrict__ frames, int max_pictures, int ring_depth, int n_pictures,
-    const int32_t* __restrict__ call_pos, int epoch, int stream0, int n_streams, uint32_t* __restrict__ sync,
-    uint32_t* __restrict__ status, int max_items)
-{
-    __shared__ uint32_t lds[64 * kLaneDwords + 32 + 16];
-    recon_all_body<false>(lds, mbrecs, coefs, scan_tab, qtab_custom, frames, max_pictures, ring_depth, n_pictures, call_pos, epoch,
-                          stream0, n_streams, sync, status, max_items);
+    recon_all_body(lds, mbrecs, coefs, scan_tab, qtab_custom, frames, max_pictures, ring_depth, n_pictures, call_pos, epoch, stream0,
+                   n_streams, sync, status, max_items);
 }
 
 // FNV-1a-64 of whole ring frames, one lane per frame (verification helper, not on the timed path)

@@ -5,9 +5,11 @@
 // pixel blitter blit 690-804) as a pure function of (front frame, standard, _frame_counter):
 // the ISR writes every sample of every line either directly or through the black fill the
 // preceding blanking lines left in the two ping-pong DMA buffers, so a whole field is
-// data-parallel over (stream, line, 8-sample group).  One workgroup renders 8 consecutive lines
-// of one stream; the 3 KiB chroma-phase LUT lives in LDS; every thread produces one 16-byte
-// (8-sample) store, so line writes are fully coalesced.
+// data-parallel over (stream, line, 8-sample group).  One workgroup renders kCompositeItemsPerBlock
+// consecutive 8-sample groups of one stream's field (round 5: whole lines per workgroup left the last pass of
+// an NTSC workgroup one eighth full -- 16 lines x 114 groups = 7.1 passes of 256 threads, against PAL's 8.9);
+// the 3 KiB chroma-phase LUT lives in LDS; every thread produces one 16-byte (8-sample) store per pass, so
+// line writes are fully coalesced.
 //
 // Two-frame horizontal scroll (_hscroll, video.cpp:1146-1154: the front frame from column h, then
 // the other frame from column 0, each blit restarting its running luma average) and the 80 x 16
@@ -25,7 +27,6 @@ namespace efx {
 
 namespace {
 
-constexpr int kLinesPerBlock = kCompositeLinesPerBlock;
 
 __device__ inline int luma_row_off(int y) { return (y >> 4) * kStripBytes + (y & 15) * kStride; }
 __device__ inline int chroma_row_off(int plane, int c)
@@ -52,9 +53,12 @@ __global__ __launch_bounds__(256) void k_composite(const uint8_t* __restrict__ f
     }
     __syncthreads();
 
-    const int blocks_per_field = (v.line_count + kLinesPerBlock - 1) / kLinesPerBlock;
+    const int groups = v.line_width / 8;  // 16-byte groups per line
+    const int field_items = v.line_count * groups;
+    const int blocks_per_field = (field_items + kCompositeItemsPerBlock - 1) / kCompositeItemsPerBlock;
     const int s = blockIdx.x / blocks_per_field;
-    const int line0 = (blockIdx.x - s * blocks_per_field) * kLinesPerBlock;
+    const int item0 = (blockIdx.x - s * blocks_per_field) * kCompositeItemsPerBlock;
+    const uint32_t groups_magic = (0xFFFFFFFFu / (uint32_t)groups) + 1;  // item / groups = umulhi(item, magic): exact below 2^32 / groups
     const uint8_t* stream_frames = frames + (size_t)(first_stream + s) * ring_depth * kFrameBytes;
     // video_isr, video.cpp:1146-1154: a negative scroll shows the OTHER frame first
     int hscroll = a.hscroll, lead_slot = a.slot, trail_slot = a.other_slot;
@@ -66,16 +70,15 @@ __global__ __launch_bounds__(256) void k_composite(const uint8_t* __restrict__ f
     const int lead_groups = (EFX_FRAME_WIDTH - hscroll) / 4;  // 4-pixel groups taken from the leading frame
     const uint8_t* overlay = a.overlay ? a.overlay + (size_t)s * a.overlay_stride : nullptr;
     const int overlay_top = 32 + (v.pal ? 32 : 0) + 192 + 2;  // ptop, video.cpp:1182
-    const int groups = v.line_width / 8;  // 16-byte groups per line
     const int active_top = 32 + (v.pal ? 32 : 0);
     const int vsync_start = v.line_count - (v.pal ? 8 : 3);
     const int first_pix_group = (v.active_start + 16 + (v.pal ? 80 : 0)) / 8;
 
-    for (int item = threadIdx.x; item < kLinesPerBlock * groups; item += blockDim.x) {
-        const int li = item / groups, g = item - li * groups;
-        const int i = line0 + li;
-        if (i >= v.line_count)
+    for (int k = threadIdx.x; k < kCompositeItemsPerBlock; k += blockDim.x) {
+        const int item = item0 + k;
+        if (item >= field_items)
             break;
+        const int i = (int)__umulhi((uint32_t)item, groups_magic), g = item - i * groups;
         uint4 o;
         const int pg = g - first_pix_group;
         const bool active = i >= active_top && i < active_top + 192;

@@ -335,8 +335,8 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out);
 typedef enum efx_option {
     EFX_OPT_GROUPS = 1,      /* reconstruction groups per efx_decode: 0 = automatic (above), n >= 1 = always n */
     EFX_OPT_PARSE_CAP = 2,   /* k_parse's residency cap: 0 = only while reconstruction is queued, 1 = always, 2 = never */
-    EFX_OPT_RECON_MODE = 3,  /* 0 = one k_recon launch per picture index; 1 = one persistent launch per group (k_recon_all), an
-                                item signalled when its stores have left; 2 = ... signalled one item later (default) */
+    EFX_OPT_RECON_MODE = 3,  /* 0 = one k_recon launch per picture index; 1 or 2 = ONE launch per group for all picture indices
+                                (k_recon_all: a stream's pictures ordered by a per-stream counter; default) */
     EFX_OPT_RECON_WAVES = 4, /* k_recon_all with EFX_OPT_RECON_ITEMS = 0: workgroups (waves) per compute unit; 0 = default (18) */
     EFX_OPT_RECON_ITEMS = 6, /* k_recon_all: items -- (picture, stream, 64 blocks) -- a wave takes before it ends and frees its
                                 slot (default 16); 0 = as many as there are (a grid of what the chip holds) */
