@@ -114,6 +114,7 @@ struct efx_ctx {
         std::vector<uint64_t> stream_off;
         std::vector<uint32_t> es_len;    // per stream, ES input only
         int n_streams = 0;
+        int sort_groups = 1;  // d_stream_perm orders the streams by length INSIDE each of this many groups (group_first)
         size_t es_used = 0, ts_bytes = 0;
         bool ts_input = false, valid = false;
         hipEvent_t uploaded = nullptr;                                  // H2D (+ k_demux) done, copy stream
@@ -884,8 +885,10 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
     for (int i = 0; i < n_streams; i++)
         m_perm[i] = (uint32_t)i;
     {
-        // (sorted inside every group of streams that efx_decode runs as a unit)
-        const int G = group_count(n_streams);
+        // (sorted inside every group of streams that efx_decode runs as a unit: the groups of an idle-GPU call, or the
+        // pinned number of them; a call that runs as fewer, coarser groups is served by the same order)
+        const int G = ctx->opt_groups > 0 ? std::min(std::min(ctx->opt_groups, kMaxGroups), std::max(1, n_streams / 8)) : group_count(n_streams);
+        u.sort_groups = G;
         for (int g = 0; g < G; g++)
             std::stable_sort(m_perm + group_first(n_streams, G, g), m_perm + group_first(n_streams, G, g + 1),
                              [&](uint32_t a, uint32_t b) { return len[a] > len[b]; });
@@ -1179,6 +1182,32 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
     // (efx_set_option pins the structure: the same call sequence then runs the same launches whatever the timing)
     const int G = ctx->opt_groups > 0 ? std::min(std::min(ctx->opt_groups, kMaxGroups), std::max(1, n_all / 8))
                                       : (idle_at_call ? group_count(n_all) : 1);
+    {
+        // The order of the slices inside a picture index (streams by descending length) was laid down at upload INSIDE the
+        // groups of that moment; every group of this call must be a union of those -- else (EFX_OPT_GROUPS changed between
+        // upload and decode) the order is laid down again for this call's groups, once, behind everything queued.
+        bool nested = true;
+        for (int g = 1; g < G && nested; g++) {
+            bool found = false;
+            for (int k = 0; k <= u.sort_groups && !found; k++)
+                found = group_first(n_all, u.sort_groups, k) == group_first(n_all, G, g);
+            nested = found;
+        }
+        if (!nested) {
+            int r = sync_all(ctx);
+            if (r)
+                return r;
+            std::vector<uint32_t> perm((size_t)n_all);
+            for (int i = 0; i < n_all; i++)
+                perm[i] = (uint32_t)i;
+            auto len_of = [&](uint32_t i) { return u.stream_off[i + 1] - u.stream_off[i]; };  // (padded lengths: the same order up to ties)
+            for (int g = 0; g < G; g++)
+                std::stable_sort(perm.begin() + group_first(n_all, G, g), perm.begin() + group_first(n_all, G, g + 1),
+                                 [&](uint32_t a, uint32_t b) { return len_of(a) > len_of(b); });
+            EFX_HIP(hipMemcpy(u.d_stream_perm, perm.data(), perm.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            u.sort_groups = G;
+        }
+    }
     hipStream_t sr = ctx->stream;
     int timing_slot = -1;
     if (ctx->timing && !ctx->timing_ring.empty()) {
