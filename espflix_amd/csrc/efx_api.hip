@@ -76,7 +76,8 @@ constexpr int kReconMerge = EFX_RECON_MERGE;  // parse halves whose streams are 
 constexpr int kGroupStreams = EFX_GROUP_STREAMS;
 constexpr int kTimingRing = 64;   // efx_decode calls whose stage times efx_get_timing can average
 constexpr int kSlots = EFX_SLOTS;         // parse -> recon hand-over buffer sets (one being reconstructed + two being parsed)
-constexpr int kUploads = 2;       // bitstream buffers: one being decoded, one being filled
+constexpr int kUploads = 3;       // bitstream buffers: up to two being parsed (two parse halves are in flight), one being filled --
+                                  // with two, an upload had to wait for the parse half two calls back before its transfer could start
 // k_recon_all's hand-over words: 64 lines of 128 bytes (queue heads, spins, abort, development statistics), then one line per stream
 constexpr size_t kReconSyncWords(size_t streams) { return (64 + streams) * 32; }
 
@@ -202,7 +203,8 @@ struct efx_ctx {
     int opt_groups = 0;        // reconstruction groups per call: 0 = one group behind a busy reconstruction stream, groups of
                                // kGroupStreams streams when it is idle; n >= 1: always n
     int opt_parse_cap = 0;     // 0 = cap the parse kernel's residency only while reconstruction is queued; 1 always; 2 never
-    int opt_recon_mode = 2;    // 0 = one k_recon launch per picture index; 1, 2 = one k_recon_all launch per group
+    int opt_recon_mode = 0;    // 0 = one k_recon launch per picture index (default: measured faster beside the parse halves,
+                               // profiles/r5_recon_all.md); 1, 2 = one k_recon_all launch per group
     int opt_recon_waves = 0;   // k_recon_all with opt_recon_items = 0: workgroups per compute unit (0 = 18, what its LDS admits)
     int opt_recon_items = 16;  // k_recon_all: items a wave takes before it ends (0: until none is left)
     int n_cus = 256;
@@ -792,17 +794,12 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
         }
     if (u.valid) {
         // this record's pinned metadata (and, staged path, its staging buffer) are about to be rewritten by the host: its own
-        // previous transfer must have read them -- two uploads ago, long done
+        // previous transfer must have read them -- three uploads ago, long done
         EFX_HIP(hipEventSynchronize(u.uploaded));
-        // the DEVICE buffer is free once the parse halves that read its previous batch are through: the in-place path lets the
-        // copy stream wait for them (the host goes on queueing -- a host that waited here kept one parse half fewer in flight);
-        // the staged path keeps the host wait it always had (its staging copy is the long part anyway)
-        for (auto ev : u.last_read) {
-            if (arena_src)
-                EFX_HIP(hipStreamWaitEvent(st, ev, 0));
-            else
-                EFX_HIP(hipEventSynchronize(ev));
-        }
+        // ... and the device buffer is free once the parse halves that read its previous batch are through (three uploads ago:
+        // long done; letting the copy stream wait instead of the host was measured and is slower, 6.9 against 8.0 M frames/s)
+        for (auto ev : u.last_read)
+            EFX_HIP(hipEventSynchronize(ev));
     }
     u.valid = false;
     uint8_t* d_dst = is_ts ? ctx->d_ts : u.d_es;

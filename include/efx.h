@@ -106,9 +106,9 @@ const char* efx_status_string(int status);
  * reference's fixed offsets, one zero byte per packet that lost sync, PES PTS values kept for
  * efx_picture_pts.  Like MpegDecoder::more() at end of data (src/player.cpp:456,469-473) each
  * stream is terminated with 00 | 00 00 01 B7 | 00 00 01 B7.  Does NOT reset the frame rings.
- * Two bitstream buffers alternate: the call copies into pinned staging memory and queues the
+ * Three bitstream buffers take turns: the call copies into pinned staging memory and queues the
  * transfer (and k_demux) on a copy stream, then returns; the GPU may still be decoding the previous
- * batch, so ingest and decode of consecutive batches overlap.  efx_decode decodes the batch uploaded
+ * batches, so ingest and decode of consecutive batches overlap.  efx_decode decodes the batch uploaded
  * last. */
 int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, const size_t* len, int format);
 
@@ -335,8 +335,9 @@ int efx_get_timing(efx_ctx* ctx, efx_timing* out);
 typedef enum efx_option {
     EFX_OPT_GROUPS = 1,      /* reconstruction groups per efx_decode: 0 = automatic (above), n >= 1 = always n */
     EFX_OPT_PARSE_CAP = 2,   /* k_parse's residency cap: 0 = only while reconstruction is queued, 1 = always, 2 = never */
-    EFX_OPT_RECON_MODE = 3,  /* 0 = one k_recon launch per picture index; 1 or 2 = ONE launch per group for all picture indices
-                                (k_recon_all: a stream's pictures ordered by a per-stream counter; default) */
+    EFX_OPT_RECON_MODE = 3,  /* 0 = one k_recon launch per picture index (default); 1 or 2 = ONE launch per group for all picture
+                                indices (k_recon_all: a stream's pictures ordered by a per-stream counter -- bit-identical, on a
+                                par one call at a time, 8 % slower back to back: profiles/r5_recon_all.md) */
     EFX_OPT_RECON_WAVES = 4, /* k_recon_all with EFX_OPT_RECON_ITEMS = 0: workgroups (waves) per compute unit; 0 = default (18) */
     EFX_OPT_RECON_ITEMS = 6, /* k_recon_all: items -- (picture, stream, 64 blocks) -- a wave takes before it ends and frees its
                                 slot (default 16); 0 = as many as there are (a grid of what the chip holds) */
