@@ -139,6 +139,9 @@ constexpr int kLaneHalfwords = 2 * kLaneDwords;
 // L1 is never refreshed by another CU's stores and the XCDs' L2s are not coherent with each other:
 // MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"); the hand-over itself is the
 // per-stream counter of k_recon_all.
+#ifndef EFX_RECON_LDS_PAD
+#define EFX_RECON_LDS_PAD 0  // (counter experiments: unused dwords of LDS per wave, to hold k_recon to fewer waves per CU)
+#endif
 #ifndef EFX_RECON_STORE
 #define EFX_RECON_STORE 0  // k_recon (one launch per picture index): plain 8-byte row stores
 #endif
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     // What else a lane needs to know about another lane's block (first entry, quantiser) is fetched from that lane's
     // registers (ds_bpermute).  Measured: this layout at 16 / 18 / 19 waves per CU 8.07 / 8.16 / 7.85 M frames/s
     // (19 with the search through ds_bpermute as well), the previous one (9.7 KB, 16 waves) 7.78.
-    __shared__ uint32_t lds[64 * kLaneDwords + 32 + 16];
+    __shared__ uint32_t lds[64 * kLaneDwords + 32 + 16 + EFX_RECON_LDS_PAD];
     const int lane = threadIdx.x;
     const int s = stream0 + blockIdx.x;
     // (one record per wave, placed by launch: the ring holds ten launches of 512 streams)
