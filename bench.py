@@ -86,7 +86,7 @@ def pmc_traffic(kernel, S, P, key="kernels"):
     the figure is the one measured on this exact workload (1024 streams x GOP 12), None otherwise.
     The summary records the digest of the kernel sources it was measured on (tools/collect_profiles.sh); when the
     sources have changed since, the provenance says so and a warning goes to stderr."""
-    for name in ("r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
+    for name in ("r5_pmc_summary.json", "r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if (S, P) != (1024, 12) or not os.path.exists(path):
             continue
@@ -619,7 +619,7 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
             ingest.update(ingest_leg(dec.place_in_arena(arena, streams), "in place"))
             ingest["what"] = ("efx_upload_streams of a batch that lies in page-locked caller memory in the device layout (efx_host_alloc + "
                               "efx_stream_layout): ONE H2D per step straight from the caller's bytes on the copy stream, no staging copy; "
-                              "+ efx_decode per step, two bitstream buffers: the upload of step n+1 runs under the decode of step n")
+                              "+ efx_decode per step, three bitstream buffers: the upload of step n+1 runs under the decode of step n")
             ingest["staged_from_pageable_memory"] = ingest_leg(dec.prepare_upload(streams), "staged")
             ingest["staged_from_pageable_memory"]["what"] = ("the same from pageable host buffers: threaded staging copy into the library's "
                                                              "pinned memory, then H2D")
@@ -815,7 +815,7 @@ def run(job, args):
                    "streams_per_gpu": S, "streams_total": S * world, "pictures_per_stream": P, "es_bytes_per_gpu": r["es_bytes"],
                    "mean_bytes_per_picture": r["es_bytes"] / (S * P), "parallelism": f"stream-partition x{world}",
                    "coefficients_per_gpu": r["n_coefs"], "ring_depth": 2},
-        "roofline": {"bound": "hbm", "limiter": "25 600 waves per launch living 10.6 us each (record 1.5 us -> owner search, entry loads, dequantisation 5.9 us -> IDCT, sum, stores 2.8 us) at 14 resident per CU alone and 10.8 beside the parser, plus one wave life of fill and drain per launch; with all pixel and coefficient traffic removed a launch still takes 53 of 81 us (instruction issue); profiles/r4_ablations.md, DESIGN.md section 6", "kernel": names[2], "achieved": achieved,
+        "roofline": {"bound": "hbm", "limiter": "what a CU can issue and turn around with its 12-14 resident waves, not any one wave's chain: 25 600 waves per launch living 10.6 us each (record 1.5 us -> owner search, entry loads, dequantisation 5.9 us -> IDCT, sum, stores 2.8 us); the same 1.25-1.3 items per us and CU whether the pictures are twelve launches or one (k_recon_all: record fetched an item ahead, no launch tails -- on a par alone, 3 % shorter beside the parser, profiles/r5_recon_all.md), and between 10 and 16 resident waves per CU; with all pixel and coefficient traffic removed a launch still takes 53 of 81 us (instruction issue, profiles/r4_ablations.md); DESIGN.md section 6", "kernel": names[2], "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_launch, "avg_launch_ms": dur_s * 1e3, "launches_per_step": L,

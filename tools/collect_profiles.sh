@@ -37,4 +37,7 @@ timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o vide
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 150 rocprofv3 --pmc $c --output-format csv -d $out/vpmc_$c -o p -- python tools/bench_video.py > /dev/null 2>&1
 done
-grep "^{" $out/bench_pipelined.log | cut -c1-200; ls $out
+# (the merge back from the GPU box is limited to 64 MiB: the per-dispatch traces are not needed, the stats tables are)
+rm -f $out/*_kernel_trace.csv
+find $out -name "*_agent_info.csv" -delete
+grep "^{" $out/bench_pipelined.log | cut -c1-200; du -sh $out

@@ -18,6 +18,9 @@ ap.add_argument("tag")
 ap.add_argument("--stats", nargs="*", default=[])
 ap.add_argument("--pmc", nargs="*", default=[])
 ap.add_argument("--video-pmc", nargs="*", default=[], help="PMC passes of tools/bench_video.py (k_composite NTSC / PAL, k_pdm ...)")
+ap.add_argument("--extra", nargs="*", default=[], metavar="NAME=DIR[,DIR...]",
+                help="further PMC passes summarised the same way into their own section NAME (round 5: the uncapped parse "
+                     "schedule, the TA / TCP / LDS counters of k_recon at two LDS footprints)")
 ap.add_argument("--note", default="")
 a = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,6 +30,44 @@ os.makedirs(out, exist_ok=True)
 for s in a.stats:
     name = os.path.basename(s)
     shutil.copy(s + "_kernel_stats.csv", os.path.join(out, f"{a.tag}_kernel_stats_{name}.csv"))
+
+def summarise(dirs):
+    summary = collections.defaultdict(dict)
+    for d in dirs:
+        rows = collections.defaultdict(list)
+        if not os.path.isdir(d):
+            continue
+        for f in os.listdir(d):
+            if not f.endswith("counter_collection.csv"):
+                continue
+            for r in csv.DictReader(open(os.path.join(d, f))):
+                k = r["Kernel_Name"].split("(")[0]
+                if k.startswith("efx::"):
+                    rows[k].append((int(r["Grid_Size"]), r["Counter_Name"], float(r["Counter_Value"])))
+        for k, rs in rows.items():
+            grid = collections.Counter(g for g, _, _ in rs).most_common(1)[0][0]
+            summary[k]["grid_size"] = grid
+            cs = collections.defaultdict(list)
+            for g, c, v in rs:
+                if g == grid:
+                    cs[c].append(v)
+            for c, v in cs.items():
+                summary[k][c] = sum(v) / len(v)
+                summary[k]["dispatches_" + c] = len(v)
+    for k, cs in summary.items():
+        if "FETCH_SIZE" in cs:
+            cs["hbm_read_bytes"] = 2.0 * cs["FETCH_SIZE"] * 1024.0
+        if "WRITE_SIZE" in cs:
+            cs["hbm_write_bytes"] = cs["WRITE_SIZE"] * 1024.0
+        if "hbm_read_bytes" in cs and "hbm_write_bytes" in cs:
+            cs["hbm_traffic_bytes"] = cs["hbm_read_bytes"] + cs["hbm_write_bytes"]
+    return summary
+
+
+extra = {}
+for spec in a.extra:
+    name, dirs = spec.split("=", 1)
+    extra[name] = summarise(dirs.split(","))
 
 summary = collections.defaultdict(dict)
 for d in a.pmc:
@@ -97,6 +138,7 @@ for k, cs in video.items():
 if summary or video:
     sys.path.insert(0, root)
     import bench  # (kernel_sources_digest: what the counters were measured on; bench.py warns when the sources move on)
-    json.dump({"note": a.note, "kernel_sources_digest": bench.kernel_sources_digest(), "kernels": summary, "video_kernels": video},
-              open(os.path.join(out, f"{a.tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
-    print(json.dumps({"kernels": summary, "video_kernels": video}, indent=1, sort_keys=True))
+    doc = {"note": a.note, "kernel_sources_digest": bench.kernel_sources_digest(), "kernels": summary, "video_kernels": video}
+    doc.update(extra)
+    json.dump(doc, open(os.path.join(out, f"{a.tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: v for k, v in doc.items() if k != "note"}, indent=1, sort_keys=True))
