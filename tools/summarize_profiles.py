@@ -21,10 +21,11 @@ ap.add_argument("--video-pmc", nargs="*", default=[], help="PMC passes of tools/
 ap.add_argument("--extra", nargs="*", default=[], metavar="NAME=DIR[,DIR...]",
                 help="further PMC passes summarised the same way into their own section NAME (round 5: the uncapped parse "
                      "schedule, the TA / TCP / LDS counters of k_recon at two LDS footprints)")
+ap.add_argument("--out", default=None, help="directory to write into (default: profiles/ of the repository)")
 ap.add_argument("--note", default="")
 a = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = os.path.join(root, "profiles")
+out = a.out or os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
 for s in a.stats:
