@@ -1943,7 +1943,7 @@ int efx_debug_poke(efx_ctx* ctx, void* dptr, size_t bytes, long long offset_byte
 }
 
 // development: the header lines of k_recon_all's hand-over words after the most recent call (word 0 of each of the 64 lines;
-// lines 16 ... carry per-phase times only in an -DEFX_RA_STATS build: tools/r5_recon_check.py)
+// lines 16 ... carry per-phase times only in an -DEFX_RA_STATS build: tools/exp/r5_recon_check.py)
 int efx_debug_recon_stats(efx_ctx* ctx, uint32_t out[64])
 {
     bind_device(ctx);

@@ -677,7 +677,7 @@ constexpr uint32_t kSyncLine = 32;  // words per line
 constexpr uint32_t kSyncHeads = 0, kSyncSpins = 8 * kSyncLine, kSyncAbort = 9 * kSyncLine, kSyncDone = 64 * kSyncLine;
 #ifdef EFX_RA_STATS
 // (development build: where a wave's time goes, summed over the launch -- lines 16 ... of the header, one word per line;
-// read through efx_debug_recon_stats, tools/r5_recon_check.py)
+// read through efx_debug_recon_stats, tools/exp/r5_recon_check.py)
 constexpr uint32_t kSyncStats = 16 * kSyncLine;
 enum { kStWaves, kStItems, kStForeign, kStClaim, kStDep, kStBody, kStSignal, kStLife, kStXcc0 /* .. +7 */, kStCount = kStXcc0 + 8 };
 #define EFX_RA_T() wall_clock64()

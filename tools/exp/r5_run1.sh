@@ -4,8 +4,8 @@ export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r5a; mkdir -p $O
 rocminfo 2>/dev/null | grep -m1 -i "gfx950" > $O/box.txt
-( time timeout 400 python tools/r5_recon_check.py > $O/recon_check_a.jsonl 2> $O/recon_check_a.err ) 2> $O/recon_check_a.time; echo "check_a rc=$?" >> $O/rc.txt
-( time EFX_LIB=$GRAFT_REPO_ROOT/espflix_amd/libefx_b.so timeout 300 python tools/r5_recon_check.py quick > $O/recon_check_b.jsonl 2> $O/recon_check_b.err ) 2> $O/recon_check_b.time; echo "check_b rc=$?" >> $O/rc.txt
+( time timeout 400 python tools/exp/r5_recon_check.py > $O/recon_check_a.jsonl 2> $O/recon_check_a.err ) 2> $O/recon_check_a.time; echo "check_a rc=$?" >> $O/rc.txt
+( time EFX_LIB=$GRAFT_REPO_ROOT/espflix_amd/libefx_b.so timeout 300 python tools/exp/r5_recon_check.py quick > $O/recon_check_b.jsonl 2> $O/recon_check_b.err ) 2> $O/recon_check_b.time; echo "check_b rc=$?" >> $O/rc.txt
 MODE=2
 grep -q '"ALL_OK": true' $O/recon_check_a.jsonl || MODE=0
 echo "tests run with EFX_RECON_MODE=$MODE" >> $O/rc.txt

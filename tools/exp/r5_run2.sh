@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r5b; mkdir -p $O
 timeout 300 python tools/guard_selftest.py > $O/guard_selftest.txt 2>&1; echo "guard_selftest rc=$?" >> $O/rc.txt
-( time EFX_CHECK_LIBS=b,c,d,e,g,f timeout 600 python tools/r5_recon_check.py > $O/recon_check.jsonl 2> $O/recon_check.err ) 2> $O/recon_check.time; echo "check rc=$?" >> $O/rc.txt
+( time EFX_CHECK_LIBS=b,c,d,e,g,f timeout 600 python tools/exp/r5_recon_check.py > $O/recon_check.jsonl 2> $O/recon_check.err ) 2> $O/recon_check.time; echo "check rc=$?" >> $O/rc.txt
 MODE=2
 grep -q '"ALL_OK": true' $O/recon_check.jsonl || MODE=0
 echo "tests run with EFX_RECON_MODE=$MODE" >> $O/rc.txt

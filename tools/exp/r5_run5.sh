@@ -3,8 +3,8 @@
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r5e; mkdir -p $O
-timeout 400 python tools/r5_sweep.py 0 > $O/sweep_gop12.jsonl 2> $O/sweep_gop12.err; echo "sweep rc=$?" >> $O/rc.txt
-timeout 400 python tools/r5_sweep.py 36 > $O/sweep_wide.jsonl 2> $O/sweep_wide.err; echo "sweep wide rc=$?" >> $O/rc.txt
+timeout 400 python tools/exp/r5_sweep.py 0 > $O/sweep_gop12.jsonl 2> $O/sweep_gop12.err; echo "sweep rc=$?" >> $O/rc.txt
+timeout 400 python tools/exp/r5_sweep.py 36 > $O/sweep_wide.jsonl 2> $O/sweep_wide.err; echo "sweep wide rc=$?" >> $O/rc.txt
 ITEMS=$(tail -1 $O/sweep_gop12.jsonl | python -c "import json,sys; print(json.loads(sys.stdin.read())['best']['items_per_wave'])")
 WAVES=$(tail -1 $O/sweep_gop12.jsonl | python -c "import json,sys; print(json.loads(sys.stdin.read())['best']['waves_per_cu'])")
 echo "best: items $ITEMS waves $WAVES" >> $O/rc.txt
