@@ -4,10 +4,10 @@ set -e
 tag=$1; flags=$2
 d=/tmp/var_$tag; mkdir -p $d
 cd /root/repo
-for f in efx_api k_parse k_recon k_index; do
+for f in efx_api k_parse k_recon k_index k_demux; do
   extra=""; [ $f = k_recon ] && extra="-mllvm -amdgpu-atomic-optimizer-strategy=None"   # (as the Makefile does)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iespflix_amd/csrc $flags $extra -c espflix_amd/csrc/$f.hip -o $d/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $d/efx_api.o $d/k_parse.o $d/k_recon.o $d/k_index.o espflix_amd/csrc/k_demux.o espflix_amd/csrc/k_video.o espflix_amd/csrc/k_sbc.o espflix_amd/csrc/k_tsindex.o espflix_amd/csrc/efx_tables.o espflix_amd/csrc/efx_multi.o -o espflix_amd/libefx_$tag.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $d/efx_api.o $d/k_parse.o $d/k_recon.o $d/k_index.o $d/k_demux.o espflix_amd/csrc/k_video.o espflix_amd/csrc/k_sbc.o espflix_amd/csrc/k_tsindex.o espflix_amd/csrc/efx_tables.o espflix_amd/csrc/efx_multi.o -o espflix_amd/libefx_$tag.so
 echo built $tag
