@@ -29,9 +29,6 @@ namespace {
 constexpr int kChunk = 128;  // packets per workgroup iteration
 constexpr int kTsPacket = 188;
 constexpr int kThreads = 256;
-#ifndef EFX_DEMUX_STAGE
-#define EFX_DEMUX_STAGE 1
-#endif
 
 __device__ inline uint32_t wave_incl_scan(uint32_t v)
 {
@@ -289,12 +286,9 @@ __device__ __forceinline__ void demux_gather_body(const uint8_t* __restrict__ ts
                                                   const DemuxChunk* __restrict__ chunks, uint8_t* __restrict__ es,
                                                   const uint64_t* __restrict__ out_off, PesEntry* __restrict__ pes)
 {
-    // EFX_DEMUX_STAGE = 1: the chunk is staged in LDS (24 KB per workgroup: 6 workgroups per CU) and parsed / gathered from
-    // there; 0: headers and payload are read straight from global memory (the chunk is 24 KB of L2-resident lines that its own
-    // workgroup reads: the staging bought LDS latency for a third of the residency), 1.6 KB of LDS per workgroup.
-    __shared__ uint4 sh_pkt4[EFX_DEMUX_STAGE ? kChunk * kTsPacket / 16 + 1 : 1];
+    __shared__ uint4 sh_pkt4[kChunk * kTsPacket / 16 + 1];
     __shared__ uint32_t sh_prefix[kChunk + 1];  // exclusive prefix of payload bytes; [npk] = chunk total
-    __shared__ int32_t sh_src[kChunk];          // byte offset of the payload inside the chunk (-1: emit a zero byte)
+    __shared__ int32_t sh_src[kChunk];          // LDS byte offset of the payload (-1: emit a zero byte)
     __shared__ uint32_t sh_wave[2][4];          // per-wave totals: payload bytes, PTS flags
     __shared__ uint32_t sh_gate[2];
 
@@ -308,18 +302,16 @@ __device__ __forceinline__ void demux_gather_body(const uint8_t* __restrict__ ts
     PesEntry* my_pes = AUDIO ? nullptr : pes + pkt_base[s];
     const DemuxChunk base = chunks[chunk_slot(pkt_base[s], s) + blockIdx.x];
     const uint32_t es_pos = base.bytes, n_pes = base.n_pes;
+    const uint8_t* pk = reinterpret_cast<const uint8_t*>(sh_pkt4);
     const uint32_t npk = min((uint32_t)kChunk, n_packets - first);
-    // the chunk's bytes: in LDS or where they lie (16-byte aligned: 128 * 188 = 16 * 1504, streams start on 16-byte multiples)
-    const uint8_t* const chunk_g = src + (size_t)first * kTsPacket;
-    const uint8_t* const pk = EFX_DEMUX_STAGE ? reinterpret_cast<const uint8_t*>(sh_pkt4) : chunk_g;
     // ---- 1. stage the chunk --------------------------------------------------------------
-    if (EFX_DEMUX_STAGE) {
-        const uint4* g = reinterpret_cast<const uint4*>(chunk_g);
+    {
+        const uint4* g = reinterpret_cast<const uint4*>(src + (size_t)first * kTsPacket);  // 128 * 188 = 16 * 1504
         const uint32_t n16 = (npk * kTsPacket + 15) / 16;  // may read <= 15 bytes past the packets: inside the buffer
         for (uint32_t i = tid; i < n16; i += kThreads)
             sh_pkt4[i] = g[i];
-        __syncthreads();
     }
+    __syncthreads();
     // ---- 2. one thread per packet --------------------------------------------------------
     uint32_t n = 0, has_pts = 0, gate = 0;
     int32_t from = 0;
@@ -327,7 +319,7 @@ __device__ __forceinline__ void demux_gather_body(const uint8_t* __restrict__ ts
     if ((uint32_t)tid < npk) {
         const uint8_t* p = pk + tid * kTsPacket;
         parse_packet<AUDIO>([&](int i) { return (uint32_t)p[i]; }, from, n, pts, has_pts, gate);
-        if (from > 0)
+        if (from > 0 || (from == 0 && n))
             from += tid * kTsPacket;
     }
     const int wave = tid >> 6, lane = tid & 63;
@@ -365,25 +357,17 @@ __device__ __forceinline__ void demux_gather_body(const uint8_t* __restrict__ ts
             sh_prefix[kChunk] = total;
     }
     __syncthreads();
-    // ---- 4. gather: one destination group of 16 bytes per thread and pass ------------------
-    // (one search per group; a group that lies inside one packet's payload -- eleven in twelve -- is five aligned dwords
-    // funnel-shifted into four and ONE 16-byte store; the groups across packet boundaries and the ragged chunk edges -- shared
-    // with the neighbouring chunks' workgroups, each writing its own bytes -- go byte by byte).  A chunk holds at most
-    // 128 x 184 payload bytes = 1472 groups (+ 1 for a ragged start): six passes of 256 threads; the searches of all six are
-    // done before the first load is issued, so that a thread's loads are in flight together.
+    // ---- 4. gather: one destination group of 16 bytes per thread --------------------------
+    // (one search per group; a group that lies inside one packet's payload -- eleven in twelve -- is five aligned LDS
+    // dwords funnel-shifted into four and ONE 16-byte store; the groups across packet boundaries and the ragged
+    // chunk edges -- shared with the neighbouring chunks' workgroups, each writing its own bytes -- go byte by byte)
     const uint32_t lo = es_pos, hi = es_pos + total;
-    const uint32_t* pk32 = reinterpret_cast<const uint32_t*>(pk);
-    constexpr int kPasses = 6;
-    static_assert(kPasses * kThreads >= kChunk * (kTsPacket - 4) / 16 + 2, "every output group of a chunk has its pass");
-    uint32_t rel_[kPasses], next_[kPasses], at_[kPasses];
-    int a_[kPasses];
-    bool fast_[kPasses];
-#pragma unroll
-    for (int ps = 0; ps < kPasses; ps++) {
-        const uint32_t g0 = ((lo >> 4) + tid + ps * kThreads) * 16;
+    const uint32_t* pk32 = reinterpret_cast<const uint32_t*>(sh_pkt4);
+    for (uint32_t g = (lo >> 4) + tid; g * 16 < hi; g += kThreads) {
+        const uint32_t g0 = g * 16;
         const uint32_t first_o = max(g0, lo), last_o = min(g0 + 16, hi);  // bytes [first_o, last_o) of this group
         // packet holding byte first_o: the last j with prefix[j] <= rel (zero-length packets share a prefix)
-        const uint32_t rel = g0 < hi ? first_o - lo : 0u;
+        uint32_t rel = first_o - lo;
         int a = 0, b = kChunk;  // invariant: prefix[a] <= rel < prefix[b]
 #pragma unroll
         for (int it = 0; it < 7; it++) {
@@ -393,37 +377,15 @@ __device__ __forceinline__ void demux_gather_body(const uint8_t* __restrict__ ts
             else
                 b = m;
         }
-        const uint32_t next = sh_prefix[a + 1];
+        uint32_t next = sh_prefix[a + 1];
         const int32_t sp0 = sh_src[a];
-        rel_[ps] = rel;
-        next_[ps] = next;
-        a_[ps] = a;
-        fast_[ps] = g0 < hi && last_o - first_o == 16 && sp0 >= 0 && next - rel >= 16;
-        at_[ps] = (uint32_t)sp0 + (rel - sh_prefix[a]);
-    }
-    uint32_t d_[kPasses][5];
-#pragma unroll
-    for (int ps = 0; ps < kPasses; ps++) {
-        const uint32_t w = fast_[ps] ? at_[ps] >> 2 : 0u;  // (a thread without a fast group reads the chunk's first dwords: no branch around the loads)
-#pragma unroll
-        for (int k = 0; k < 5; k++)
-            d_[ps][k] = pk32[w + k];
-    }
-#pragma unroll
-    for (int ps = 0; ps < kPasses; ps++) {
-        const uint32_t g0 = ((lo >> 4) + tid + ps * kThreads) * 16;
-        if (g0 >= hi)
-            continue;
-        if (fast_[ps]) {
-            const uint32_t sh = (at_[ps] & 3) * 8;
-            *reinterpret_cast<uint4*>(dst + g0) =
-                make_uint4(__builtin_amdgcn_alignbit(d_[ps][1], d_[ps][0], sh), __builtin_amdgcn_alignbit(d_[ps][2], d_[ps][1], sh),
-                           __builtin_amdgcn_alignbit(d_[ps][3], d_[ps][2], sh), __builtin_amdgcn_alignbit(d_[ps][4], d_[ps][3], sh));
+        if (last_o - first_o == 16 && sp0 >= 0 && next - rel >= 16) {
+            const uint32_t at = (uint32_t)sp0 + (rel - sh_prefix[a]), w = at >> 2, sh = (at & 3) * 8;
+            const uint32_t d0 = pk32[w], d1 = pk32[w + 1], d2 = pk32[w + 2], d3 = pk32[w + 3], d4 = pk32[w + 4];
+            *reinterpret_cast<uint4*>(dst + g0) = make_uint4(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
+                                                            __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh));
             continue;
         }
-        const uint32_t first_o = max(g0, lo), last_o = min(g0 + 16, hi);
-        uint32_t rel = rel_[ps], next = next_[ps];
-        int a = a_[ps];
         for (uint32_t o0 = first_o & ~3u; o0 < last_o; o0 += 4) {
             const uint32_t f_o = max(o0, first_o), l_o = min(o0 + 4, last_o);
             uint32_t word = 0;
