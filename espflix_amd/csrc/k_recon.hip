@@ -139,6 +139,9 @@ constexpr int kLaneHalfwords = 2 * kLaneDwords;
 // L1 is never refreshed by another CU's stores and the XCDs' L2s are not coherent with each other:
 // MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"); the hand-over itself is the
 // per-stream counter of k_recon_all.
+#ifndef EFX_RECON_PER_ROUND
+#define EFX_RECON_PER_ROUND 3  // coefficient entries a lane takes per round of the wave's entry dealing
+#endif
 #ifndef EFX_RECON_LDS_PAD
 #define EFX_RECON_LDS_PAD 0  // (counter experiments: unused dwords of LDS per wave, to hold k_recon to fewer waves per CU)
 #endif
@@ -343,7 +346,7 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
     // Three entries per lane per round: the owners are searched and all loads issued before the first entry
     // is used -- a wave is alive for as many memory round trips as it makes one after the other, and with
     // one load per loop trip the entries alone cost it three (-5.5 % per launch).
-    constexpr int kPerRound = 3;
+    constexpr int kPerRound = EFX_RECON_PER_ROUND;
     int own[kPerRound], own_next[kPerRound];
     uint32_t ent[kPerRound], ent_next[kPerRound];
     auto fetch = [&](uint32_t i0, int (&own)[kPerRound], uint32_t (&ent)[kPerRound]) {
