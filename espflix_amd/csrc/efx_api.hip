@@ -46,17 +46,25 @@ __global__ void k_frame_hash(const uint8_t*, int, uint64_t*);
 __global__ void k_fill(uint32_t*, uint32_t, size_t);
 __global__ void k_composite(const uint8_t*, const VideoTables*, const VideoLineTemplates*, FieldArgs, uint16_t*);
 __global__ void k_pdm(const int16_t*, int, int, int32_t*, uint16_t*);
-__global__ void k_sbc(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int,
-                      const uint32_t*);
-__global__ void k_sbc_par_stereo(const uint8_t*, size_t, int, int, const SbcState*, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*,
-                                 uint32_t*, int, const uint32_t*);
-__global__ void k_sbc_par_mono(const uint8_t*, size_t, int, int, const SbcState*, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*,
-                               uint32_t*, int, const uint32_t*);
-__global__ void k_sbc_commit(SbcState*, const SbcState*, const uint32_t*);
-__global__ void k_sbc_check(const uint8_t*, size_t, int, int, uint32_t*);
+__global__ void k_sbc(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int);
+__global__ void k_sbc_frames(const uint8_t*, size_t, int, int, SbcFrameInfo*, uint32_t*, uint32_t*);
+__global__ void k_sbc_plan(const SbcFrameInfo*, int, int, const SbcState*, SbcFramePlan*, uint32_t*, SbcQueues*, uint32_t*, int, int, uint32_t*,
+                           uint32_t*);
+__global__ void k_sbc_par_stereo(const uint8_t*, size_t, int, int, const SbcState*, SbcState*, const SbcTables*, const SbcFrameInfo*, int16_t*,
+                                 size_t, uint32_t*, int, SbcQueues*, const uint32_t*, int);
+__global__ void k_sbc_par_mono(const uint8_t*, size_t, int, int, const SbcState*, SbcState*, const SbcTables*, const SbcFrameInfo*, int16_t*,
+                               size_t, uint32_t*, int, SbcQueues*, const uint32_t*, int);
+__global__ void k_sbc_gen(const uint8_t*, size_t, int, int, const SbcState*, SbcState*, const SbcTables*, const SbcFrameInfo*,
+                          const SbcFramePlan*, int16_t*, size_t, int, SbcQueues*, const uint32_t*, int);
+__global__ void k_sbc_finish(const uint8_t*, size_t, int, int, SbcState*, const SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*,
+                             uint32_t*, int, uint32_t*);
 }  // namespace efx
 
 using namespace efx;
+
+#ifndef EFX_SBC_WG_PER_CU
+#define EFX_SBC_WG_PER_CU 4  // k_sbc_par_mono workgroups per compute unit (k_sbc.hip: EFX_SBC_WAVES)
+#endif
 
 #ifndef EFX_PARSE_STREAMS
 #define EFX_PARSE_STREAMS 2
@@ -208,9 +216,16 @@ struct efx_ctx {
     int opt_recon_waves = 0;   // k_recon_all with opt_recon_items = 0: workgroups per compute unit (0 = 18, what its LDS admits)
     int opt_recon_items = 16;  // k_recon_all: items a wave takes before it ends (0: until none is left)
     int n_cus = 256;
-    uint32_t* d_sbc_flags = nullptr;  // per stream of an efx_sbc_decode call: 1 = decoded frame-parallel (k_sbc_check)
-    SbcState* d_sbc_next = nullptr;   // ... the state its frame-parallel kernel leaves, put in place by k_sbc_commit
+    // efx_sbc_decode's scratch.  d_sbc_flags: n words per stream-indexed array -- [0, n) which kernel decodes the stream
+    // (k_sbc_frames / k_sbc_plan), [n, 4n) the three work lists; then the SbcQueues
+    uint32_t* d_sbc_flags = nullptr;
+    SbcState* d_sbc_next = nullptr;   // the state a frame-parallel kernel leaves, put in place by k_sbc_commit
     size_t sbc_flags_cap = 0;
+    SbcFrameInfo* d_sbc_info = nullptr;  // per (stream, frame)
+    SbcFramePlan* d_sbc_plan = nullptr;  // per (stream, frame + 1)
+    size_t sbc_info_cap = 0;             // in frames: streams x (frames + 1)
+    int opt_sbc_serial = 0;              // 1 = every stream through k_sbc, one wave per stream (the tests' comparison)
+    bool sbc_flags_clean = false;        // d_sbc_flags[0, n) all kSbcRegularFlag (k_sbc_finish leaves them so)
     uint64_t* d_hash = nullptr;
 
     // results of the last decode (fetch_results)
@@ -643,7 +658,7 @@ void efx_destroy(efx_ctx* ctx)
         else
             (void)hipHostUnregister(a.base);
     }
-    void* bufs[] = {ctx->d_tables, ctx->d_tm_tables, ctx->d_sbc_flags, ctx->d_sbc_next, ctx->d_state, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0],
+    void* bufs[] = {ctx->d_tables, ctx->d_tm_tables, ctx->d_sbc_flags, ctx->d_sbc_next, ctx->d_sbc_info, ctx->d_sbc_plan, ctx->d_state, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0],
                     ctx->d_video_lines[1], ctx->d_hash, ctx->d_ts, ctx->d_demux_chunks, ctx->d_sbc_tables, ctx->d_idx_info, ctx->d_ts_off, ctx->d_idx_len,
                     ctx->d_idx_base, ctx->d_idx_seq};
     for (auto& te : ctx->timing_ring)
@@ -1039,6 +1054,9 @@ int efx_set_option(efx_ctx* ctx, int option, int value)
     case EFX_OPT_RECON_ITEMS:
         ctx->opt_recon_items = value;
         return EFX_OK;
+    case EFX_OPT_SBC_SERIAL:
+        ctx->opt_sbc_serial = value != 0;
+        return EFX_OK;
     default:
         return EFX_ERR_ARG;
     }
@@ -1055,6 +1073,7 @@ int efx_get_option(efx_ctx* ctx, int option, int* value)
     case EFX_OPT_RECON_MODE: *value = ctx->opt_recon_mode; return EFX_OK;
     case EFX_OPT_RECON_WAVES: *value = ctx->opt_recon_waves; return EFX_OK;
     case EFX_OPT_RECON_ITEMS: *value = ctx->opt_recon_items; return EFX_OK;
+    case EFX_OPT_SBC_SERIAL: *value = ctx->opt_sbc_serial; return EFX_OK;
     case EFX_OPT_RECON_SPINS: {
         int r = sync_all(ctx);
         if (r)
@@ -1817,8 +1836,16 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
     if (!ctx || !frames_device || !state_device || !pcm_device || n_streams <= 0 || n_frames < 0 || frame_bytes <= 0 ||
         (size_t)frame_bytes * (size_t)n_frames > 0x7FFFFFFFu || ((uintptr_t)state_device & 3))
         return EFX_ERR_ARG;
-    // which streams decode frame-parallel (every frame accepted, one geometry): k_sbc_check; those k_sbc_par takes, the rest
-    // -- a rejected frame re-synthesises its predecessor's samples: a chain -- the one-wave-per-stream kernel
+    SbcState* const state = static_cast<SbcState*>(state_device);
+    if (n_frames == 0 || ctx->opt_sbc_serial) {
+        // one wave per stream walking its frames (no frames: it leaves the state as it reads it and a PCM count of zero)
+        hipLaunchKernelGGL(k_sbc, dim3(n_streams), dim3(64), 0, ctx->stream, frames_device, stream_stride, frame_bytes, n_frames, state,
+                           ctx->d_sbc_tables, pcm_device, pcm_stride, ret_device, pcm_count_device, flags);
+        EFX_HIP(hipGetLastError());
+        return EFX_OK;
+    }
+    // scratch: which kernel decodes a stream + the three work lists + their counters; the states on their way; per frame the
+    // bit allocation (k_sbc_frames) and, for streams that are not regular, the plan (k_sbc_plan)
     if ((size_t)n_streams > ctx->sbc_flags_cap) {
         if (ctx->d_sbc_flags)
             (void)dev_free(ctx->d_sbc_flags);
@@ -1827,30 +1854,55 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
         ctx->d_sbc_flags = nullptr;
         ctx->d_sbc_next = nullptr;
         ctx->sbc_flags_cap = 0;
-        EFX_HIP(dalloc(&ctx->d_sbc_flags, (size_t)n_streams));
+        EFX_HIP(dalloc(&ctx->d_sbc_flags, (size_t)n_streams * 4 + sizeof(SbcQueues) / 4));
         EFX_HIP(dalloc(&ctx->d_sbc_next, (size_t)n_streams));
         ctx->sbc_flags_cap = (size_t)n_streams;
+        ctx->sbc_flags_clean = false;
     }
-    EFX_HIP(hipMemsetAsync(ctx->d_sbc_flags, 0xFF, (size_t)n_streams * sizeof(uint32_t), ctx->stream));
-    if (n_frames > 0) {
-        hipLaunchKernelGGL(k_sbc_check, dim3((n_frames + 255) / 256, n_streams), dim3(256), 0, ctx->stream, frames_device, stream_stride,
-                           frame_bytes, n_frames, ctx->d_sbc_flags);
-        // (one instantiation per channel count: a workgroup whose stream is of the other kind leaves at once)
-        hipLaunchKernelGGL(k_sbc_par_mono, dim3((n_frames + 7) / 8, n_streams), dim3(256), 0, ctx->stream, frames_device, stream_stride,
-                           frame_bytes, n_frames, static_cast<SbcState*>(state_device), ctx->d_sbc_next, ctx->d_sbc_tables, pcm_device,
-                           pcm_stride, ret_device, pcm_count_device, flags, ctx->d_sbc_flags);
-        hipLaunchKernelGGL(k_sbc_par_stereo, dim3((n_frames + 7) / 8, n_streams), dim3(256), 0, ctx->stream, frames_device, stream_stride,
-                           frame_bytes, n_frames, static_cast<SbcState*>(state_device), ctx->d_sbc_next, ctx->d_sbc_tables, pcm_device,
-                           pcm_stride, ret_device, pcm_count_device, flags, ctx->d_sbc_flags);
-        // (the last chunk of a stream must not overwrite the state its first chunk is still reading: the new states wait in
-        // d_sbc_next until both kernels are through)
-        hipLaunchKernelGGL(k_sbc_commit, dim3(n_streams), dim3(256), 0, ctx->stream, static_cast<SbcState*>(state_device), ctx->d_sbc_next,
-                           ctx->d_sbc_flags);
+    const size_t info_need = (size_t)n_streams * ((size_t)n_frames + 1);
+    if (info_need > ctx->sbc_info_cap) {
+        if (ctx->d_sbc_info)
+            (void)dev_free(ctx->d_sbc_info);
+        if (ctx->d_sbc_plan)
+            (void)dev_free(ctx->d_sbc_plan);
+        ctx->d_sbc_info = nullptr;
+        ctx->d_sbc_plan = nullptr;
+        ctx->sbc_info_cap = 0;
+        EFX_HIP(dalloc(&ctx->d_sbc_info, info_need));
+        EFX_HIP(dalloc(&ctx->d_sbc_plan, info_need));
+        ctx->sbc_info_cap = info_need;
     }
-    hipLaunchKernelGGL(k_sbc, dim3(n_streams), dim3(64), 0, ctx->stream, frames_device, stream_stride, frame_bytes, n_frames,
-                       static_cast<SbcState*>(state_device), ctx->d_sbc_tables, pcm_device, pcm_stride, ret_device,
-                       pcm_count_device, flags, n_frames > 0 ? ctx->d_sbc_flags : nullptr);
+    uint32_t* const d_how = ctx->d_sbc_flags;
+    uint32_t* const d_lists = d_how + ctx->sbc_flags_cap;
+    SbcQueues* const d_queues = reinterpret_cast<SbcQueues*>(d_how + 4 * ctx->sbc_flags_cap);
+    // parallel[]: every word kSbcRegularFlag when k_sbc_frames starts -- as the previous call's k_sbc_finish left them
+    if (!ctx->sbc_flags_clean)
+        EFX_HIP(hipMemsetAsync(d_how, 0xFF, ctx->sbc_flags_cap * sizeof(uint32_t), ctx->stream));
+    ctx->sbc_flags_clean = false;
+    hipLaunchKernelGGL(k_sbc_frames, dim3((n_frames + 255) / 256, n_streams), dim3(256), 0, ctx->stream, frames_device, stream_stride,
+                       frame_bytes, n_frames, ctx->d_sbc_info, ret_device, d_how);
+    hipLaunchKernelGGL(k_sbc_plan, dim3(n_streams + 1), dim3(256), 0, ctx->stream, ctx->d_sbc_info, n_frames, flags, state, ctx->d_sbc_plan,
+                       d_how, d_queues, d_lists, n_streams, (int)ctx->sbc_flags_cap, ret_device, pcm_count_device);
+    // Persistent workgroups take (stream, chunk of frames) items off the list of their kind, dealt round robin; a list that
+    // stayed empty costs its kernel one look.  Grids = what is resident at a time: EFX_SBC_WG_PER_CU workgroups per compute unit
+    // 
+    // for the mono kernel (16 frames per item: 36 KB of LDS), 4 for the other two (35 KB of LDS).
+    const long long items = (long long)n_streams * ((n_frames + 8) / 8);
+    const int g_mono = (int)std::min<long long>(items, (long long)ctx->n_cus * EFX_SBC_WG_PER_CU), g_wide = (int)std::min<long long>(items, (long long)ctx->n_cus * 4);
+    hipLaunchKernelGGL(k_sbc_par_mono, dim3(g_mono), dim3(256), 0, ctx->stream, frames_device, stream_stride, frame_bytes, n_frames, state,
+                       ctx->d_sbc_next, ctx->d_sbc_tables, ctx->d_sbc_info, pcm_device, pcm_stride, pcm_count_device, flags, d_queues, d_lists,
+                       (int)ctx->sbc_flags_cap);
+    hipLaunchKernelGGL(k_sbc_par_stereo, dim3(g_wide), dim3(256), 0, ctx->stream, frames_device, stream_stride, frame_bytes, n_frames, state,
+                       ctx->d_sbc_next, ctx->d_sbc_tables, ctx->d_sbc_info, pcm_device, pcm_stride, pcm_count_device, flags, d_queues, d_lists,
+                       (int)ctx->sbc_flags_cap);
+    hipLaunchKernelGGL(k_sbc_gen, dim3(g_wide), dim3(256), 0, ctx->stream, frames_device, stream_stride, frame_bytes, n_frames, state,
+                       ctx->d_sbc_next, ctx->d_sbc_tables, ctx->d_sbc_info, ctx->d_sbc_plan, pcm_device, pcm_stride, flags, d_queues, d_lists,
+                       (int)ctx->sbc_flags_cap);
+    // the new states take their place; a stream whose state no call of this library can have left is decoded by one wave
+    hipLaunchKernelGGL(k_sbc_finish, dim3(n_streams), dim3(64), 0, ctx->stream, frames_device, stream_stride, frame_bytes, n_frames, state,
+                       ctx->d_sbc_next, ctx->d_sbc_tables, pcm_device, pcm_stride, ret_device, pcm_count_device, flags, d_how);
     EFX_HIP(hipGetLastError());
+    ctx->sbc_flags_clean = true;
     return EFX_OK;
 }
 

@@ -152,6 +152,46 @@ struct FieldArgs {
 struct SbcTables {
     int32_t syn[128];   // syn[i * 8 + k] = floor(65536 cos((i + 4)(2k + 1) pi / 16))
     int32_t proto[80];  // proto[i * 10 + j] = floor(-8 * 32768 * Proto_8_80[8 j + i])
+    // IQUANT's C division by 2^bits - 1 (sbc_decoder.cpp:263-270) as a multiplication: the round-up constant
+    // m' = floor(2^32 (2^l - d) / d) + 1 of Granlund & Montgomery's unsigned division (l = bits; d = 1: m' = 1, no shifts):
+    // a / d = (t + ((a - t) >> 1)) >> (bits - 1), t = mulhi(m', a), for every 32-bit a
+    uint32_t iq_magic[20];
+};
+
+// What k_sbc_frames leaves per (stream, frame): the header's verdict and the bit allocation -- one thread per frame with all
+// 64 lanes of a wave busy, instead of once per workgroup that has the frame in reach.
+struct alignas(16) SbcFrameInfo {
+    uint8_t bits[2][8];       // bits of a sample of (channel, subband)
+    uint8_t prefix[2][8];     // ... and where it starts inside a block's bits
+    uint16_t per_block;       // bits of one block, all channels
+    uint16_t framelen;        // get_samples()'s return value (0xFFFF = -1)
+    uint8_t h1, bitpool, flags, pad;
+    uint32_t pad2[2];
+};
+static_assert(sizeof(SbcFrameInfo) == 48, "SbcFrameInfo is moved as three uint4");
+constexpr uint32_t kSbcSync = 1, kSbcOk = 2;  // flags: sync byte and length in order (the header moves the geometry); decodable
+
+// What k_sbc_plan leaves per (stream, VIRTUAL frame) of a stream that is not regular (virtual frame v = frame max(v - probe, 0):
+// decode_audio()'s frame-size probe decodes frame 0 once more up front).  Everything the reference chains from frame to frame
+// -- the geometry a rejected frame is synthesised under, the stale samples it synthesises, where its PCM goes, where its rows
+// sit on a channel's timeline of matrixing outputs -- as prefix scans, so that any chunk of frames can be decoded on its own.
+struct alignas(16) SbcFramePlan {
+    int32_t src[8];     // [q * 2 + c]: the frame whose get_samples() last wrote blocks 4q .. 4q+3 of channel c; -1 = the state's
+    uint32_t pcm_off;   // PCM samples of this call before this frame's
+    uint32_t vb[2];     // rows on channel c's timeline before this frame's
+    int32_t back[2];    // the latest earlier frame with rows on channel c's timeline; -1 = none in this call
+    int32_t gsrc;       // the frame whose header left the geometry this frame is synthesised under; -1 = the state's
+    uint32_t geom;      // blocks | channels << 8 | synthesised << 16
+    uint32_t pad;
+};
+static_assert(sizeof(SbcFramePlan) == 64, "SbcFramePlan is moved as four uint4");
+
+// efx_sbc_decode's work lists: streams by the kernel that decodes them (kSbcMono / kSbcStereo: regular streams -- every frame
+// decodes, one geometry --, kSbcGeneral: the rest), filled by k_sbc_plan, drained by persistent workgroups
+constexpr int kSbcMono = 0, kSbcStereo = 1, kSbcGeneral = 2;
+struct SbcQueues {
+    uint32_t count[4];  // streams on list c
+    uint32_t next[4];   // next (stream, chunk) item of list c
 };
 
 // per-stream SBC decoder state (the reference's SBC_Decode, sbc_decoder.h:12-25, with the sliding

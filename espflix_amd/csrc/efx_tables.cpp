@@ -194,6 +194,10 @@ void build_sbc_tables(SbcTables* t)
             p = -p;
         t->proto[(n & 7) * 10 + (n >> 3)] = p == 0 ? 0 : (int32_t)std::floor(-8.0 * 32768.0 * p);
     }
+    for (int bits = 0; bits < 20; bits++) {
+        const uint64_t d = bits >= 1 && bits <= 16 ? (1ull << bits) - 1 : 1;
+        t->iq_magic[bits] = d == 1 ? 1u : (uint32_t)((1ull << 32) / d + 1);  // (2^l - d = 1 for d = 2^l - 1)
+    }
 }
 
 }  // namespace efx

@@ -5,21 +5,28 @@
 // decode_audio() drives it (src/video.cpp:962-989): a stream is a run of equally sized frames
 // decoded in order, the synthesis filter memory carrying over from frame to frame.
 //
-// Two paths.  The synthesis filter is an FIR: the matrixing outputs of a block depend on that block's samples only, a PCM
-// sample on the last ten blocks' outputs -- so a stream whose frames all decode and share one geometry (k_sbc_check) is
-// decoded FRAME-PARALLEL by k_sbc_par: a workgroup takes eight consecutive frames, dequantises them and the nine blocks
-// before them, matrixes, windows.  What chains from frame to frame in the reference -- a rejected frame re-synthesising
-// the PREVIOUS frame's samples under the geometry its header left behind -- stays with k_sbc, one wave per stream walking
-// its frames; INSIDE a frame nothing is serial there either:
+// FRAME-PARALLEL.  The synthesis filter is an FIR: the matrixing outputs of a block depend on that block's samples only, a
+// PCM sample on the last ten blocks' outputs -- a workgroup takes eight consecutive frames, dequantises them and the frames
+// that hold the nine blocks before them, matrixes, windows.  The kernels of an efx_sbc_decode call:
+//   k_sbc_frames   one thread per frame: the header's verdict and the bit allocation (SbcFrameInfo) -- the one long serial
+//                  piece of a frame, with every lane of its waves busy;
+//   k_sbc_plan     one wave per stream: sorts the stream onto a work list -- REGULAR (every frame decodes, one geometry; mono /
+//                  stereo) or GENERAL -- and, for a general stream, resolves what the reference chains from frame to frame (a
+//                  rejected frame re-synthesises the samples and the geometry the state holds: sbc_decoder.cpp:346-373) into
+//                  prefix scans over the frames (SbcFramePlan);
+//   k_sbc_par_*    persistent workgroups that pull (stream, chunk of eight frames) items of the regular lists;
+//   k_sbc_gen      the same for the general list, every index looked up in the plan instead of computed in closed form;
+//   k_sbc_commit   puts the new decoder states in place (the last chunk of a stream must not overwrite the state its first
+//                  chunk may still be reading).
+// k_sbc, one wave per stream walking its frames, stays for a state no efx_sbc_decode call can have left (a block count that
+// is no multiple of four) and as the comparison the tests run the other kernels against (EFX_OPT_SBC_SERIAL).  In all of them:
 //   * the reference's lazy bit reader is replaced by direct addressing -- every block of a frame
 //     has the same layout, so sample (blk, ch, sb) starts at bit blk * bits_per_block +
 //     prefix[ch][sb] -- one lane per sample extracts, dequantises (32-bit wrapping shift, C
 //     division) and stores it;
 //   * the reference's sliding buffer v[170] + 16 offsets (a 10-deep history per matrix output) is
 //     kept as rows: row t holds the 16 matrixing outputs of block t.  The matrixing of ALL blocks
-//     of the frame is computed at once (16 x 8 MACs per block, one lane per output), then the
-//     windowing of all blocks (10 MACs per PCM sample, one lane per sample) reads rows t .. t-9,
-//     the first nine of which are the previous frame's;
+//     in reach is computed at once, then the windowing of all blocks reads rows t .. t-9;
 //   * accumulation is 32-bit wrapping, >> 15 arithmetic, clip to +-0x7FFF exactly as the reference.
 // Frames the reference rejects behave as it does: a bad sync byte re-synthesises the state's
 // previous subband samples, joint stereo switches the geometry and synthesises stale samples, a
@@ -30,6 +37,8 @@
 #include "efx.h"
 
 namespace efx {
+
+constexpr uint32_t kSbcRegularFlag = 0xFFFFFFFFu, kSbcGeneralFlag = 0, kSbcSerialFlag = 2;  // parallel[stream]
 
 namespace {
 
@@ -50,6 +59,7 @@ __device__ void bit_allocation(int frequency, int allocation, int bitpool, const
     const int8_t offset8[4][8] = {{-2, 0, 0, 0, 0, 0, 0, 1}, {-3, 0, 0, 0, 0, 0, 1, 2}, {-4, 0, 0, 0, 0, 0, 1, 2}, {-4, 0, 0, 0, 0, 0, 1, 2}};
     int bitneed[8];
     int max_bitneed = 0;
+#pragma unroll
     for (int sb = 0; sb < 8; sb++) {
         int s = scale[sb];
         int need;
@@ -71,6 +81,7 @@ __device__ void bit_allocation(int frequency, int allocation, int bitpool, const
         bitslice--;
         bitcount += slicecount;
         slicecount = 0;
+#pragma unroll
         for (int sb = 0; sb < 8; sb++) {
             if (bitneed[sb] > bitslice + 1 && bitneed[sb] < bitslice + 16)
                 slicecount++;
@@ -82,23 +93,30 @@ __device__ void bit_allocation(int frequency, int allocation, int bitpool, const
         bitcount += slicecount;
         bitslice--;
     }
+#pragma unroll
     for (int sb = 0; sb < 8; sb++) {
         int b = 0;
         if (bitneed[sb] >= bitslice + 2)
             b = min(bitneed[sb] - bitslice, 16);
         bits[sb] = b;
     }
-    for (int sb = 0; bitcount < bitpool && sb < 8; sb++) {
-        if (bits[sb] >= 2 && bits[sb] < 16) {
-            bits[sb]++;
-            bitcount++;
-        } else if (bitneed[sb] == bitslice + 1 && bitpool > bitcount + 1) {
-            bits[sb] = 2;
-            bitcount += 2;
+    // (both loops written out: with the subband a constant, bits[] and bitneed[] stay registers -- the rolled loops indexed
+    // them through chains of selects, ten times the instructions)
+#pragma unroll
+    for (int sb = 0; sb < 8; sb++) {
+        if (bitcount < bitpool) {
+            if (bits[sb] >= 2 && bits[sb] < 16) {
+                bits[sb]++;
+                bitcount++;
+            } else if (bitneed[sb] == bitslice + 1 && bitpool > bitcount + 1) {
+                bits[sb] = 2;
+                bitcount += 2;
+            }
         }
     }
-    for (int sb = 0; bitcount < bitpool && sb < 8; sb++)
-        if (bits[sb] < 16) {
+#pragma unroll
+    for (int sb = 0; sb < 8; sb++)
+        if (bitcount < bitpool && bits[sb] < 16) {
             bits[sb]++;
             bitcount++;
         }
@@ -112,14 +130,12 @@ __device__ void bit_allocation(int frequency, int allocation, int bitpool, const
 // (stream, frame) the reference's return value in the low 16 bits (0xFFFF = -1) and the decoded
 // byte count in the high 16.  flags bit 0: decode frame 0 once more up front and drop its PCM
 // (decode_audio()'s frame-size probe, video.cpp:964-972).
-__global__ __launch_bounds__(64) void k_sbc(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
-                                            int n_frames, SbcState* __restrict__ states,
-                                            const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
-                                            size_t pcm_stride, uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count,
-                                            int flags, const uint32_t* __restrict__ parallel)
+__device__ __forceinline__ void sbc_serial_body(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
+                                                int n_frames, SbcState* __restrict__ states,
+                                                const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
+                                                size_t pcm_stride, uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count,
+                                                int flags)
 {
-    if (parallel && parallel[blockIdx.x])
-        return;  // (k_sbc_par decodes this stream)
     __shared__ SbcTables tb;
     __shared__ int32_t sb_sample[16][2][8];  // the reference's sb_sample (persists across frames)
     __shared__ int32_t rows[2][9 + 16][16];   // matrixing outputs: 9 rows of history + this frame's blocks
@@ -296,262 +312,986 @@ __global__ __launch_bounds__(64) void k_sbc(const uint8_t* __restrict__ frames, 
     }
 }
 
-// ---- the frame-parallel path ---------------------------------------------------------------------------------------------
-constexpr int kSbcChunk = 8;                 // frames per workgroup
-constexpr int kSbcFrames = kSbcChunk + 3;    // + the frames that hold the nine blocks before them (blocks >= 4)
+__global__ __launch_bounds__(64) void k_sbc(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
+                                            int n_frames, SbcState* __restrict__ states,
+                                            const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
+                                            size_t pcm_stride, uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count,
+                                            int flags)
+{
+    sbc_serial_body(frames, stream_stride, frame_bytes, n_frames, states, tables, pcm, pcm_stride, ret, pcm_count, flags);
+}
 
-// one thread per frame: parallel[s] stays 1 when every frame of stream s decodes (sbc_decoder.cpp:282-295) with the
-// geometry of frame 0.  parallel[] arrives set to all ones.
-__global__ __launch_bounds__(256) void k_sbc_check(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
-                                                   int n_frames, uint32_t* __restrict__ parallel)
+// ---- per frame: header and bit allocation --------------------------------------------------------------------------------
+// grid = (frames / 256, streams), one thread per frame.  parallel[] arrives set to kSbcRegularFlag; a frame that does not
+// decode (sbc_decoder.cpp:282-295) or leaves the geometry of frame 0 clears its stream's word (= kSbcGeneralFlag).  ret: the
+// reference's return value of a frame that decodes is its own affair (a frame it rejects: k_sbc_plan / k_sbc).
+__global__ __launch_bounds__(256) void k_sbc_frames(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
+                                                    int n_frames, SbcFrameInfo* __restrict__ info, uint32_t* __restrict__ ret,
+                                                    uint32_t* __restrict__ parallel)
 {
     const int s = blockIdx.y, f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_frames)
         return;
     const uint8_t* base = frames + (size_t)s * stream_stride;
     const uint8_t* d = base + (size_t)f * frame_bytes;
-    bool ok = frame_bytes >= 4 && d[0] == 0x9C;
-    if (ok) {
-        const uint32_t h1 = d[1], g0 = base[1];
-        const int mode = (h1 >> 2) & 3;
-        ok = mode != 3 && (h1 & 1) && d[2] <= 128;
-        // same blocks, same channel count as frame 0 (the PCM of a frame then sits at f * its size)
-        ok = ok && ((h1 >> 4) & 3) == ((g0 >> 4) & 3) && (mode != 0) == (((g0 >> 2) & 3) != 0);
+    const uint32_t avail = (uint32_t)(n_frames - f) * (uint32_t)frame_bytes;  // bytes of the stream from this frame on
+    uint32_t wb[4] = {0, 0, 0, 0}, wp[4] = {0, 0, 0, 0};
+    uint32_t per_block = 0, framelen = 0xFFFF, h1 = 0, bitpool = 0, fl = 0, decoded = 0;
+    // header and scale factors: twelve byte loads issued together (a byte beyond the stream's frames reads as zero -- loaded
+    // from a clamped address, not branched around: every branch was a round trip to memory of its own)
+    uint32_t hb[12];
+#pragma unroll
+    for (uint32_t i = 0; i < 12; i++) {
+        const uint32_t a = d[min(i, avail - 1)];
+        hb[i] = i < avail ? a : 0u;
     }
-    if (!ok)
-        atomicAnd(&parallel[s], 0u);
+    if (frame_bytes >= 4 && hb[0] == 0x9C) {
+        h1 = hb[1];
+        bitpool = hb[2];
+        fl = kSbcSync;
+        const int mode = (h1 >> 2) & 3;
+        // joint stereo and 4 subbands are not decoded (sbc_decoder.cpp:293-295); a bitpool the allocation loop can never
+        // meet would hang the reference: rejected the same way
+        if (mode != 3 && (h1 & 1) && bitpool <= 128) {
+            fl |= kSbcOk;
+            const int channels = mode ? 2 : 1, blocks = 4 * (int)(((h1 >> 4) & 3) + 1);
+            uint32_t acc = 0;
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+                if (c < channels) {
+                    uint8_t sc[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t a = hb[4 + ((c * 8 + j) >> 1)];
+                        sc[j] = ((c * 8 + j) & 1) ? (a & 0xF) : (a >> 4);
+                    }
+                    int b[8];
+                    bit_allocation((h1 >> 6) & 3, (h1 >> 1) & 1, (int)bitpool, sc, b);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        wb[c * 2 + (j >> 2)] |= (uint32_t)b[j] << (8 * (j & 3));
+                        wp[c * 2 + (j >> 2)] |= acc << (8 * (j & 3));
+                        acc += (uint32_t)b[j];
+                    }
+                }
+            per_block = acc;
+            framelen = 4 + (uint32_t)channels * 4 + ((uint32_t)blocks * acc + 7) / 8;
+            decoded = (uint32_t)(blocks * 8 * channels * 2);
+        }
+    }
+    uint4* o = reinterpret_cast<uint4*>(info + (size_t)s * n_frames + f);
+    o[0] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+    o[1] = make_uint4(wp[0], wp[1], wp[2], wp[3]);
+    o[2] = make_uint4(per_block | (framelen << 16), h1 | (bitpool << 8) | (fl << 16), 0u, 0u);
+    const uint32_t g0 = frame_bytes >= 4 ? base[1] : 0u;
+    const bool regular = (fl & kSbcOk) && ((h1 >> 4) & 3) == ((g0 >> 4) & 3) && (((h1 >> 2) & 3) != 0) == (((g0 >> 2) & 3) != 0);
+    if (!regular)
+        atomicAnd(&parallel[s], kSbcGeneralFlag);
+    if (ret && (fl & kSbcOk))
+        ret[(size_t)s * n_frames + f] = framelen | (decoded << 16);
 }
 
-// grid = (chunks of kSbcChunk frames, streams), block = 256.  Same arguments and results as k_sbc.  One instantiation per
-// channel count (a mono stream needs half the LDS: twice the workgroups per CU); a workgroup whose stream is of the other
-// kind leaves at once.  The frame bytes in reach are copied into LDS with coalesced dword loads first: headers, scale
-// factors and the samples' bit fields are then LDS reads (the byte loads from global memory were 45 % of a workgroup's life).
-constexpr int kSbcStageDwords = 1536;  // 6 KB: eleven frames of up to 558 bytes (16 blocks x 2 channels x 8 subbands x 16 bits + 12 is 524)
-template <int C>
-__device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
-                                             int n_frames, const SbcState* __restrict__ states, SbcState* __restrict__ states_next,
-                                             const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
-                                             size_t pcm_stride, uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count,
-                                             int flags, const uint32_t* __restrict__ parallel)
-{
-    const int s = blockIdx.y, tid = threadIdx.x;
-    if (!parallel[s] || n_frames <= 0)
-        return;
-    const uint8_t* gbase = frames + (size_t)s * stream_stride;
-    const uint32_t g0 = gbase[1];
-    const int blocks = 4 * (int)(((g0 >> 4) & 3) + 1), channels = ((g0 >> 2) & 3) ? 2 : 1, per_blk = channels * 8;
-    if (channels != C)
-        return;
-    __shared__ SbcTables tb;
-    __shared__ int32_t sb[kSbcFrames][16][C][8];            // dequantised samples of the frames in reach
-    __shared__ int32_t rows[C][9 + kSbcChunk * 16][16];    // matrixing outputs: nine blocks of history + the chunk's
-    __shared__ uint8_t sh_scale[kSbcFrames][C][8], sh_bits[kSbcFrames][C][8];
-    __shared__ uint16_t sh_prefix[kSbcFrames][C * 8], sh_per_block[kSbcFrames];
-    __shared__ uint32_t sh_in[kSbcStageDwords];
+namespace {
 
-    const uint32_t limit = (uint32_t)n_frames * (uint32_t)frame_bytes;
-    const bool probe = (flags & 1) != 0;  // decode_audio()'s frame-size probe: frame 0 is decoded once more up front
-    const int f0 = blockIdx.x * kSbcChunk, f1 = min(n_frames, f0 + kSbcChunk);
-    // Virtual block timeline: block vb >= 0 is block vb % blocks of frame vb / blocks; with the probe, blocks
-    // -blocks .. -1 are frame 0's once more; everything before comes from the state's nine history rows.
-    const int vb0 = f0 * blocks, vb1 = f1 * blocks;
-    const int first_vb = max(vb0 - 9, probe ? -blocks : 0);      // first block whose samples this workgroup needs
-    const int fr_lo = first_vb < 0 ? -1 : first_vb / blocks;     // ... it lies in this frame (-1: the probe's copy of frame 0)
-    const int n_fr = f1 - fr_lo;                                 // frames in reach (<= kSbcFrames)
+// wave-wide inclusive scans (64 lanes)
+__device__ inline int scan_max(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        v = lane >= d ? max(v, o) : v;
+    }
+    return v;
+}
+__device__ inline uint32_t scan_add(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        v = lane >= d ? v + o : v;
+    }
+    return v;
+}
+
+struct SbcGeom {
+    int blocks, channels;
+    bool four;  // four subbands: nothing is synthesised
+};
+__device__ inline SbcGeom geom_of_header(uint32_t h1) { return {4 * (int)(((h1 >> 4) & 3) + 1), ((h1 >> 2) & 3) ? 2 : 1, (h1 & 1) == 0}; }
+// the geometry a decoder state holds, as k_sbc reads it (a state buffer that was not zero-initialised must not index out of range)
+__device__ inline SbcGeom geom_of_state(const SbcState* st) { return {min((int)st->blocks, 16), min((int)st->channels, 2), st->subbands == 4}; }
+
+}  // namespace
+
+// grid = streams + 1, block = 256.
+// The LAST workgroup sorts the streams onto the work lists, a thread per stream (a stream's place on its list from ballots and a
+// sum over the waves -- an atomic per stream on the three list counters was 14 us for 1024 streams).
+// Workgroup s < streams, its first wave: the plan of stream s if it is a general one.
+__global__ __launch_bounds__(256) void k_sbc_plan(const SbcFrameInfo* __restrict__ info, int n_frames, int flags,
+                                                  const SbcState* __restrict__ states, SbcFramePlan* __restrict__ plan,
+                                                  uint32_t* __restrict__ parallel, SbcQueues* __restrict__ queues,
+                                                  uint32_t* __restrict__ lists, int n_streams, int list_stride,
+                                                  uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count)
+{
+    if ((int)blockIdx.x == n_streams) {
+        __shared__ uint32_t wsum[3][4];
+        __shared__ uint32_t base[3];
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        if (tid < 3)
+            base[tid] = 0;
+        __syncthreads();
+        for (int s0 = 0; s0 < n_streams; s0 += 256) {
+            const int s = s0 + tid;
+            int cls = -1;
+            uint32_t bcode = 0;  // block count of a regular stream's frames (4, 8, 12, 16), packed into its list entry
+            if (s < n_streams) {
+                if (parallel[s] == kSbcRegularFlag) {
+                    const uint32_t h1 = info[(size_t)s * n_frames].h1;
+                    cls = ((h1 >> 2) & 3) ? kSbcStereo : kSbcMono;
+                    bcode = (h1 >> 4) & 3;
+                } else if (geom_of_state(states + s).blocks & 3)
+                    cls = 3;  // (k_sbc_finish: one wave, frame by frame)
+                else
+                    cls = kSbcGeneral;
+            }
+            uint32_t rank = 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const unsigned long long m = __ballot(cls == c);
+                if (cls == c)
+                    rank = (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                if (lane == 0)
+                    wsum[c][wave] = (uint32_t)__popcll(m);
+            }
+            __syncthreads();
+            if (cls >= 0 && cls < 3) {
+                uint32_t off = base[cls];
+                for (int w = 0; w < wave; w++)
+                    off += wsum[cls][w];
+                lists[(size_t)cls * list_stride + off + rank] = (uint32_t)s | (cls == kSbcGeneral ? 0u : bcode << 30);
+            }
+            __syncthreads();
+            if (tid < 3)
+                base[tid] += wsum[tid][0] + wsum[tid][1] + wsum[tid][2] + wsum[tid][3];
+            __syncthreads();
+        }
+        if (tid < 3)
+            queues->count[tid] = base[tid];
+        return;
+    }
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (lane >= 64 || parallel[s] != kSbcGeneralFlag)
+        return;
+    const SbcFrameInfo* inf = info + (size_t)s * n_frames;
+    const SbcGeom gs = geom_of_state(states + s);
+    if (gs.blocks & 3) {
+        // No call leaves such a state: a frame before the first header of the call would put 1-3 rows on a timeline, and the
+        // nine rows before a chunk could lie in more frames than a workgroup looks back.  (The classifier, which runs beside
+        // this workgroup, reads the same state and keeps the stream off the lists.)
+        if (lane == 0)
+            parallel[s] = kSbcSerialFlag;
+        return;
+    }
+    const int probe = flags & 1;
+    const int F = n_frames + probe;
+    SbcFramePlan* pl = plan + (size_t)s * (n_frames + 1);
+    int c_gsrc = -1, c_back0 = -1, c_back1 = -1;
+    int c_src[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        c_src[k] = -1;
+    uint32_t c_vb0 = 0, c_vb1 = 0, c_pcm = 0;
+    for (int v0 = 0; v0 < F; v0 += 64) {
+        const int v = v0 + lane;
+        const bool in = v < F;
+        const int f = max(v - probe, 0);
+        uint32_t misc = 0;
+        if (in)
+            misc = reinterpret_cast<const uint32_t*>(inf + f)[9];  // h1 | bitpool << 8 | flags << 16
+        const bool sync = (misc >> 16) & kSbcSync, ok = (misc >> 16) & kSbcOk;
+        const int gsrc = max(c_gsrc, scan_max(sync ? v : -1, lane));
+        SbcGeom g = gs;
+        if (in && gsrc >= 0)
+            g = geom_of_header(inf[max(gsrc - probe, 0)].h1);
+        const bool synth = in && !g.four;
+        const uint32_t nb0 = synth && g.channels > 0 ? (uint32_t)g.blocks : 0u, nb1 = synth && g.channels > 1 ? (uint32_t)g.blocks : 0u;
+        const uint32_t pcm = synth ? (uint32_t)(g.blocks * 8 * g.channels) : 0u;
+        const uint32_t pcm_c = (probe && v == 0) ? 0u : pcm;  // (the probe's PCM is dropped)
+        const uint32_t i_pcm = scan_add(pcm_c, lane), i_vb0 = scan_add(nb0, lane), i_vb1 = scan_add(nb1, lane);
+        const int i_back0 = scan_max(nb0 ? v : -1, lane), i_back1 = scan_max(nb1 ? v : -1, lane);
+        // exclusive: what lies before this frame
+        int e_back0 = __shfl_up(i_back0, 1, 64), e_back1 = __shfl_up(i_back1, 1, 64);
+        e_back0 = lane ? max(e_back0, c_back0) : c_back0;
+        e_back1 = lane ? max(e_back1, c_back1) : c_back1;
+        const SbcGeom hg = geom_of_header(misc & 0xFF);
+        int src[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool writes = ok && hg.blocks > 4 * (k >> 1) && hg.channels > (k & 1);
+            src[k] = max(c_src[k], scan_max(writes ? v : -1, lane));
+        }
+        if (in) {
+            uint4* o = reinterpret_cast<uint4*>(pl + v);
+            o[0] = make_uint4((uint32_t)src[0], (uint32_t)src[1], (uint32_t)src[2], (uint32_t)src[3]);
+            o[1] = make_uint4((uint32_t)src[4], (uint32_t)src[5], (uint32_t)src[6], (uint32_t)src[7]);
+            o[2] = make_uint4(c_pcm + i_pcm - pcm_c, c_vb0 + i_vb0 - nb0, c_vb1 + i_vb1 - nb1, (uint32_t)e_back0);
+            o[3] = make_uint4((uint32_t)e_back1, (uint32_t)gsrc, (uint32_t)g.blocks | ((uint32_t)g.channels << 8) | (synth ? 1u << 16 : 0u), 0u);
+            if (ret && !ok && v >= probe)
+                ret[(size_t)s * n_frames + f] = 0xFFFFu | ((pcm * 2) << 16);
+        }
+        // carries: the last lane's inclusive values
+        c_gsrc = __shfl(gsrc, 63, 64);
+        c_back0 = max(c_back0, __shfl(i_back0, 63, 64));
+        c_back1 = max(c_back1, __shfl(i_back1, 63, 64));
+        c_pcm += __shfl(i_pcm, 63, 64);
+        c_vb0 += __shfl(i_vb0, 63, 64);
+        c_vb1 += __shfl(i_vb1, 63, 64);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            c_src[k] = __shfl(src[k], 63, 64);
+    }
+    if (pcm_count && lane == 0)
+        pcm_count[s] = c_pcm;
+}
+
+// ---- the frame-parallel kernels ----------------------------------------------------------------------------------------------
+// (development switches: the alternatives measured in profiles/r5_sbc.md)
+#ifndef EFX_SBC_M
+#define EFX_SBC_M 1      // matrixing: a thread makes two outputs of 1 = two consecutive rows, 0 = one row per trip
+#endif
+#ifndef EFX_SBC_SKIP
+#define EFX_SBC_SKIP 0   // timing ablations (wrong PCM): 1 = no dequantisation, 2 = no matrixing of the chunk's rows, 4 = no windowing
+#endif
+#ifndef EFX_SBC_CHUNK_MONO
+#define EFX_SBC_CHUNK_MONO 16  // frames per work item of k_sbc_par_mono (8: 7 workgroups per compute unit; 16: 4, and 12 % faster)
+#endif
+#ifndef EFX_SBC_PITCH
+#define EFX_SBC_PITCH 18 // (16 = unpadded)
+#endif
+#ifndef EFX_SBC_WAVES
+#define EFX_SBC_WAVES 4  // k_sbc_par_mono: waves per SIMD the register allocation aims at (= workgroups per compute unit)
+#endif
+constexpr int kSbcChunk = 8;                 // frames per work item (k_sbc_par_mono: EFX_SBC_CHUNK_MONO)
+constexpr int kSbcStageDwords = 1024;        // 4 KB of frame bytes in LDS
+constexpr int kSbcRowPitch = EFX_SBC_PITCH;    // dwords between two rows of matrixing outputs in LDS
+constexpr uint32_t kSbcSlack = 528;          // a frame's bit fields may run past the frame size the caller states (at most 524 bytes
+                                             // from its start): the reference reads on into the next frame's bytes, so does this
+
+namespace {
+
+// Work item `it` of this workgroup on list `cls`: the items of a list are dealt round robin (they cost the same, but for a
+// stream's last chunk; a shared counter was tried first: 48 k atomics on one address serialise at 50-90 per microsecond and
+// took longer than the decoding).  false when the list is through.
+__device__ inline bool sbc_next_item(const SbcQueues* queues, const uint32_t* lists, int cls, int n_streams, int chunks, int it, int* s,
+                                     int* chunk)
+{
+    __syncthreads();  // (the LDS of the previous item is free)
+    const uint32_t item = blockIdx.x + (uint32_t)it * gridDim.x;
+    if (item >= queues->count[cls] * (uint32_t)chunks)
+        return false;
+    *s = (int)lists[(size_t)cls * n_streams + item / (uint32_t)chunks];
+    *chunk = (int)(item % (uint32_t)chunks);
+    return true;
+}
+
+// IQUANT (sbc_decoder.cpp:263-270): sample = ((v << 1 | 1) << scale) / (2^bits - 1) - (1 << scale), the shift wrapping at 32
+// bits and the division C's (truncating, of the wrapped value as a signed number)
+__device__ inline int32_t sbc_iquant(uint32_t v, uint32_t bits, uint32_t scale, uint32_t magic)
+{
+    const uint32_t n = ((v << 1) | 1u) << scale;
+    const bool neg = (int32_t)n < 0;
+    const uint32_t a = neg ? 0u - n : n;
+    const uint32_t t = __umulhi(magic, a);
+    const uint32_t q = (t + ((a - t) >> (bits > 1 ? 1 : 0))) >> ((bits - 1) & 31);
+    return (neg ? -(int32_t)q : (int32_t)q) - (int32_t)(1u << scale);
+}
+
+// acc + a * b with 24-bit operands, as ONE v_mad_i32_i24: written as __mul24() + add, the sums of a dot product are
+// re-associated into multiplies and three-input adds -- 1.4 instructions per term (hipcc -S) in kernels the VALU bounds
+__device__ inline uint32_t mad24(int32_t a, int32_t b, uint32_t acc)
+{
+    uint32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
+    return d;
+}
+
+// A workgroup barrier for LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also waits for every global
+// load in flight (vmcnt(0)) -- among them the ones the frame-parallel kernel issues for its NEXT work item.
+__device__ inline void sbc_lds_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+}
+
+}  // namespace
+
+// Regular streams: every frame decodes under the geometry of frame 0, so everything has a closed form -- frame f's PCM sits at
+// f * its size, block b of frame f is row f * blocks + b of the channel's timeline.  One instantiation per channel count (a
+// mono stream needs half the LDS).  Values multiplied with v_mad_i32_i24: table entries (18 bits), subband samples (|s| < 2^18:
+// IQUANT's quotient) and matrixing outputs (an int32 >> 15) all fit 24 bits -- the low 32 bits of the products are the
+// reference's, at four times the rate of a full 32-bit multiply.  (Which holds for the filter memory of a state, too, as long as
+// it is one a call of this library left, or zeros.)
+template <int C, int CH>
+__device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes, int n_frames,
+                                             const SbcState* __restrict__ states, SbcState* __restrict__ states_next,
+                                             const SbcTables* __restrict__ tables, const SbcFrameInfo* __restrict__ info,
+                                             int16_t* __restrict__ pcm, size_t pcm_stride, uint32_t* __restrict__ pcm_count, int flags,
+                                             SbcQueues* __restrict__ queues, const uint32_t* __restrict__ lists, int n_streams)
+{
+    constexpr int PB = 8 * C;  // samples of a block
+    __shared__ SbcTables tb;
+    constexpr int FR = CH + 3;  // + the frames that hold the nine blocks before them (blocks >= 4)
+    __shared__ int32_t sb[FR * 16 * PB];              // dequantised samples of the frames in reach: [k][blk][c][sb]
+    // matrixing outputs: nine blocks of history + the chunk's.  Rows are kSbcRowPitch dwords apart: the windowing reads column o
+    // of rows four apart in the lanes of a group (ds_read_b32 banks = dword address mod 32; a pitch of 16 put four lanes on
+    // every bank it touched)
+    __shared__ int32_t rows[C][9 + CH * 16][kSbcRowPitch];
+    __shared__ uint32_t sh_in[kSbcStageDwords];
+    __shared__ SbcFrameInfo sh_info[FR];
+    __shared__ uint32_t sh_meta[FR][PB];              // per (frame, channel, subband): bits | prefix << 8 | scale factor << 16
+    __shared__ uint2 sh_fk[FR];                       // per frame: where its sample bits start in the stream (in bits), bits per block
+
+    const int tid = threadIdx.x;
+    constexpr int cls = C == 1 ? kSbcMono : kSbcStereo;
+    const uint32_t count = queues->count[cls];
+    if (count == 0)
+        return;
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(tables);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&tb);
         for (int i = tid; i < (int)(sizeof(SbcTables) / 4); i += 256)
             dst[i] = src[i];
     }
-    // the bytes of frames max(fr_lo, 0) .. f1 - 1 (contiguous in the stream): whole aligned dwords, bytes beyond the stream's
-    // frames as zeros (be_bits); a chunk too fat for the stage is read from global memory as before
-    const uint32_t lo_byte = (uint32_t)max(fr_lo, 0) * (uint32_t)frame_bytes, hi_byte = min((uint32_t)f1 * (uint32_t)frame_bytes, limit);
-    const uint32_t mis = (uint32_t)((uintptr_t)(gbase + lo_byte) & 3), n_dw = (hi_byte - lo_byte + mis + 3) / 4;
-    const bool staged = n_dw <= (uint32_t)kSbcStageDwords;
-    if (staged) {
-        const uint8_t* a0 = gbase + lo_byte - mis;  // (>= frames: the buffer starts dword-aligned)
-        for (uint32_t i = tid; i < n_dw; i += 256) {
-            uint32_t w;
-            if (i * 4 + 4 <= hi_byte - lo_byte + mis)
-                w = *reinterpret_cast<const uint32_t*>(a0 + i * 4);
-            else {  // the last dword: never past the stream's last frame byte
-                w = 0;
-                for (uint32_t b = 0; b < 4; b++)
-                    if (i * 4 + b < hi_byte - lo_byte + mis)
-                        w |= (uint32_t)a0[i * 4 + b] << (8 * b);
-            }
-            sh_in[i] = w;
+    const uint32_t chunks = (uint32_t)(n_frames + CH - 1) / CH, total = count * chunks;
+    const uint32_t limit = (uint32_t)n_frames * (uint32_t)frame_bytes;
+    const bool probe = (flags & 1) != 0;  // decode_audio()'s frame-size probe: frame 0 is decoded once more up front
+
+    // Work items = (stream of the list, chunk of CH frames), dealt round robin: this workgroup's are blockIdx.x + it * gridDim.x.
+    // A lane keeps the list entry and the chunk of one of the next 64 (one vector load per 64 items; readlane hands them out).
+    uint32_t my_entry = 0xFFFFFFFFu, my_chunk = 0;
+    auto load_entries = [&](int it0) {
+        const uint32_t item = blockIdx.x + (uint32_t)(it0 + (tid & 63)) * gridDim.x;
+        my_entry = 0xFFFFFFFFu;
+        if (item < total) {
+            const uint32_t si = item / chunks;
+            my_chunk = item - si * chunks;
+            my_entry = lists[(size_t)cls * n_streams + si];
         }
-    }
-    // where frame f (max(fr_lo, 0) <= f < f1) starts: in the stage when the chunk fits it (flat loads serve both)
-    auto frame_at = [&](int f) -> const uint8_t* {
-        return staged ? reinterpret_cast<const uint8_t*>(sh_in) + ((uint32_t)f * (uint32_t)frame_bytes - lo_byte + mis)
-                      : gbase + (size_t)f * frame_bytes;
     };
-    __syncthreads();
-    // ---- headers, scale factors, bit allocation: one thread per (frame, channel) ---------------------------------------
-    if (tid < n_fr * 2) {
-        const int k = tid >> 1, c = tid & (C - 1), f = max(fr_lo + k, 0);
-        const uint8_t* d = frame_at(f);
-        const uint32_t avail = limit - (uint32_t)f * (uint32_t)frame_bytes;
-        if ((tid & 1) < C) {
-            uint8_t sc[8];
-            for (int j = 0; j < 8; j++) {
-                const uint32_t i = 4 + (uint32_t)((c * 8 + j) >> 1);
-                const uint32_t a = i < avail ? d[i] : 0u;
-                sc[j] = ((c * 8 + j) & 1) ? (a & 0xF) : (a >> 4);
-                sh_scale[k][c][j] = sc[j];
+    // everything about an item that is the same for all threads
+    struct Item {
+        bool valid, staged;
+        int s, blocks, f0, f1, vb0, vb1, first_vb, fr_lo, n_fr;
+        uint32_t inv_b, lo_byte, hi_byte, mis, span, n_dw, n_zero;
+        const uint8_t* gbase;
+        const SbcFrameInfo* inf;
+    };
+    auto setup = [&](int it) -> Item {
+        Item p;
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)my_entry, it & 63);
+        const int chunk = __builtin_amdgcn_readlane((int)my_chunk, it & 63);
+        p.valid = e != 0xFFFFFFFFu;
+        p.s = p.valid ? (int)(e & 0x3FFFFFFFu) : 0;
+        p.blocks = 4 * (int)(((p.valid ? e : 0u) >> 30) + 1);  // (k_sbc_plan packs the block count of the stream's frames into the entry)
+        p.inv_b = p.blocks == 4 ? 16385u : p.blocks == 8 ? 8193u : p.blocks == 12 ? 5462u : 4097u;  // x / blocks = x * inv_b >> 16 (x < 4096)
+        p.gbase = frames + (size_t)p.s * stream_stride;
+        p.inf = info + (size_t)p.s * n_frames;
+        p.f0 = chunk * CH;
+        p.f1 = min(n_frames, p.f0 + CH);
+        // Virtual block timeline: block vb >= 0 is block vb % blocks of frame vb / blocks; with the probe, blocks
+        // -blocks .. -1 are frame 0's once more; everything before comes from the state's nine history rows.
+        p.vb0 = p.f0 * p.blocks;
+        p.vb1 = p.f1 * p.blocks;
+        p.first_vb = max(p.vb0 - 9, probe ? -p.blocks : 0);      // first block whose samples this workgroup needs
+        p.fr_lo = p.first_vb < 0 ? -1 : (int)(((uint32_t)p.first_vb * p.inv_b) >> 16);  // ... it lies in this frame (-1: the probe's frame 0)
+        p.n_fr = p.f1 - p.fr_lo;                                   // frames in reach (<= FR)
+        // the frame bytes in reach (contiguous in the stream), whole aligned dwords, bytes beyond the stream's frames as zeros
+        p.lo_byte = (uint32_t)max(p.fr_lo, 0) * (uint32_t)frame_bytes;
+        p.hi_byte = min((uint32_t)p.f1 * (uint32_t)frame_bytes + kSbcSlack, limit);
+        p.mis = (uint32_t)((uintptr_t)(p.gbase + p.lo_byte) & 3);
+        p.span = p.hi_byte - p.lo_byte + p.mis;
+        p.n_dw = (p.span + 3) / 4;
+        // (the stream ends inside the reach: zeros behind its last byte, as far as a frame's bit fields can run -- the
+        // sample loop then reads the stage without a look at the limit)
+        p.n_zero = p.hi_byte == limit ? kSbcSlack / 4 + 2 : 1;
+        p.staged = p.n_dw + p.n_zero <= (uint32_t)kSbcStageDwords;
+        return p;
+    };
+    // The global loads of an item -- its frame bytes and the frames' SbcFrameInfo -- are ISSUED while the item before it is
+    // being decoded and land in registers; they go to LDS when their item's turn comes.  (Whole aligned dwords: the first and
+    // the last may hold bytes that are not the reach's -- an aligned dword with one valid byte lies in that byte's page --
+    // and are masked on their way to LDS.)  Nothing between issue and use waits for memory: the barriers of the loop are
+    // LDS barriers (sbc_lds_barrier), not __syncthreads().
+    struct Fetch {
+        uint32_t w[kSbcStageDwords / 256];
+        uint4 info;
+    };
+    auto fetch = [&](const Item& p) -> Fetch {
+        Fetch r = {};
+        if (!p.valid)
+            return r;
+        if (p.staged) {
+            const uint32_t* a0 = reinterpret_cast<const uint32_t*>(p.gbase + p.lo_byte - p.mis);
+#pragma unroll
+            for (int j = 0; j < kSbcStageDwords / 256; j++)
+                if ((uint32_t)(tid + 256 * j) < p.n_dw)
+                    r.w[j] = a0[tid + 256 * j];
+        }
+        if (tid < p.n_fr * 3)
+            r.info = reinterpret_cast<const uint4*>(p.inf + max(p.fr_lo + tid / 3, 0))[tid % 3];
+        return r;
+    };
+    auto commit = [&](const Item& p, const Fetch& r) {
+        if (p.staged) {
+#pragma unroll
+            for (int j = 0; j < kSbcStageDwords / 256; j++) {
+                const uint32_t i = (uint32_t)(tid + 256 * j);
+                if (i < p.n_dw + p.n_zero) {
+                    uint32_t w = i < p.n_dw ? r.w[j] : 0u;
+                    if (i * 4 + 4 > p.span)  // the last dword: bytes beyond the reach (or the stream's frames) are zeros
+                        w &= i * 4 < p.span ? 0xFFFFFFFFu >> (8 * (i * 4 + 4 - p.span)) : 0u;
+                    if (i == 0)              // the first: bytes before the reach
+                        w &= 0xFFFFFFFFu << (8 * p.mis);
+                    sh_in[i] = __builtin_amdgcn_perm(0u, w, 0x00010203u);  // MSB first: a bit field is a shift away
+                }
             }
-            int b[8];
-            bit_allocation((d[1] >> 6) & 3, (d[1] >> 1) & 1, d[2], sc, b);
+        }
+        if (tid < p.n_fr * 3)
+            reinterpret_cast<uint4*>(&sh_info[tid / 3])[tid % 3] = r.info;
+    };
+
+    load_entries(0);
+    Item cur = setup(0);
+    Fetch got = fetch(cur);
+    for (int it = 0; cur.valid; it++) {
+        sbc_lds_barrier();  // (the LDS of the previous item is free)
+        commit(cur, got);
+        if (((it + 1) & 63) == 0)
+            load_entries(it + 1);
+        const Item nxt = setup(it + 1);
+        got = fetch(nxt);
+        const Item p = cur;
+        cur = nxt;
+        const int s = p.s, blocks = p.blocks, f0 = p.f0, f1 = p.f1, vb0 = p.vb0, vb1 = p.vb1, first_vb = p.first_vb, fr_lo = p.fr_lo,
+                  n_fr = p.n_fr;
+        const uint32_t inv_b = p.inv_b, lo_byte = p.lo_byte, mis = p.mis;
+        const bool staged = p.staged;
+        const uint8_t* gbase = p.gbase;
+        // byte `pos` of the stream (bytes at or beyond `limit` read as zero); the stage holds its dwords MSB first
+        auto byte_at = [&](uint32_t pos) -> uint32_t {
+            if (staged)
+                return reinterpret_cast<const uint8_t*>(sh_in)[(pos - lo_byte + mis) ^ 3];
+            return pos < limit ? gbase[pos] : 0u;
+        };
+        // `bits` (1..16) bits from bit `bitpos` on: of the stage (bitpos counts from the stage's first bit) ...
+        auto field_staged = [&](uint32_t bitpos, uint32_t bits) -> uint32_t {
+            const uint32_t di = bitpos >> 5;
+            const uint64_t x = ((uint64_t)sh_in[di] << 32) | sh_in[di + 1];
+            return (uint32_t)((x << (bitpos & 31)) >> 32) >> ((32 - bits) & 31);
+        };
+        // ... or of the stream (a reach too fat for the stage)
+        auto field_global = [&](uint32_t bitpos, uint32_t bits) -> uint32_t {
+            const uint32_t pos = bitpos >> 3;
+            uint32_t w = 0;
+            for (uint32_t k = 0; k < 4; k++)
+                w = (w << 8) | (pos + k < limit ? gbase[pos + k] : 0u);
+            return (w << (bitpos & 7)) >> ((32 - bits) & 31);
+        };
+        sbc_lds_barrier();
+        // ---- scale factors: one thread per (frame, channel, subband) ----------------------------------------------------------
+        for (int i = tid; i < n_fr * PB; i += 256) {
+            const int k = i / PB, r = i - k * PB;
+            const uint32_t fpos = (uint32_t)max(fr_lo + k, 0) * (uint32_t)frame_bytes;
+            const uint32_t a = byte_at(fpos + 4 + (uint32_t)(r >> 1));
+            const uint8_t* fi = reinterpret_cast<const uint8_t*>(&sh_info[k]);
+            sh_meta[k][r] = fi[r] | ((uint32_t)fi[16 + r] << 8) | (((r & 1) ? (a & 0xF) : (a >> 4)) << 16);
+            if (r == 0)
+                sh_fk[k] = make_uint2((fpos + 4 + PB / 2 - (staged ? lo_byte - mis : 0u)) * 8, sh_info[k].per_block);
+        }
+        // ---- history rows that predate every frame in reach: the state's --------------------------------------------------------
+        // row t of `rows` is virtual block vb0 - 9 + t
+        const SbcState* st = states + s;
+        const int hist_end = probe ? -blocks : 0;  // virtual blocks below this one are the state's history: block v -> hist[9 + v - hist_end]
+        for (int i = tid; i < C * 9 * 16; i += 256) {
+            const int c = i / 144, r = i - c * 144, t = r >> 4, o = r & 15, vb = vb0 - 9 + t;
+            if (vb < hist_end)
+                rows[c][t][o] = st->hist[c][9 + vb - hist_end][o];
+        }
+        sbc_lds_barrier();
+#if EFX_SBC_SKIP & 1
+        sbc_lds_barrier();
+#else
+        // ---- samples (get_samples(), sbc_decoder.cpp:297-343): a thread takes (frame, channel, subband) and four consecutive
+        // blocks -- width, place and scale factor of the field, the divisor's constant are read once, the bit position advances
+        // by the block's bits.  Of the first frame in reach only the quarters that hold the nine blocks before the chunk.
+        {
+            const int r = tid & (PB - 1);
+            const int QB = blocks >> 2;  // quarters of a frame
+            const uint32_t inv_q = QB == 1 ? 65537u : QB == 2 ? 32769u : QB == 3 ? 21846u : 16385u;
+            const int q_lo = fr_lo >= 0 ? (first_vb - fr_lo * blocks) >> 2 : 0, nq0 = QB - q_lo;
+            const int n_tasks = nq0 + (n_fr - 1) * QB;
+            auto tasks = [&](auto&& field) {
+                for (int t = tid / PB; t < n_tasks; t += 256 / PB) {
+                    int k = 0, q = q_lo + t;
+                    if (t >= nq0) {
+                        const int u = t - nq0, kq = (int)(__umul24((uint32_t)u, inv_q) >> 16);
+                        k = 1 + kq;
+                        q = u - kq * QB;
+                    }
+                    const uint32_t meta = sh_meta[k][r], bits = meta & 0xFF, scale = meta >> 16;
+                    const uint2 fk = sh_fk[k];
+                    const uint32_t magic = tb.iq_magic[bits];
+                    uint32_t bitpos = fk.x + __umul24((uint32_t)(4 * q), fk.y) + ((meta >> 8) & 0xFF);
+                    int32_t* dst = &sb[(k * 16 + 4 * q) * PB + r];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int32_t sample = sbc_iquant(field(bitpos, bits), bits, scale, magic);
+                        dst[i * PB] = bits ? sample : 0;
+                        bitpos += fk.y;
+                    }
+                }
+            };
+            if (staged)
+                tasks(field_staged);
+            else
+                tasks(field_global);
+        }
+        sbc_lds_barrier();
+#endif
+        // ---- matrixing (sbc_decoder.cpp:86-104): rows[c][t][o] = (sum_j syn[o][j] * sb[blk][c][j]) >> 15.  The chunk's own
+        // rows: below; the nine rows before them that are not the state's: one thread per output.
+        const int n_t = 9 + (vb1 - vb0);
+        for (int i = tid; i < C * 144; i += 256) {
+            const int c = i / 144, rr = i - c * 144, t = rr >> 4, o = rr & 15, vb = vb0 - 9 + t;
+            if (vb < hist_end)
+                continue;
+            const int vbp = vb < 0 ? vb + blocks : vb;
+            const int fq = (int)(__umul24((uint32_t)vbp, inv_b) >> 16);
+            const int k = (vb < 0 ? -1 : fq) - fr_lo, blk = vb < 0 ? vbp : vbp - (int)__umul24((uint32_t)fq, (uint32_t)blocks);
+            const int32_t* x = &sb[((k * 16 + blk) * C + c) * 8];
+            uint32_t acc = 0;
+#pragma unroll
             for (int j = 0; j < 8; j++)
-                sh_bits[k][c][j] = (uint8_t)b[j];
+                acc = mad24(tb.syn[o * 8 + j], x[j], acc);
+            rows[c][t][o] = (int32_t)acc >> 15;
         }
-    }
-    __syncthreads();
-    if (tid < n_fr) {
-        int acc = 0;
-        for (int c = 0; c < channels; c++)
+#if EFX_SBC_SKIP & 2
+#elif EFX_SBC_M
+        {
+            // outputs o8 and o8 + 8 of TWO consecutive rows (blocks of one frame: a block count is even) per trip: the 16
+            // coefficients and the address arithmetic serve 32 multiply-adds
+            const int o8 = tid & 7;
+            int32_t sa[8], sh[8];
+#pragma unroll
             for (int j = 0; j < 8; j++) {
-                sh_prefix[tid][c * 8 + j] = (uint16_t)acc;
-                acc += sh_bits[tid][c][j];
+                sa[j] = tb.syn[o8 * 8 + j];
+                sh[j] = tb.syn[(o8 + 8) * 8 + j];
             }
-        sh_per_block[tid] = (uint16_t)acc;
-    }
-    __syncthreads();
-    // ---- samples: one thread per (frame, blk, ch, sb) (IQUANT, sbc_decoder.cpp:263-270) --------------------------------
-    const uint32_t data_off = 4 + (uint32_t)(per_blk >> 1);
-    for (int i = tid; i < n_fr * blocks * per_blk; i += 256) {
-        const int k = i / (blocks * per_blk), r0 = i - k * blocks * per_blk, blk = r0 / per_blk, r = r0 - blk * per_blk;
-        const int f = max(fr_lo + k, 0);
-        const uint8_t* d = frame_at(f);
-        const uint32_t avail = limit - (uint32_t)f * (uint32_t)frame_bytes;
-        const int bits = sh_bits[k][r >> 3][r & 7];
-        int32_t sample = 0;
-        if (bits) {
-            const uint32_t bitpos = data_off * 8 + (uint32_t)blk * sh_per_block[k] + sh_prefix[k][r];
-            const int scale = sh_scale[k][r >> 3][r & 7];
-            int32_t q = (int32_t)be_bits(d, avail, bitpos, bits);
-            q = (q << 1) | 1;
-            q = (int32_t)((uint32_t)q << scale) / ((1 << bits) - 1);
-            sample = q - (1 << scale);
-        }
-        sb[k][blk][r >> 3][r & 7] = sample;
-    }
-    // ---- history rows that predate every frame in reach: the state's ------------------------------------------------------
-    // row t of `rows` is virtual block vb0 - 9 + t
-    const SbcState* st = states + s;
-    const int hist_end = probe ? -blocks : 0;  // virtual blocks below this one are the state's history: block v -> hist[9 + v - hist_end]
-    for (int i = tid; i < channels * 9 * 16; i += 256) {
-        const int c = i / 144, r = i - c * 144, t = r >> 4, o = r & 15, vb = vb0 - 9 + t;
-        if (vb < hist_end)
-            rows[c][t][o] = st->hist[c][9 + vb - hist_end][o];
-    }
-    __syncthreads();
-    // ---- matrixing (sbc_decoder.cpp:86-104): rows[c][t][o] = (sum_j syn[o][j] * sb[blk][c][j]) >> 15 ----------------------
-    const int n_t = 9 + (vb1 - vb0);
-    for (int i = tid; i < channels * n_t * 16; i += 256) {
-        const int c = i / (n_t * 16), r = i - c * n_t * 16, t = r >> 4, o = r & 15, vb = vb0 - 9 + t;
-        if (vb < hist_end)
-            continue;
-        const int f = vb < 0 ? -1 : vb / blocks, blk = vb < 0 ? vb + blocks : vb - f * blocks, k = f - fr_lo;
-        uint32_t acc = 0;
+            const int RH = (vb1 - vb0) >> 1;
+            for (int idx = tid >> 3; idx < C * RH; idx += 32) {
+                const int c = (C == 2 && idx >= RH) ? 1 : 0, row = 2 * (idx - c * RH), vb = vb0 + row;
+                const int fq = (int)(__umul24((uint32_t)vb, inv_b) >> 16), k = fq - fr_lo, blk = vb - (int)__umul24((uint32_t)fq, (uint32_t)blocks);
+                const int4* sp = reinterpret_cast<const int4*>(&sb[((k * 16 + blk) * C + c) * 8]);
+                const int4 x0 = sp[0], x1 = sp[1], y0 = sp[2 * C], y1 = sp[2 * C + 1];
+                const int32_t x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                const int32_t y[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+                uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-            acc += (uint32_t)tb.syn[o * 8 + j] * (uint32_t)sb[k][blk][c][j];
-        rows[c][t][o] = (int32_t)acc >> 15;
-    }
-    __syncthreads();
-    // ---- windowing (sbc_decoder.cpp:106-137): sample o of block t from rows t .. t - 9 ---------------------------------------
-    int16_t* out = pcm + (size_t)s * pcm_stride;
-    const int frame_samples = channels * blocks * 8;
-    for (int i = tid; i < (f1 - f0) * frame_samples; i += 256) {
-        const int fl = i / frame_samples, r0 = i - fl * frame_samples, c = r0 / (blocks * 8), r = r0 - c * blocks * 8, blk = r >> 3,
-                  o = r & 7, t = 9 + fl * blocks + blk;
-        uint32_t acc = 0;
+                for (int j = 0; j < 8; j++) {
+                    a0 = mad24(sa[j], x[j], a0);
+                    a1 = mad24(sh[j], x[j], a1);
+                    b0 = mad24(sa[j], y[j], b0);
+                    b1 = mad24(sh[j], y[j], b1);
+                }
+                rows[c][9 + row][o8] = (int32_t)a0 >> 15;
+                rows[c][9 + row][o8 + 8] = (int32_t)a1 >> 15;
+                rows[c][10 + row][o8] = (int32_t)b0 >> 15;
+                rows[c][10 + row][o8 + 8] = (int32_t)b1 >> 15;
+            }
+        }
+#else
+        {
+            const int o8 = tid & 7;
+            int32_t sa[8], sh[8];
 #pragma unroll
-        for (int j = 0; j < 10; j += 2) {
-            acc += (uint32_t)rows[c][t - j][o] * (uint32_t)tb.proto[o * 10 + j];
-            acc += (uint32_t)rows[c][t - j - 1][o + 8] * (uint32_t)tb.proto[o * 10 + j + 1];
+            for (int j = 0; j < 8; j++) {
+                sa[j] = tb.syn[o8 * 8 + j];
+                sh[j] = tb.syn[(o8 + 8) * 8 + j];
+            }
+            const int RB = vb1 - vb0;
+            for (int idx = tid >> 3; idx < C * RB; idx += 32) {
+                const int c = (C == 2 && idx >= RB) ? 1 : 0, row = idx - c * RB, vb = vb0 + row;
+                const int fq = (int)(__umul24((uint32_t)vb, inv_b) >> 16), k = fq - fr_lo, blk = vb - (int)__umul24((uint32_t)fq, (uint32_t)blocks);
+                const int4* sp = reinterpret_cast<const int4*>(&sb[((k * 16 + blk) * C + c) * 8]);
+                const int4 x0 = sp[0], x1 = sp[1];
+                const int32_t x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    a0 = mad24(sa[j], x[j], a0);
+                    a1 = mad24(sh[j], x[j], a1);
+                }
+                rows[c][9 + row][o8] = (int32_t)a0 >> 15;
+                rows[c][9 + row][o8 + 8] = (int32_t)a1 >> 15;
+            }
         }
-        int32_t v = (int32_t)acc >> 15;
-        v = v < -0x7FFF ? -0x7FFF : (v > 0x7FFF ? 0x7FFF : v);
-        out[(size_t)(f0 + fl) * frame_samples + r0] = (int16_t)v;
-    }
-    if (ret)
-        for (int fl = tid; fl < f1 - f0; fl += 256) {
-            const int k = f0 + fl - fr_lo;
-            const uint32_t framelen = data_off + ((uint32_t)blocks * sh_per_block[k] + 7) / 8;
-            ret[(size_t)s * n_frames + f0 + fl] = (framelen & 0xFFFF) | ((uint32_t)(frame_samples * 2) << 16);
+#endif
+        sbc_lds_barrier();
+        // ---- windowing (sbc_decoder.cpp:106-137): sample o of block t from rows t .. t - 9; a thread makes sample o of four
+        // consecutive blocks (a frame's block count is a multiple of four) out of one pass over the thirteen rows they read
+        int16_t* out = pcm + (size_t)s * pcm_stride;
+        const int frame_samples = C * blocks * 8;
+#if !(EFX_SBC_SKIP & 4)
+        {
+            const int o = tid & 7;
+            int32_t p[10];
+#pragma unroll
+            for (int j = 0; j < 10; j++)
+                p[j] = tb.proto[o * 10 + j];
+            const int segs_c = (vb1 - vb0) >> 2;
+            for (int seg = tid >> 3; seg < C * segs_c; seg += 32) {
+                const int c = (C == 2 && seg >= segs_c) ? 1 : 0, r0 = (seg - c * segs_c) * 4;
+                const int32_t* R = &rows[c][r0][0];  // (row 9 + r0 is the first of the four: R is the row nine before it)
+                int32_t lo[13], hi[13];
+#pragma unroll
+                for (int j = 0; j < 13; j++) {
+                    lo[j] = R[j * kSbcRowPitch + o];
+                    hi[j] = R[j * kSbcRowPitch + o + 8];
+                }
+                const int fl = (int)(__umul24((uint32_t)r0, inv_b) >> 16), blk = r0 - fl * blocks;
+                int16_t* op = out + (size_t)(f0 + fl) * frame_samples + c * blocks * 8 + blk * 8 + o;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int j = 0; j < 10; j += 2) {
+                        acc = mad24(lo[9 + i - j], p[j], acc);
+                        acc = mad24(hi[9 + i - j - 1], p[j + 1], acc);
+                    }
+                    int32_t v = (int32_t)acc >> 15;
+                    v = v < -0x7FFF ? -0x7FFF : (v > 0x7FFF ? 0x7FFF : v);
+                    op[i * 8] = (int16_t)v;
+                }
+            }
         }
-    // ---- the workgroup of the last frames leaves the decoder state -------------------------------------------------------------
-    // NOT in `states`: the workgroup of the stream's first frames reads the history there, in this same launch, whenever it
-    // gets to it.  The new state goes to `states_next` as a whole (what this geometry does not touch copied over) and
-    // k_sbc_commit, the next kernel on the stream, puts it in place.
-    if (f1 == n_frames) {
-        SbcState* so = states_next + s;
-        const int k_last = n_frames - 1 - fr_lo;
-        __syncthreads();
-        for (int i = tid; i < 256; i += 256) {
-            const int blk = i >> 4, c = (i >> 3) & 1, j = i & 7;
-            // (blocks beyond this geometry keep what an earlier frame left there: the reference's array is not cleared)
-            so->sb_sample[blk][c][j] = (blk < blocks && c < channels) ? sb[k_last][blk][c][j] : st->sb_sample[blk][c][j];
-        }
-        for (int i = tid; i < 2 * 144; i += 256) {
-            const int c = i / 144, r = i - c * 144;
-            so->hist[c][r >> 4][r & 15] = c < channels ? rows[c][n_t - 9 + (r >> 4)][r & 15] : st->hist[c][r >> 4][r & 15];
-        }
-        if (tid == 0) {
-            so->reserved = st->reserved;
-            for (int k = 0; k < 8; k++)
-                so->pad[k] = st->pad[k];
-            const uint8_t* d = frame_at(n_frames - 1);
-            so->frequency = (d[1] >> 6) & 3;
-            so->blocks = (uint8_t)blocks;
-            so->channels = (uint8_t)channels;
-            so->mode = (d[1] >> 2) & 3;
-            so->allocation = (d[1] >> 1) & 1;
-            so->subbands = 8;
-            so->bitpool = d[2];
-            if (pcm_count)
-                pcm_count[s] = (uint32_t)n_frames * (uint32_t)frame_samples;
+#endif  // (ablation)
+        // ---- the workgroup of the last frames leaves the decoder state -------------------------------------------------------------
+        // NOT in `states`: the workgroup of the stream's first frames reads the history there, in this same launch, whenever it
+        // gets to it.  The new state goes to `states_next` as a whole (what this geometry does not touch copied over) and
+        // k_sbc_commit, the next kernel on the stream, puts it in place.
+        if (f1 == n_frames) {
+            SbcState* so = states_next + s;
+            const int k_last = n_frames - 1 - fr_lo;
+            for (int i = tid; i < 256; i += 256) {
+                const int blk = i >> 4, c = (i >> 3) & 1, j = i & 7;
+                // (blocks beyond this geometry keep what an earlier frame left there: the reference's array is not cleared)
+                so->sb_sample[blk][c][j] = (blk < blocks && c < C) ? sb[((k_last * 16 + blk) * C + c) * 8 + j] : st->sb_sample[blk][c][j];
+            }
+            for (int i = tid; i < 2 * 144; i += 256) {
+                const int c = i / 144, r = i - c * 144;
+                so->hist[c][r >> 4][r & 15] = c < C ? rows[c < C ? c : 0][n_t - 9 + (r >> 4)][r & 15] : st->hist[c][r >> 4][r & 15];
+            }
+            if (tid == 0) {
+                so->reserved = st->reserved;
+                for (int k = 0; k < 8; k++)
+                    so->pad[k] = st->pad[k];
+                const uint32_t h1 = sh_info[k_last].h1;
+                so->frequency = (h1 >> 6) & 3;
+                so->blocks = (uint8_t)blocks;
+                so->channels = (uint8_t)C;
+                so->mode = (h1 >> 2) & 3;
+                so->allocation = (h1 >> 1) & 1;
+                so->subbands = 8;
+                so->bitpool = sh_info[k_last].bitpool;
+                if (pcm_count)
+                    pcm_count[s] = (uint32_t)n_frames * (uint32_t)frame_samples;
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_sbc_par_mono(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
-                                                      int n_frames, const SbcState* __restrict__ states,
-                                                      SbcState* __restrict__ states_next,
-                                                      const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
-                                                      size_t pcm_stride, uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count,
-                                                      int flags, const uint32_t* __restrict__ parallel)
+// grid = as many workgroups as fit the chip (efx_sbc_decode), block = 256
+__global__ __launch_bounds__(256, EFX_SBC_WAVES) void k_sbc_par_mono(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes, int n_frames,
+                                                      const SbcState* __restrict__ states, SbcState* __restrict__ states_next,
+                                                      const SbcTables* __restrict__ tables, const SbcFrameInfo* __restrict__ info,
+                                                      int16_t* __restrict__ pcm, size_t pcm_stride, uint32_t* __restrict__ pcm_count,
+                                                      int flags, SbcQueues* __restrict__ queues, const uint32_t* __restrict__ lists,
+                                                      int n_streams)
 {
-    sbc_par_body<1>(frames, stream_stride, frame_bytes, n_frames, states, states_next, tables, pcm, pcm_stride, ret, pcm_count, flags, parallel);
+    sbc_par_body<1, EFX_SBC_CHUNK_MONO>(frames, stream_stride, frame_bytes, n_frames, states, states_next, tables, info, pcm, pcm_stride, pcm_count, flags,
+                    queues, lists, n_streams);
 }
 __global__ __launch_bounds__(256) void k_sbc_par_stereo(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
                                                         int n_frames, const SbcState* __restrict__ states,
-                                                        SbcState* __restrict__ states_next,
-                                                        const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
-                                                        size_t pcm_stride, uint32_t* __restrict__ ret,
-                                                        uint32_t* __restrict__ pcm_count, int flags,
-                                                        const uint32_t* __restrict__ parallel)
+                                                        SbcState* __restrict__ states_next, const SbcTables* __restrict__ tables,
+                                                        const SbcFrameInfo* __restrict__ info, int16_t* __restrict__ pcm,
+                                                        size_t pcm_stride, uint32_t* __restrict__ pcm_count, int flags,
+                                                        SbcQueues* __restrict__ queues, const uint32_t* __restrict__ lists, int n_streams)
 {
-    sbc_par_body<2>(frames, stream_stride, frame_bytes, n_frames, states, states_next, tables, pcm, pcm_stride, ret, pcm_count, flags, parallel);
+    sbc_par_body<2, kSbcChunk>(frames, stream_stride, frame_bytes, n_frames, states, states_next, tables, info, pcm, pcm_stride, pcm_count, flags,
+                    queues, lists, n_streams);
 }
 
-// the states k_sbc_par left in `next` take their place (grid = streams; only streams that went the frame-parallel way)
-__global__ __launch_bounds__(256) void k_sbc_commit(SbcState* __restrict__ states, const SbcState* __restrict__ next,
-                                                    const uint32_t* __restrict__ parallel)
+// ---- general streams -------------------------------------------------------------------------------------------------------------
+// A work item is eight VIRTUAL frames v0 .. v1-1 of a stream; the plan says for each of them which geometry it is synthesised
+// under, where its rows sit on each channel's timeline, where its PCM goes and which frame's bits every quarter (four blocks x
+// one channel) of its subband samples comes from.  SLOTS = the frames whose samples the item needs: per channel up to three
+// earlier frames that hold the nine rows before the chunk's (found over plan.back: a channel's timeline skips the frames that put
+// nothing on it -- mono frames for channel 1, 4-subband headers for both), then the chunk's own.
+constexpr int kSbcSlots = 6 + kSbcChunk;
+constexpr int kSbcRowsMax = 9 + kSbcChunk * 16;
+
+__global__ __launch_bounds__(256) void k_sbc_gen(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes, int n_frames,
+                                                 const SbcState* __restrict__ states, SbcState* __restrict__ states_next,
+                                                 const SbcTables* __restrict__ tables, const SbcFrameInfo* __restrict__ info,
+                                                 const SbcFramePlan* __restrict__ plan, int16_t* __restrict__ pcm, size_t pcm_stride,
+                                                 int flags, SbcQueues* __restrict__ queues, const uint32_t* __restrict__ lists,
+                                                 int n_streams)
+{
+    __shared__ SbcTables tb;
+    __shared__ int32_t sb[kSbcSlots][16][2][8];       // the sb_sample array as it stood after each slot's get_samples()
+    __shared__ int32_t rows[2][kSbcRowsMax][16];
+    __shared__ uint16_t rowmap[2][kSbcRowsMax];       // row t of channel c <- slot << 4 | block; 0xFFFF: not this workgroup's to make
+    __shared__ SbcFramePlan sh_plan[kSbcSlots];
+    __shared__ SbcFrameInfo sh_info[kSbcSlots];
+    __shared__ uint8_t sh_scale[kSbcSlots][16];
+    __shared__ int sh_slot[kSbcSlots];
+
+    const int tid = threadIdx.x;
+    if (queues->count[kSbcGeneral] == 0)
+        return;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(tables);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&tb);
+        for (int i = tid; i < (int)(sizeof(SbcTables) / 4); i += 256)
+            dst[i] = src[i];
+    }
+    const int probe = flags & 1;
+    const int F = n_frames + probe;
+    const int chunks = (n_frames + 1 + kSbcChunk - 1) / kSbcChunk;  // (of virtual frames; the last may be empty)
+    const uint32_t limit = (uint32_t)n_frames * (uint32_t)frame_bytes;
+    int s, chunk;
+    for (int it = 0; sbc_next_item(queues, lists, kSbcGeneral, n_streams, chunks, it, &s, &chunk); it++) {
+        const int v0 = chunk * kSbcChunk, v1 = min(F, v0 + kSbcChunk);
+        if (v0 >= F)
+            continue;
+        const uint8_t* gbase = frames + (size_t)s * stream_stride;
+        const SbcFrameInfo* inf = info + (size_t)s * n_frames;
+        const SbcFramePlan* pl = plan + (size_t)s * (n_frames + 1);
+        const SbcState* st = states + s;
+        // ---- slots -----------------------------------------------------------------------------------------------------------
+        if (tid < 2) {
+            int need = 9, g = pl[v0].back[tid];
+            for (int hop = 0; hop < 3; hop++) {
+                const bool take = need > 0 && g >= 0;
+                sh_slot[tid * 3 + hop] = take ? g : -1;
+                if (take) {
+                    need -= (int)(pl[g].geom & 0xFF);  // (a frame on the chain has rows on this timeline)
+                    g = pl[g].back[tid];
+                }
+            }
+        } else if (tid < 2 + kSbcChunk)
+            sh_slot[6 + tid - 2] = v0 + tid - 2 < v1 ? v0 + tid - 2 : -1;
+        for (int i = tid; i < 2 * kSbcRowsMax; i += 256)
+            (&rowmap[0][0])[i] = 0xFFFF;
+        __syncthreads();
+        if (tid < kSbcSlots * 7) {
+            const int j = tid / 7, part = tid - j * 7, u = sh_slot[j];
+            if (u >= 0) {
+                if (part < 4)
+                    reinterpret_cast<uint4*>(&sh_plan[j])[part] = reinterpret_cast<const uint4*>(pl + u)[part];
+                else
+                    reinterpret_cast<uint4*>(&sh_info[j])[part - 4] = reinterpret_cast<const uint4*>(inf + max(u - probe, 0))[part - 4];
+            }
+        } else if (tid < kSbcSlots * 7 + kSbcSlots * 2) {
+            // scale factors, eight bytes per slot
+            const int i = tid - kSbcSlots * 7, j = i >> 1, half = i & 1, u = sh_slot[j];
+            if (u >= 0) {
+                const uint32_t pos = (uint32_t)max(u - probe, 0) * (uint32_t)frame_bytes + 4 + 4 * (uint32_t)half;
+                for (int b = 0; b < 4; b++) {
+                    const uint32_t a = pos + b < limit ? gbase[pos + b] : 0u;
+                    sh_scale[j][half * 8 + 2 * b] = (uint8_t)(a >> 4);
+                    sh_scale[j][half * 8 + 2 * b + 1] = (uint8_t)(a & 0xF);
+                }
+            }
+        }
+        __syncthreads();
+        // timeline index of row 0 of channel c, and how many rows the channel has here (nine before the chunk's first + the chunk's)
+        const SbcFramePlan& pf = sh_plan[6];
+        const SbcFramePlan& plast = sh_plan[6 + v1 - v0 - 1];
+        int base[2], n_t[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            base[c] = (int)pf.vb[c] - 9;
+            const bool has = ((plast.geom >> 16) & 1) && (int)((plast.geom >> 8) & 0xFF) > c;
+            n_t[c] = (int)plast.vb[c] + (has ? (int)(plast.geom & 0xFF) : 0) - base[c];
+        }
+        const bool last_item = v1 == F;
+        // ---- row map; history rows; samples -------------------------------------------------------------------------------------------
+        for (int i = tid; i < kSbcSlots * 32; i += 256) {
+            const int j = i >> 5, c = (i >> 4) & 1, blk = i & 15, u = sh_slot[j];
+            if (u < 0 || (j < 6 && j / 3 != c))
+                continue;  // (an earlier frame serves the channel whose chain it is on)
+            const SbcFramePlan& p = sh_plan[j];
+            if (!((p.geom >> 16) & 1) || (int)((p.geom >> 8) & 0xFF) <= c || blk >= (int)(p.geom & 0xFF))
+                continue;
+            const int t = (int)p.vb[c] + blk - base[c];
+            if (t >= 0 && t < n_t[c])
+                rowmap[c][t] = (uint16_t)(j << 4 | blk);
+        }
+        for (int i = tid; i < 2 * 9 * 16; i += 256) {
+            const int c = i / 144, r = i - c * 144, t = r >> 4, o = r & 15, T = base[c] + t;
+            if (T < 0)
+                rows[c][t][o] = st->hist[c][9 + T][o];  // (rows before the call's first: the state's filter memory)
+        }
+        for (int j = 0; j < kSbcSlots; j++) {
+            const int u = sh_slot[j];
+            if (u < 0)
+                continue;
+            const int blk = tid >> 4, c = (tid >> 3) & 1, sbi = tid & 7;
+            const SbcFramePlan& p = sh_plan[j];
+            const bool whole = last_item && j == 6 + v1 - v0 - 1;  // (the last frame's samples become the state's: all of them)
+            if (!whole && (blk >= (int)(p.geom & 0xFF) || c >= (int)((p.geom >> 8) & 0xFF) || (j < 6 && j / 3 != c)))
+                continue;
+            const int h = p.src[(blk >> 2) * 2 + c];
+            int32_t sample;
+            if (h < 0)
+                sample = st->sb_sample[blk][c][sbi];
+            else {
+                // the frame that wrote this quarter last: this one (its info is in LDS) or an earlier one
+                const int fh = max(h - probe, 0);
+                uint32_t bits, prefix, per_block, h1, scale;
+                if (h == u) {
+                    const uint8_t* fi = reinterpret_cast<const uint8_t*>(&sh_info[j]);
+                    bits = fi[c * 8 + sbi];
+                    prefix = fi[16 + c * 8 + sbi];
+                    per_block = sh_info[j].per_block;
+                    h1 = sh_info[j].h1;
+                    scale = sh_scale[j][c * 8 + sbi];
+                } else {
+                    const SbcFrameInfo* fi = inf + fh;
+                    bits = fi->bits[c][sbi];
+                    prefix = fi->prefix[c][sbi];
+                    per_block = fi->per_block;
+                    h1 = fi->h1;
+                    const uint32_t pos = (uint32_t)fh * (uint32_t)frame_bytes + 4 + (uint32_t)((c * 8 + sbi) >> 1);
+                    const uint32_t a = pos < limit ? gbase[pos] : 0u;
+                    scale = (sbi & 1) ? (a & 0xF) : (a >> 4);
+                }
+                const uint32_t data_off = 4 + (((h1 >> 2) & 3) ? 8u : 4u);
+                const uint32_t bitpos = ((uint32_t)fh * (uint32_t)frame_bytes + data_off) * 8 + (uint32_t)blk * per_block + prefix;
+                const uint32_t pos = bitpos >> 3;
+                uint32_t w = 0;
+                for (uint32_t k = 0; k < 4; k++)
+                    w = (w << 8) | (pos + k < limit ? gbase[pos + k] : 0u);
+                const uint32_t v = __builtin_amdgcn_ubfe(w, 32 - (bitpos & 7) - bits, bits);
+                sample = bits ? sbc_iquant(v, bits, scale, tb.iq_magic[bits]) : 0;
+            }
+            sb[j][blk][c][sbi] = sample;
+        }
+        __syncthreads();
+        // ---- matrixing -------------------------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+            for (int i = tid; i < n_t[c] * 16; i += 256) {
+                const int t = i >> 4, o = i & 15;
+                const uint32_t m = rowmap[c][t];
+                if (m == 0xFFFF)
+                    continue;
+                const int32_t* x = &sb[m >> 4][m & 15][c][0];
+                uint32_t acc = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    acc = mad24(tb.syn[o * 8 + j], x[j], acc);
+                rows[c][t][o] = (int32_t)acc >> 15;
+            }
+        __syncthreads();
+        // ---- windowing: items (channel, frame of the chunk, block, sample) -----------------------------------------------------------------
+        int16_t* out = pcm + (size_t)s * pcm_stride;
+        for (int it = 0; it < 2 * kSbcChunk * 16 * 8 / 256; it++) {
+            const int i = it * 256 + tid;
+            const int c = i >> 10, fr = (i >> 7) & 7, blk = (i >> 3) & 15, o = i & 7;
+            if (fr >= v1 - v0)
+                continue;
+            const SbcFramePlan& p = sh_plan[6 + fr];
+            const int blocks = (int)(p.geom & 0xFF), channels = (int)((p.geom >> 8) & 0xFF);
+            if (!((p.geom >> 16) & 1) || c >= channels || blk >= blocks || (probe && v0 + fr == 0))
+                continue;
+            const int t = (int)p.vb[c] + blk - base[c];
+            uint32_t acc = 0;
+#pragma unroll
+            for (int j = 0; j < 10; j += 2) {
+                acc = mad24(rows[c][t - j][o], tb.proto[o * 10 + j], acc);
+                acc = mad24(rows[c][t - j - 1][o + 8], tb.proto[o * 10 + j + 1], acc);
+            }
+            int32_t v = (int32_t)acc >> 15;
+            v = v < -0x7FFF ? -0x7FFF : (v > 0x7FFF ? 0x7FFF : v);
+            out[(size_t)p.pcm_off + c * blocks * 8 + blk * 8 + o] = (int16_t)v;
+        }
+        // ---- the item of the last frame leaves the decoder state (in states_next: k_sbc_commit) ------------------------------------------
+        if (last_item) {
+            SbcState* so = states_next + s;
+            const int jl = 6 + v1 - v0 - 1;
+            {
+                const int blk = tid >> 4, c = (tid >> 3) & 1, j = tid & 7;
+                so->sb_sample[blk][c][j] = sb[jl][blk][c][j];
+            }
+            for (int i = tid; i < 2 * 144; i += 256) {
+                const int c = i / 144, r = i - c * 144;
+                so->hist[c][r >> 4][r & 15] = rows[c][n_t[c] - 9 + (r >> 4)][r & 15];
+            }
+            if (tid == 0) {
+                so->reserved = st->reserved;
+                for (int k = 0; k < 8; k++)
+                    so->pad[k] = st->pad[k];
+                const int g = plast.gsrc;
+                if (g >= 0) {
+                    const SbcFrameInfo* fi = inf + max(g - probe, 0);
+                    const uint32_t h1 = fi->h1;
+                    so->frequency = (h1 >> 6) & 3;
+                    so->blocks = (uint8_t)(4 * (((h1 >> 4) & 3) + 1));
+                    so->mode = (h1 >> 2) & 3;
+                    so->channels = ((h1 >> 2) & 3) ? 2 : 1;
+                    so->allocation = (h1 >> 1) & 1;
+                    so->subbands = (h1 & 1) ? 8 : 4;
+                    so->bitpool = fi->bitpool;
+                } else {
+                    so->frequency = st->frequency;
+                    so->blocks = (uint8_t)min((int)st->blocks, 16);
+                    so->channels = (uint8_t)min((int)st->channels, 2);
+                    so->mode = st->mode;
+                    so->allocation = st->allocation;
+                    so->subbands = st->subbands == 4 ? 4 : 8;
+                    so->bitpool = st->bitpool;
+                }
+            }
+        }
+    }
+}
+
+// grid = streams, block = 64: what ends an efx_sbc_decode call.  The state a frame-parallel kernel left in `next` takes its
+// place (the last chunk of a stream must not overwrite the state its first chunk may still be reading); a stream no list took
+// (k_sbc_plan) is decoded here, one wave walking its frames; and the stream's word in parallel[] goes back to
+// kSbcRegularFlag, where the next call's k_sbc_frames expects it.
+__global__ __launch_bounds__(64) void k_sbc_finish(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
+                                                   int n_frames, SbcState* __restrict__ states, const SbcState* __restrict__ next,
+                                                   const SbcTables* __restrict__ tables, int16_t* __restrict__ pcm,
+                                                   size_t pcm_stride, uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count,
+                                                   int flags, uint32_t* __restrict__ parallel)
 {
     const int s = blockIdx.x;
-    if (!parallel[s])
-        return;
-    static_assert(sizeof(SbcState) % 4 == 0, "SbcState is copied by dwords");
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(next + s);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(states + s);
-    for (int i = threadIdx.x; i < (int)(sizeof(SbcState) / 4); i += 256)
-        dst[i] = src[i];
+    const uint32_t how = parallel[s];
+    if (how == kSbcSerialFlag)
+        sbc_serial_body(frames, stream_stride, frame_bytes, n_frames, states, tables, pcm, pcm_stride, ret, pcm_count, flags);
+    else {
+        static_assert(sizeof(SbcState) % 4 == 0, "SbcState is copied by dwords");
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(next + s);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(states + s);
+        for (int i = threadIdx.x; i < (int)(sizeof(SbcState) / 4); i += 64)
+            dst[i] = src[i];
+    }
+    if (threadIdx.x == 0)
+        parallel[s] = kSbcRegularFlag;
 }
 
 }  // namespace efx

@@ -341,6 +341,8 @@ typedef enum efx_option {
     EFX_OPT_RECON_WAVES = 4, /* k_recon_all with EFX_OPT_RECON_ITEMS = 0: workgroups (waves) per compute unit; 0 = default (18) */
     EFX_OPT_RECON_ITEMS = 6, /* k_recon_all: items -- (picture, stream, 64 blocks) -- a wave takes before it ends and frees its
                                 slot (default 16); 0 = as many as there are (a grid of what the chip holds) */
+    EFX_OPT_SBC_SERIAL = 7,  /* 1 = efx_sbc_decode runs every stream through the one-wave-per-stream kernel (the comparison the tests
+                                run the frame-parallel kernels against); 0 = default */
     EFX_OPT_RECON_SPINS = 5  /* read only: polls the reconstruction waves of the most recent call spent waiting for a predecessor
                                 picture (synchronises) */
 } efx_option;

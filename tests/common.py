@@ -189,6 +189,35 @@ def sbc_frames(seed: int, n: int, freq: int = 3, blocks: int = 16, mode: int = 0
     return out.reshape(-1)
 
 
+def sbc_mutate(rng, frames: np.ndarray, fb: int, n: int, hits: int | None = None) -> np.ndarray:
+    """Frames the reference rejects or decodes under another geometry, sprinkled over a valid stream: a bad sync byte
+    (the previous samples are synthesised again), joint stereo (the geometry moves, stale samples), a 4-subband header
+    (nothing is synthesised until a good frame), an impossible bitpool, another block count or channel count (the PCM
+    size of a frame changes mid-stream), runs of bad sync bytes, another bitpool (the frame runs past -- or stops short
+    of -- the frame size)."""
+    fr = frames.reshape(n, fb).copy()
+    for _ in range(int(rng.integers(1, 8)) if hits is None else hits):
+        f = int(rng.integers(0, n))
+        kind = int(rng.integers(0, 8))
+        if kind == 0:
+            fr[f, 0] = 0x9D
+        elif kind == 1:
+            fr[f, 1] |= 0x0C
+        elif kind == 2:
+            fr[f, 1] &= 0xFE
+        elif kind == 3:
+            fr[f, 2] = 200
+        elif kind == 4:
+            fr[f, 1] = (fr[f, 1] & 0xCF) | (int(rng.integers(0, 4)) << 4)
+        elif kind == 5:
+            fr[f, 1] = (fr[f, 1] & 0xF3) | (int(rng.integers(0, 3)) << 2)
+        elif kind == 6:
+            fr[f:f + int(rng.integers(2, 12)), 0] = 0
+        else:
+            fr[f, 2] = int(rng.integers(2, 129))
+    return fr.reshape(-1)
+
+
 # (name, kwargs, frames, probe)
 SBC_CASES = [
     ("espflix_mono_48k_bp28", dict(freq=3, blocks=16, mode=0, alloc=0, bitpool=28), 40, True),

@@ -110,14 +110,14 @@ def test_rejected_frames(efx):
 
 
 def test_parallel_and_serial_paths_side_by_side(efx):
-    """Streams whose frames all decode with one geometry take the frame-parallel kernel (k_sbc_par), a stream with a
-    rejected frame the one-wave-per-stream kernel -- in the same call, and a stream changes sides from one call to the
-    next with its state (filter memory, stale samples) carried over.  21 and 13 frames: chunks of eight with a tail."""
+    """Streams whose frames all decode with one geometry take the regular frame-parallel kernel (k_sbc_par), a stream with
+    a rejected frame the general one (k_sbc_plan + k_sbc_gen) -- in the same call, and a stream changes sides from one call
+    to the next with its state (filter memory, stale samples) carried over.  21 and 13 frames: chunks of eight with a tail."""
     kw = dict(freq=3, blocks=16, mode=0, alloc=0, bitpool=28)
     fb = common.sbc_frame_bytes(16, 1, 28)
     clean = [common.sbc_frames(100 + i, 34, **kw) for i in range(3)]
     dirty = common.sbc_frames(200, 34, **kw).reshape(34, -1).copy()
-    dirty[5, 0] = 0x9D    # first call: a bad sync byte (the serial kernel's case); second call: clean
+    dirty[5, 0] = 0x9D    # first call: a bad sync byte (the general kernel's case); second call: clean
     streams = [clean[0], dirty.reshape(-1), clean[1], clean[2].copy()]
     streams[3].reshape(34, -1)[30, 0] = 0x9D   # clean in the first call (frames 0..20), rejected frame in the second
     dec = efx.Decoder(1, 1, 2)
@@ -143,6 +143,129 @@ def test_parallel_and_serial_paths_side_by_side(efx):
         assert np.array_equal(got[i], want), i
     for b in (d_fr, d_st, d_pcm, d_ret, d_cnt):
         b.free()
+    dec.close()
+
+
+def _decode_batch(efx, dec, streams, fb, frames, probe, calls, serial, state0=None):
+    """streams of `frames` frames each, decoded in `calls` calls (state carried over).  Returns per stream the PCM and the
+    return values, and the final states."""
+    n = len(streams)
+    stride = (frames * fb + 15) & ~15
+    buf = np.zeros(n * stride + 1024, dtype=np.uint8)
+    for i, st in enumerate(streams):
+        buf[i * stride:i * stride + frames * fb] = st
+    dec.set_option(efx.OPT_SBC_SERIAL, 1 if serial else 0)
+    d_fr, d_st = dec.alloc(buf.size), dec.alloc(n * efx.sbc_state_bytes())
+    d_fr.upload(buf)
+    d_st.upload(np.zeros(n * efx.sbc_state_bytes(), dtype=np.uint8) if state0 is None else state0)
+    pcm_stride = frames * 256
+    d_pcm, d_ret, d_cnt = dec.alloc(n * pcm_stride * 2), dec.alloc(n * frames * 4), dec.alloc(n * 4)
+    pcm = [[] for _ in range(n)]
+    rets = [[] for _ in range(n)]
+    per = (frames + calls - 1) // calls
+    for c in range(calls):
+        f0, f1 = c * per, min(frames, (c + 1) * per)
+        if f1 <= f0:
+            continue
+        d_ret.upload(np.full(n * frames, 0xDEADBEEF, dtype=np.uint32))
+        dec.sbc_decode(n, d_fr.ptr + f0 * fb, stride, fb, f1 - f0, d_st, d_pcm, pcm_stride, d_ret, d_cnt, probe_first=probe and c == 0)
+        dec.sync()
+        cnt = d_cnt.download(np.uint32, n)
+        allpcm = d_pcm.download(np.int16, n * pcm_stride).reshape(n, pcm_stride)
+        r = d_ret.download(np.uint32, n * (f1 - f0)).reshape(n, f1 - f0)
+        for i in range(n):
+            pcm[i].append(allpcm[i, :cnt[i]].copy())
+            rets[i] += [unpack_ret(x) for x in r[i]]
+    states = d_st.download(np.uint8, n * efx.sbc_state_bytes()).reshape(n, -1).copy()
+    for b in (d_fr, d_st, d_pcm, d_ret, d_cnt):
+        b.free()
+    dec.set_option(efx.OPT_SBC_SERIAL, 0)
+    return [np.concatenate(p) for p in pcm], rets, states
+
+
+@pytest.mark.parametrize("case", [0, 2, 3, 1], ids=["mono16", "dual8", "stereo4", "mono12"])
+def test_rejected_frames_decode_frame_parallel(efx, case):
+    """A stream with frames the reference rejects -- or that change the geometry mid-stream -- is resolved by k_sbc_plan (the
+    geometry, the stale samples, the PCM offsets and the rows a frame puts on each channel's timeline as prefix scans) and
+    decoded in chunks of eight frames by k_sbc_gen: against the oracle (PCM and return values of every frame), and against
+    the one-wave-per-stream kernel (the decoder states both leave, byte for byte).  48 streams per case: clean ones (the
+    regular kernels, in the same launch), lightly and heavily damaged ones; in one call with and without decode_audio()'s
+    probe, and in three calls with the state carried over."""
+    name, kw, _, _ = common.SBC_CASES[case]
+    ch = 1 if kw["mode"] == 0 else 2
+    fb = common.sbc_frame_bytes(kw["blocks"], ch, kw["bitpool"])
+    frames = 45
+    rng = np.random.default_rng(77 + case)
+    streams = []
+    for i in range(48):
+        fr = common.sbc_frames(3000 + 100 * case + i, frames, **kw)
+        if i % 4:
+            fr = common.sbc_mutate(rng, fr, fb, frames, hits=None if i % 4 == 3 else 1)
+        streams.append(fr)
+    dec = efx.Decoder(1, 1, 2)
+    for probe, calls in ((False, 1), (True, 1), (False, 3)):
+        got, rets, states = _decode_batch(efx, dec, streams, fb, frames, probe, calls, serial=False)
+        ser, sret, sstates = _decode_batch(efx, dec, streams, fb, frames, probe, calls, serial=True)
+        for i, fr in enumerate(streams):
+            if calls == 1:
+                want, wret = oracle.sbc_decode(fr, fb, probe)
+                if probe:
+                    want, wret = want[wret[0][1] // 2:], wret[1:]
+                assert rets[i] == wret, (name, probe, i)
+                assert np.array_equal(got[i], want), (name, probe, i)
+            # (three calls: a frame that runs past the frame size reads zeros beyond its call's last frame -- the oracle,
+            # one call, reads the next frame's bytes: the serial kernel, same calls, is the reference there)
+            assert rets[i] == sret[i], (name, probe, calls, i)
+            assert np.array_equal(got[i], ser[i]), (name, probe, calls, i)
+            assert np.array_equal(states[i], sstates[i]), (name, probe, calls, i)
+    dec.close()
+
+
+def test_frame_that_runs_past_the_stated_frame_size(efx):
+    """The caller states ONE frame size (decode_audio() takes it from the probe); a frame with a larger bitpool runs past
+    it and the reference reads on into the next frame's bytes (get_samples() never looks at the length again,
+    sbc_decoder.cpp:297-343).  So does every kernel -- also when such a frame is the last of a chunk of eight."""
+    kw = dict(freq=3, blocks=16, mode=0, alloc=0, bitpool=28)
+    fb = common.sbc_frame_bytes(16, 1, 28)
+    fr = common.sbc_frames(4242, 40, **kw).reshape(40, fb).copy()
+    for f in (7, 15, 16, 39):
+        fr[f, 2] = 60  # 124 bytes of sample bits in a 64-byte frame
+    fr = fr.reshape(-1)
+    want, wret = oracle.sbc_decode(fr, fb)
+    dec = efx.Decoder(1, 1, 2)
+    for serial in (False, True):
+        got, rets, _ = _decode_batch(efx, dec, [fr], fb, 40, False, 1, serial)
+        assert rets[0] == wret, serial
+        assert np.array_equal(got[0], want), serial
+    dec.close()
+
+
+def test_state_no_call_leaves_goes_to_the_serial_kernel(efx):
+    """A decoder state with a block count that is no multiple of four (no header leaves one) and frames that are synthesised
+    under it -- bad sync bytes up front -- would put 5 rows per frame on a timeline: k_sbc_plan hands such a stream to the one
+    wave that walks the frames (k_sbc_finish), next to regular and general streams in the same call."""
+    kw = dict(freq=3, blocks=16, mode=0, alloc=0, bitpool=28)
+    fb = common.sbc_frame_bytes(16, 1, 28)
+    frames = 20
+    streams = [common.sbc_frames(7000 + i, frames, **kw) for i in range(6)]
+    for i in (1, 3, 4):
+        streams[i] = streams[i].copy()
+        streams[i].reshape(frames, fb)[0:3, 0] = 0  # synthesised under the state's geometry
+    sb = efx.sbc_state_bytes()
+    st = np.zeros((6, sb), dtype=np.uint8)
+    rng = np.random.default_rng(9)
+    for i, blocks in ((1, 5), (3, 7), (4, 8)):  # (4: a state a call CAN leave: the general kernel's)
+        st[i, 1152:2176] = rng.integers(-2000, 2000, 256).astype(np.int32).view(np.uint8)
+        st[i, :1152] = rng.integers(-30000, 30000, 288).astype(np.int32).view(np.uint8)
+        st[i, 2176:2183] = (3, blocks, 1, 0, 0, 8, 28)
+    dec = efx.Decoder(1, 1, 2)
+    got, rets, states = _decode_batch(efx, dec, streams, fb, frames, False, 1, False, st.reshape(-1))
+    ser, sret, sstates = _decode_batch(efx, dec, streams, fb, frames, False, 1, True, st.reshape(-1))
+    for i in range(6):
+        assert rets[i] == sret[i], i
+        assert np.array_equal(got[i], ser[i]), i
+        assert np.array_equal(states[i], sstates[i]), i
+    assert len(got[1]) == 3 * 5 * 8 + 17 * 128 and len(got[4]) == 3 * 8 * 8 + 17 * 128
     dec.close()
 
 

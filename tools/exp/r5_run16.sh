@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 5, run 16: the mono/stereo kernels with the next item's loads in flight; chunk 8 (default) and 16
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r5u
+timeout 300 python -m pytest tests/test_gpu_sbc.py -x -q > gpurun_out/r5u/sbc_tests.log 2>&1; echo "tests rc=$?"; tail -4 gpurun_out/r5u/sbc_tests.log
+EFX_LIB=$GRAFT_REPO_ROOT/espflix_amd/libefx_c16.so timeout 300 python -m pytest tests/test_gpu_sbc.py -x -q > gpurun_out/r5u/sbc_tests_c16.log 2>&1; echo "tests c16 rc=$?"; tail -4 gpurun_out/r5u/sbc_tests_c16.log
+for v in "" c16 c16k7; do
+  L=$GRAFT_REPO_ROOT/espflix_amd/libefx.so; [ -n "$v" ] && L=$GRAFT_REPO_ROOT/espflix_amd/libefx_$v.so
+  EFX_LIB=$L timeout 100 python tools/exp/r5_sbc.py > gpurun_out/r5u/all_$v.json 2>/dev/null; cat gpurun_out/r5u/all_$v.json
+  EFX_LIB=$L timeout 100 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5u/prof_$v -o sbc -- python tools/exp/r5_sbc.py mono_clean > gpurun_out/r5u/t_$v.json 2>/dev/null
+  f=$(find gpurun_out/r5u/prof_$v -name "*kernel_stats.csv" | head -1)
+  echo "== ${v:-default} $(cut -c1-110 gpurun_out/r5u/t_$v.json)"; python tools/exp/kstats.py $f | grep "k_sbc_"
+  rm -rf gpurun_out/r5u/prof_$v
+done 2>&1 | tee gpurun_out/r5u/variants.txt
