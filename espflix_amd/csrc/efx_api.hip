@@ -49,13 +49,13 @@ __global__ void k_pdm(const int16_t*, int, int, int32_t*, uint16_t*);
 __global__ void k_sbc(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int);
 __global__ void k_sbc_frames(const uint8_t*, size_t, int, int, SbcFrameInfo*, uint32_t*, uint32_t*);
 __global__ void k_sbc_plan(const SbcFrameInfo*, int, int, const SbcState*, SbcFramePlan*, uint32_t*, SbcQueues*, uint32_t*, int, int, uint32_t*,
-                           uint32_t*);
+                           uint32_t*, SbcExtraItem*, uint8_t*);
 __global__ void k_sbc_par_stereo(const uint8_t*, size_t, int, int, const SbcState*, SbcState*, const SbcTables*, const SbcFrameInfo*, int16_t*,
-                                 size_t, uint32_t*, int, SbcQueues*, const uint32_t*, int);
+                                 size_t, uint32_t*, int, SbcQueues*, const uint32_t*, int, const SbcExtraItem*, int);
 __global__ void k_sbc_par_mono(const uint8_t*, size_t, int, int, const SbcState*, SbcState*, const SbcTables*, const SbcFrameInfo*, int16_t*,
-                               size_t, uint32_t*, int, SbcQueues*, const uint32_t*, int);
+                               size_t, uint32_t*, int, SbcQueues*, const uint32_t*, int, const SbcExtraItem*, int);
 __global__ void k_sbc_gen(const uint8_t*, size_t, int, int, const SbcState*, SbcState*, const SbcTables*, const SbcFrameInfo*,
-                          const SbcFramePlan*, int16_t*, size_t, int, SbcQueues*, const uint32_t*, int);
+                          const SbcFramePlan*, int16_t*, size_t, int, SbcQueues*, const uint32_t*, int, const uint8_t*, int);
 __global__ void k_sbc_finish(const uint8_t*, size_t, int, int, SbcState*, const SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*,
                              uint32_t*, int, uint32_t*);
 }  // namespace efx
@@ -223,6 +223,8 @@ struct efx_ctx {
     size_t sbc_flags_cap = 0;
     SbcFrameInfo* d_sbc_info = nullptr;  // per (stream, frame)
     SbcFramePlan* d_sbc_plan = nullptr;  // per (stream, frame + 1)
+    SbcExtraItem* d_sbc_extra = nullptr; // two lists of (stream, granule of eight frames) capacity each
+    uint8_t* d_sbc_cover = nullptr;      // per (stream, granule): a regular kernel decodes it
     size_t sbc_info_cap = 0;             // in frames: streams x (frames + 1)
     int opt_sbc_serial = 0;              // 1 = every stream through k_sbc, one wave per stream (the tests' comparison)
     bool sbc_flags_clean = false;        // d_sbc_flags[0, n) all kSbcRegularFlag (k_sbc_finish leaves them so)
@@ -658,7 +660,7 @@ void efx_destroy(efx_ctx* ctx)
         else
             (void)hipHostUnregister(a.base);
     }
-    void* bufs[] = {ctx->d_tables, ctx->d_tm_tables, ctx->d_sbc_flags, ctx->d_sbc_next, ctx->d_sbc_info, ctx->d_sbc_plan, ctx->d_state, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0],
+    void* bufs[] = {ctx->d_tables, ctx->d_tm_tables, ctx->d_sbc_flags, ctx->d_sbc_next, ctx->d_sbc_info, ctx->d_sbc_plan, ctx->d_sbc_extra, ctx->d_sbc_cover, ctx->d_state, ctx->d_frames, ctx->d_video[0],  ctx->d_video[1], ctx->d_video_lines[0],
                     ctx->d_video_lines[1], ctx->d_hash, ctx->d_ts, ctx->d_demux_chunks, ctx->d_sbc_tables, ctx->d_idx_info, ctx->d_ts_off, ctx->d_idx_len,
                     ctx->d_idx_base, ctx->d_idx_seq};
     for (auto& te : ctx->timing_ring)
@@ -1865,13 +1867,22 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
             (void)dev_free(ctx->d_sbc_info);
         if (ctx->d_sbc_plan)
             (void)dev_free(ctx->d_sbc_plan);
+        if (ctx->d_sbc_extra)
+            (void)dev_free(ctx->d_sbc_extra);
+        if (ctx->d_sbc_cover)
+            (void)dev_free(ctx->d_sbc_cover);
         ctx->d_sbc_info = nullptr;
         ctx->d_sbc_plan = nullptr;
+        ctx->d_sbc_extra = nullptr;
+        ctx->d_sbc_cover = nullptr;
         ctx->sbc_info_cap = 0;
         EFX_HIP(dalloc(&ctx->d_sbc_info, info_need));
         EFX_HIP(dalloc(&ctx->d_sbc_plan, info_need));
+        EFX_HIP(dalloc(&ctx->d_sbc_extra, info_need / 4 + 2));  // (2 lists x streams x ceil(frames / 8) <= streams x (frames + 1) / 4 + 2)
+        EFX_HIP(dalloc(&ctx->d_sbc_cover, info_need));
         ctx->sbc_info_cap = info_need;
     }
+    const int n_gran = (n_frames + 7) / 8, extra_cap = n_streams * n_gran;
     uint32_t* const d_how = ctx->d_sbc_flags;
     uint32_t* const d_lists = d_how + ctx->sbc_flags_cap;
     SbcQueues* const d_queues = reinterpret_cast<SbcQueues*>(d_how + 4 * ctx->sbc_flags_cap);
@@ -1882,7 +1893,8 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
     hipLaunchKernelGGL(k_sbc_frames, dim3((n_frames + 255) / 256, n_streams), dim3(256), 0, ctx->stream, frames_device, stream_stride,
                        frame_bytes, n_frames, ctx->d_sbc_info, ret_device, d_how);
     hipLaunchKernelGGL(k_sbc_plan, dim3(n_streams + 1), dim3(256), 0, ctx->stream, ctx->d_sbc_info, n_frames, flags, state, ctx->d_sbc_plan,
-                       d_how, d_queues, d_lists, n_streams, (int)ctx->sbc_flags_cap, ret_device, pcm_count_device);
+                       d_how, d_queues, d_lists, n_streams, (int)ctx->sbc_flags_cap, ret_device, pcm_count_device, ctx->d_sbc_extra,
+                       ctx->d_sbc_cover);
     // Persistent workgroups take (stream, chunk of frames) items off the list of their kind, dealt round robin; a list that
     // stayed empty costs its kernel one look.  Grids = what is resident at a time: EFX_SBC_WG_PER_CU workgroups per compute unit
     // 
@@ -1891,13 +1903,13 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
     const int g_mono = (int)std::min<long long>(items, (long long)ctx->n_cus * EFX_SBC_WG_PER_CU), g_wide = (int)std::min<long long>(items, (long long)ctx->n_cus * 4);
     hipLaunchKernelGGL(k_sbc_par_mono, dim3(g_mono), dim3(256), 0, ctx->stream, frames_device, stream_stride, frame_bytes, n_frames, state,
                        ctx->d_sbc_next, ctx->d_sbc_tables, ctx->d_sbc_info, pcm_device, pcm_stride, pcm_count_device, flags, d_queues, d_lists,
-                       (int)ctx->sbc_flags_cap);
+                       (int)ctx->sbc_flags_cap, ctx->d_sbc_extra, extra_cap);
     hipLaunchKernelGGL(k_sbc_par_stereo, dim3(g_wide), dim3(256), 0, ctx->stream, frames_device, stream_stride, frame_bytes, n_frames, state,
                        ctx->d_sbc_next, ctx->d_sbc_tables, ctx->d_sbc_info, pcm_device, pcm_stride, pcm_count_device, flags, d_queues, d_lists,
-                       (int)ctx->sbc_flags_cap);
+                       (int)ctx->sbc_flags_cap, ctx->d_sbc_extra, extra_cap);
     hipLaunchKernelGGL(k_sbc_gen, dim3(g_wide), dim3(256), 0, ctx->stream, frames_device, stream_stride, frame_bytes, n_frames, state,
                        ctx->d_sbc_next, ctx->d_sbc_tables, ctx->d_sbc_info, ctx->d_sbc_plan, pcm_device, pcm_stride, flags, d_queues, d_lists,
-                       (int)ctx->sbc_flags_cap);
+                       (int)ctx->sbc_flags_cap, ctx->d_sbc_cover, n_gran);
     // the new states take their place; a stream whose state no call of this library can have left is decoded by one wave
     hipLaunchKernelGGL(k_sbc_finish, dim3(n_streams), dim3(64), 0, ctx->stream, frames_device, stream_stride, frame_bytes, n_frames, state,
                        ctx->d_sbc_next, ctx->d_sbc_tables, pcm_device, pcm_stride, ret_device, pcm_count_device, flags, d_how);

@@ -182,7 +182,7 @@ struct alignas(16) SbcFramePlan {
     int32_t back[2];    // the latest earlier frame with rows on channel c's timeline; -1 = none in this call
     int32_t gsrc;       // the frame whose header left the geometry this frame is synthesised under; -1 = the state's
     uint32_t geom;      // blocks | channels << 8 | synthesised << 16
-    uint32_t pad;
+    uint32_t pad;       // (k_sbc_plan's own: the first frame of the run of frames decoding under one geometry that this frame ends)
 };
 static_assert(sizeof(SbcFramePlan) == 64, "SbcFramePlan is moved as four uint4");
 
@@ -191,7 +191,15 @@ static_assert(sizeof(SbcFramePlan) == 64, "SbcFramePlan is moved as four uint4")
 constexpr int kSbcMono = 0, kSbcStereo = 1, kSbcGeneral = 2;
 struct SbcQueues {
     uint32_t count[4];  // streams on list c
-    uint32_t next[4];   // next (stream, chunk) item of list c
+    uint32_t extra[4];  // kSbcMono, kSbcStereo: single chunks of GENERAL streams that a regular kernel can take (SbcExtraItem)
+};
+// A chunk of a general stream whose frames -- and the frames that hold the nine blocks before it -- all decode under one
+// geometry is, but for where its PCM goes, a regular stream's: k_sbc_plan hands it to the regular kernel of its kind.
+struct alignas(16) SbcExtraItem {
+    uint32_t entry;     // stream | block-count code << 30 (as the list entries of regular streams)
+    uint32_t chunk;     // in the kernel's own chunk size
+    uint32_t pcm_base;  // PCM samples of the call before the chunk's first frame
+    uint32_t pad;
 };
 
 // per-stream SBC decoder state (the reference's SBC_Decode, sbc_decoder.h:12-25, with the sliding

@@ -39,6 +39,7 @@
 namespace efx {
 
 constexpr uint32_t kSbcRegularFlag = 0xFFFFFFFFu, kSbcGeneralFlag = 0, kSbcSerialFlag = 2;  // parallel[stream]
+constexpr uint32_t kSbcSkipEntry = 0xFFFFFFFEu;  // SbcExtraItem::entry of a chunk that is not a regular kernel's
 
 namespace {
 
@@ -321,6 +322,26 @@ __global__ __launch_bounds__(64) void k_sbc(const uint8_t* __restrict__ frames, 
     sbc_serial_body(frames, stream_stride, frame_bytes, n_frames, states, tables, pcm, pcm_stride, ret, pcm_count, flags);
 }
 
+// (development switches: the alternatives measured in profiles/r5_sbc.md)
+#ifndef EFX_SBC_M
+#define EFX_SBC_M 1      // matrixing: a thread makes two outputs of 1 = two consecutive rows, 0 = one row per trip
+#endif
+#ifndef EFX_SBC_SKIP
+#define EFX_SBC_SKIP 0   // timing ablations (wrong PCM): 1 = no dequantisation, 2 = no matrixing of the chunk's rows, 4 = no windowing
+#endif
+#ifndef EFX_SBC_CHUNK_MONO
+#define EFX_SBC_CHUNK_MONO 16  // frames per work item of k_sbc_par_mono (8: 7 workgroups per compute unit; 16: 4, and 12 % faster)
+#endif
+#ifndef EFX_SBC_PITCH
+#define EFX_SBC_PITCH 18 // (16 = unpadded)
+#endif
+#ifndef EFX_SBC_WAVES
+#define EFX_SBC_WAVES 4  // k_sbc_par_mono: waves per SIMD the register allocation aims at (= workgroups per compute unit)
+#endif
+constexpr int kSbcChunk = 8;                 // frames per work item (k_sbc_par_mono: EFX_SBC_CHUNK_MONO)
+constexpr int kSbcMonoGranules = EFX_SBC_CHUNK_MONO / kSbcChunk;  // k_sbc_gen items in a k_sbc_par_mono item
+static_assert(EFX_SBC_CHUNK_MONO == kSbcChunk * kSbcMonoGranules && (kSbcMonoGranules == 1 || kSbcMonoGranules == 2), "mono chunk");
+
 // ---- per frame: header and bit allocation --------------------------------------------------------------------------------
 // grid = (frames / 256, streams), one thread per frame.  parallel[] arrives set to kSbcRegularFlag; a frame that does not
 // decode (sbc_decoder.cpp:282-295) or leaves the geometry of frame 0 clears its stream's word (= kSbcGeneralFlag).  ret: the
@@ -393,25 +414,37 @@ __global__ __launch_bounds__(256) void k_sbc_frames(const uint8_t* __restrict__ 
 
 namespace {
 
-// wave-wide inclusive scans (64 lanes)
-__device__ inline int scan_max(int v, int lane)
+// Wave-wide inclusive scans (64 lanes) as six DPP steps: row_shr 1, 2, 4, 8 inside the rows of sixteen lanes, then row_bcast 15
+// and 31 carry the rows' totals on (gfx9; a lane without a source takes the identity).  __shfl_up() would be a ds_bpermute
+// round trip per step -- sixteen scans a tile made k_sbc_plan 58 us for 256 streams.
+template <int kCtrl, int kRowMask>
+__device__ inline int sbc_dpp(int identity, int v)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d, 64);
-        v = lane >= d ? max(v, o) : v;
-    }
+    return __builtin_amdgcn_update_dpp(identity, v, kCtrl, kRowMask, 0xF, false);
+}
+__device__ inline int scan_max(int v, int)  // (values >= -1: -1 is the identity)
+{
+    v = max(v, sbc_dpp<0x111, 0xF>(-1, v));
+    v = max(v, sbc_dpp<0x112, 0xF>(-1, v));
+    v = max(v, sbc_dpp<0x114, 0xF>(-1, v));
+    v = max(v, sbc_dpp<0x118, 0xF>(-1, v));
+    v = max(v, sbc_dpp<0x142, 0xA>(-1, v));
+    v = max(v, sbc_dpp<0x143, 0xC>(-1, v));
     return v;
 }
-__device__ inline uint32_t scan_add(uint32_t v, int lane)
+__device__ inline uint32_t scan_add(uint32_t u, int)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d, 64);
-        v = lane >= d ? v + o : v;
-    }
-    return v;
+    int v = (int)u;
+    v += sbc_dpp<0x111, 0xF>(0, v);
+    v += sbc_dpp<0x112, 0xF>(0, v);
+    v += sbc_dpp<0x114, 0xF>(0, v);
+    v += sbc_dpp<0x118, 0xF>(0, v);
+    v += sbc_dpp<0x142, 0xA>(0, v);
+    v += sbc_dpp<0x143, 0xC>(0, v);
+    return (uint32_t)v;
 }
+// the value of the lane before (lane 0: `first`): wave_shr 1
+__device__ inline int lane_before(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xF, 0xF, false); }
 
 struct SbcGeom {
     int blocks, channels;
@@ -431,7 +464,8 @@ __global__ __launch_bounds__(256) void k_sbc_plan(const SbcFrameInfo* __restrict
                                                   const SbcState* __restrict__ states, SbcFramePlan* __restrict__ plan,
                                                   uint32_t* __restrict__ parallel, SbcQueues* __restrict__ queues,
                                                   uint32_t* __restrict__ lists, int n_streams, int list_stride,
-                                                  uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count)
+                                                  uint32_t* __restrict__ ret, uint32_t* __restrict__ pcm_count,
+                                                  SbcExtraItem* __restrict__ extra, uint8_t* __restrict__ cover)
 {
     if ((int)blockIdx.x == n_streams) {
         __shared__ uint32_t wsum[3][4];
@@ -495,24 +529,34 @@ __global__ __launch_bounds__(256) void k_sbc_plan(const SbcFrameInfo* __restrict
     const int probe = flags & 1;
     const int F = n_frames + probe;
     SbcFramePlan* pl = plan + (size_t)s * (n_frames + 1);
-    int c_gsrc = -1, c_back0 = -1, c_back1 = -1;
+    const int n_gran = (n_frames + kSbcChunk - 1) / kSbcChunk;
+    uint8_t* cov = cover + (size_t)s * n_gran;
+    int c_gkey = -1, c_back0 = -1, c_back1 = -1, c_lb = -1;
     int c_src[8];
 #pragma unroll
     for (int k = 0; k < 8; k++)
         c_src[k] = -1;
-    uint32_t c_vb0 = 0, c_vb1 = 0, c_pcm = 0;
+    uint32_t c_vb0 = 0, c_vb1 = 0, c_pcm = 0, c_misc = 0;
+    // (a frame's word: h1 | bitpool << 8 | flags << 16; the next tile's are on their way while this one's scans run)
+    auto misc_of = [&](int v) -> uint32_t { return v < F ? reinterpret_cast<const uint32_t*>(inf + max(v - probe, 0))[9] : 0u; };
+    uint32_t misc_ahead = misc_of(lane);
     for (int v0 = 0; v0 < F; v0 += 64) {
         const int v = v0 + lane;
         const bool in = v < F;
         const int f = max(v - probe, 0);
-        uint32_t misc = 0;
-        if (in)
-            misc = reinterpret_cast<const uint32_t*>(inf + f)[9];  // h1 | bitpool << 8 | flags << 16
+        const uint32_t misc = misc_ahead;
+        misc_ahead = misc_of(v + 64);
         const bool sync = (misc >> 16) & kSbcSync, ok = (misc >> 16) & kSbcOk;
-        const int gsrc = max(c_gsrc, scan_max(sync ? v : -1, lane));
+        // the frame whose header left the geometry, with that header in the key's low byte (no second look at memory)
+        const int gkey = max(c_gkey, scan_max(sync ? (int)((uint32_t)v << 8 | (misc & 0xFF)) : -1, lane));
+        const int gsrc = gkey >> 8;
         SbcGeom g = gs;
-        if (in && gsrc >= 0)
-            g = geom_of_header(inf[max(gsrc - probe, 0)].h1);
+        if (in && gkey >= 0)
+            g = geom_of_header((uint32_t)gkey & 0xFF);
+        // where the run of frames that decode under one geometry, this frame its last so far, began (granules below)
+        const uint32_t prev = (uint32_t)lane_before((int)misc, (int)c_misc);
+        const bool runs_on = ok && ((prev >> 16) & kSbcOk) && ((misc ^ prev) & 0x30) == 0 && (((misc >> 2) & 3) != 0) == (((prev >> 2) & 3) != 0);
+        const int lb = max(c_lb, scan_max(runs_on ? -1 : v, lane));
         const bool synth = in && !g.four;
         const uint32_t nb0 = synth && g.channels > 0 ? (uint32_t)g.blocks : 0u, nb1 = synth && g.channels > 1 ? (uint32_t)g.blocks : 0u;
         const uint32_t pcm = synth ? (uint32_t)(g.blocks * 8 * g.channels) : 0u;
@@ -520,9 +564,7 @@ __global__ __launch_bounds__(256) void k_sbc_plan(const SbcFrameInfo* __restrict
         const uint32_t i_pcm = scan_add(pcm_c, lane), i_vb0 = scan_add(nb0, lane), i_vb1 = scan_add(nb1, lane);
         const int i_back0 = scan_max(nb0 ? v : -1, lane), i_back1 = scan_max(nb1 ? v : -1, lane);
         // exclusive: what lies before this frame
-        int e_back0 = __shfl_up(i_back0, 1, 64), e_back1 = __shfl_up(i_back1, 1, 64);
-        e_back0 = lane ? max(e_back0, c_back0) : c_back0;
-        e_back1 = lane ? max(e_back1, c_back1) : c_back1;
+        const int e_back0 = max(lane_before(i_back0, -1), c_back0), e_back1 = max(lane_before(i_back1, -1), c_back1);
         const SbcGeom hg = geom_of_header(misc & 0xFF);
         int src[8];
 #pragma unroll
@@ -535,43 +577,78 @@ __global__ __launch_bounds__(256) void k_sbc_plan(const SbcFrameInfo* __restrict
             o[0] = make_uint4((uint32_t)src[0], (uint32_t)src[1], (uint32_t)src[2], (uint32_t)src[3]);
             o[1] = make_uint4((uint32_t)src[4], (uint32_t)src[5], (uint32_t)src[6], (uint32_t)src[7]);
             o[2] = make_uint4(c_pcm + i_pcm - pcm_c, c_vb0 + i_vb0 - nb0, c_vb1 + i_vb1 - nb1, (uint32_t)e_back0);
-            o[3] = make_uint4((uint32_t)e_back1, (uint32_t)gsrc, (uint32_t)g.blocks | ((uint32_t)g.channels << 8) | (synth ? 1u << 16 : 0u), 0u);
+            o[3] = make_uint4((uint32_t)e_back1, (uint32_t)gsrc, (uint32_t)g.blocks | ((uint32_t)g.channels << 8) | (synth ? 1u << 16 : 0u),
+                              (uint32_t)lb);
             if (ret && !ok && v >= probe)
                 ret[(size_t)s * n_frames + f] = 0xFFFFu | ((pcm * 2) << 16);
         }
+        // ---- granules a regular kernel can take --------------------------------------------------------------------------------------
+        // In units of eight frames (k_sbc_gen's items; a tile holds eight): a granule is REGULAR when its frames and the frames
+        // that hold the nine blocks before it all decode under one geometry -- its last frame decodes and the run it ends began
+        // early enough.  Then every sample in reach is the frame's own, the rows before the granule are the last blocks of the
+        // frames before it, and only the PCM offset is not what a regular stream's would be.  Not the first granule (the state's
+        // filter memory), not the last frame's (it leaves the state), not with the probe.  A stereo granule goes to
+        // k_sbc_par_stereo as it is, two mono granules that make an aligned 16 frames to k_sbc_par_mono; every slot of the two
+        // tables (stream x chunk of the kernel's size) and every cover byte is written, taken or not.  The last lane of a
+        // granule decides (lanes 7 and 15 of a row of sixteen; what they need of each other comes over DPP row shifts).
+        {
+            const uint32_t pcm_at = c_pcm + i_pcm - pcm_c;  // PCM samples before this frame
+            const int gi = v >> 3;                          // (probe: no granule is taken, v - f does not matter)
+            const uint32_t h1 = misc & 0xFF;
+            const int pre = (9 + 4 * (int)((h1 >> 4) & 3) + 3) / (4 * (int)(((h1 >> 4) & 3) + 1));  // frames that hold nine blocks
+            const bool last_of_gran = (lane & 7) == 7;
+            const bool reg = last_of_gran && !probe && gi >= 1 && v + 1 < n_frames && ok && lb <= v - 7 - pre;
+            const bool stereo = ((h1 >> 2) & 3) != 0;
+            const uint32_t mine = (reg ? 1u : 0u) | (stereo ? 2u : 0u);
+            const uint32_t even = (uint32_t)sbc_dpp<0x118, 0xF>(0, (int)mine);  // lane 15 of a row: what lane 7 found
+            const uint32_t pcm7 = (uint32_t)sbc_dpp<0x117, 0xF>(0, (int)pcm_at), pcm15 = (uint32_t)sbc_dpp<0x11F, 0xF>(0, (int)pcm_at);
+            const bool take_stereo = mine == 3;
+            const bool take_mono = kSbcMonoGranules == 1 ? mine == 1 : ((lane & 15) == 15 && mine == 1 && even == 1);
+            const uint32_t entry = (uint32_t)s | (((h1 >> 4) & 3) << 30);
+            if (last_of_gran && gi < n_gran) {
+                SbcExtraItem e;
+                e.entry = take_stereo ? entry : kSbcSkipEntry;
+                e.chunk = (uint32_t)gi;
+                e.pcm_base = pcm7;
+                e.pad = 0;
+                extra[(size_t)kSbcStereo * n_streams * n_gran + (size_t)s * n_gran + gi] = e;
+                if (kSbcMonoGranules == 1) {
+                    e.entry = take_mono ? entry : kSbcSkipEntry;
+                    extra[(size_t)kSbcMono * n_streams * n_gran + (size_t)s * n_gran + gi] = e;
+                    cov[gi] = (take_mono || take_stereo) ? 1 : 0;
+                }
+            }
+            if (kSbcMonoGranules == 2 && (lane & 15) == 15 && gi - 1 < n_gran) {
+                // (lane 15 of a row: the odd granule gi and the even one before it)
+                SbcExtraItem e;
+                e.entry = take_mono ? entry : kSbcSkipEntry;
+                e.chunk = (uint32_t)(gi >> 1);
+                e.pcm_base = pcm15;
+                e.pad = 0;
+                extra[(size_t)kSbcMono * n_streams * n_gran + (size_t)s * ((n_gran + 1) >> 1) + (gi >> 1)] = e;
+                cov[gi - 1] = (take_mono || even == 3) ? 1 : 0;
+                if (gi < n_gran)
+                    cov[gi] = (take_mono || take_stereo) ? 1 : 0;
+            }
+        }
         // carries: the last lane's inclusive values
-        c_gsrc = __shfl(gsrc, 63, 64);
-        c_back0 = max(c_back0, __shfl(i_back0, 63, 64));
-        c_back1 = max(c_back1, __shfl(i_back1, 63, 64));
-        c_pcm += __shfl(i_pcm, 63, 64);
-        c_vb0 += __shfl(i_vb0, 63, 64);
-        c_vb1 += __shfl(i_vb1, 63, 64);
+        c_gkey = __builtin_amdgcn_readlane(gkey, 63);
+        c_lb = __builtin_amdgcn_readlane(lb, 63);
+        c_misc = (uint32_t)__builtin_amdgcn_readlane((int)misc, 63);
+        c_back0 = max(c_back0, __builtin_amdgcn_readlane(i_back0, 63));
+        c_back1 = max(c_back1, __builtin_amdgcn_readlane(i_back1, 63));
+        c_pcm += (uint32_t)__builtin_amdgcn_readlane((int)i_pcm, 63);
+        c_vb0 += (uint32_t)__builtin_amdgcn_readlane((int)i_vb0, 63);
+        c_vb1 += (uint32_t)__builtin_amdgcn_readlane((int)i_vb1, 63);
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            c_src[k] = __shfl(src[k], 63, 64);
+            c_src[k] = __builtin_amdgcn_readlane(src[k], 63);
     }
     if (pcm_count && lane == 0)
         pcm_count[s] = c_pcm;
 }
 
 // ---- the frame-parallel kernels ----------------------------------------------------------------------------------------------
-// (development switches: the alternatives measured in profiles/r5_sbc.md)
-#ifndef EFX_SBC_M
-#define EFX_SBC_M 1      // matrixing: a thread makes two outputs of 1 = two consecutive rows, 0 = one row per trip
-#endif
-#ifndef EFX_SBC_SKIP
-#define EFX_SBC_SKIP 0   // timing ablations (wrong PCM): 1 = no dequantisation, 2 = no matrixing of the chunk's rows, 4 = no windowing
-#endif
-#ifndef EFX_SBC_CHUNK_MONO
-#define EFX_SBC_CHUNK_MONO 16  // frames per work item of k_sbc_par_mono (8: 7 workgroups per compute unit; 16: 4, and 12 % faster)
-#endif
-#ifndef EFX_SBC_PITCH
-#define EFX_SBC_PITCH 18 // (16 = unpadded)
-#endif
-#ifndef EFX_SBC_WAVES
-#define EFX_SBC_WAVES 4  // k_sbc_par_mono: waves per SIMD the register allocation aims at (= workgroups per compute unit)
-#endif
-constexpr int kSbcChunk = 8;                 // frames per work item (k_sbc_par_mono: EFX_SBC_CHUNK_MONO)
 constexpr int kSbcStageDwords = 1024;        // 4 KB of frame bytes in LDS
 constexpr int kSbcRowPitch = EFX_SBC_PITCH;    // dwords between two rows of matrixing outputs in LDS
 constexpr uint32_t kSbcSlack = 528;          // a frame's bit fields may run past the frame size the caller states (at most 524 bytes
@@ -636,7 +713,8 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
                                              const SbcState* __restrict__ states, SbcState* __restrict__ states_next,
                                              const SbcTables* __restrict__ tables, const SbcFrameInfo* __restrict__ info,
                                              int16_t* __restrict__ pcm, size_t pcm_stride, uint32_t* __restrict__ pcm_count, int flags,
-                                             SbcQueues* __restrict__ queues, const uint32_t* __restrict__ lists, int n_streams)
+                                             SbcQueues* __restrict__ queues, const uint32_t* __restrict__ lists, int n_streams,
+                                             const SbcExtraItem* __restrict__ extra)
 {
     constexpr int PB = 8 * C;  // samples of a block
     __shared__ SbcTables tb;
@@ -653,8 +731,8 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
 
     const int tid = threadIdx.x;
     constexpr int cls = C == 1 ? kSbcMono : kSbcStereo;
-    const uint32_t count = queues->count[cls];
-    if (count == 0)
+    const uint32_t count = queues->count[cls], n_general = queues->count[kSbcGeneral];
+    if (count + n_general == 0)
         return;
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(tables);
@@ -662,27 +740,36 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
         for (int i = tid; i < (int)(sizeof(SbcTables) / 4); i += 256)
             dst[i] = src[i];
     }
-    const uint32_t chunks = (uint32_t)(n_frames + CH - 1) / CH, total = count * chunks;
+    const uint32_t chunks = (uint32_t)(n_frames + CH - 1) / CH, n_listed = count * chunks, total = n_listed + n_general * chunks;
     const uint32_t limit = (uint32_t)n_frames * (uint32_t)frame_bytes;
     const bool probe = (flags & 1) != 0;  // decode_audio()'s frame-size probe: frame 0 is decoded once more up front
 
     // Work items = (stream of the list, chunk of CH frames), dealt round robin: this workgroup's are blockIdx.x + it * gridDim.x.
     // A lane keeps the list entry and the chunk of one of the next 64 (one vector load per 64 items; readlane hands them out).
-    uint32_t my_entry = 0xFFFFFFFFu, my_chunk = 0;
+    // Behind the listed streams' items: the chunks of the GENERAL streams -- those of them that k_sbc_plan found regular
+    // (SbcExtraItem: the same work, but the PCM of the chunk's first frame sits where the plan says: my_pcm; ~0 = at f0 * the
+    // frame's samples); the others are k_sbc_gen's and skipped here.
+    uint32_t my_entry = 0xFFFFFFFFu, my_chunk = 0, my_pcm = 0xFFFFFFFFu;
     auto load_entries = [&](int it0) {
         const uint32_t item = blockIdx.x + (uint32_t)(it0 + (tid & 63)) * gridDim.x;
-        my_entry = 0xFFFFFFFFu;
-        if (item < total) {
+        my_entry = my_pcm = 0xFFFFFFFFu;
+        if (item < n_listed) {
             const uint32_t si = item / chunks;
             my_chunk = item - si * chunks;
             my_entry = lists[(size_t)cls * n_streams + si];
+        } else if (item < total) {
+            const uint32_t x = item - n_listed, gi = x / chunks;
+            const SbcExtraItem e = extra[(size_t)lists[(size_t)kSbcGeneral * n_streams + gi] * chunks + (x - gi * chunks)];
+            my_entry = e.entry;
+            my_chunk = e.chunk;
+            my_pcm = e.pcm_base;
         }
     };
     // everything about an item that is the same for all threads
     struct Item {
-        bool valid, staged;
+        bool valid, skip, staged;
         int s, blocks, f0, f1, vb0, vb1, first_vb, fr_lo, n_fr;
-        uint32_t inv_b, lo_byte, hi_byte, mis, span, n_dw, n_zero;
+        uint32_t inv_b, lo_byte, hi_byte, mis, span, n_dw, n_zero, pcm_base;
         const uint8_t* gbase;
         const SbcFrameInfo* inf;
     };
@@ -690,9 +777,12 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
         Item p;
         const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)my_entry, it & 63);
         const int chunk = __builtin_amdgcn_readlane((int)my_chunk, it & 63);
+        p.pcm_base = (uint32_t)__builtin_amdgcn_readlane((int)my_pcm, it & 63);
         p.valid = e != 0xFFFFFFFFu;
-        p.s = p.valid ? (int)(e & 0x3FFFFFFFu) : 0;
-        p.blocks = 4 * (int)(((p.valid ? e : 0u) >> 30) + 1);  // (k_sbc_plan packs the block count of the stream's frames into the entry)
+        p.skip = e == kSbcSkipEntry;
+        const bool work = p.valid && !p.skip;
+        p.s = work ? (int)(e & 0x3FFFFFFFu) : 0;
+        p.blocks = 4 * (int)(((work ? e : 0u) >> 30) + 1);  // (k_sbc_plan packs the block count of the stream's frames into the entry)
         p.inv_b = p.blocks == 4 ? 16385u : p.blocks == 8 ? 8193u : p.blocks == 12 ? 5462u : 4097u;  // x / blocks = x * inv_b >> 16 (x < 4096)
         p.gbase = frames + (size_t)p.s * stream_stride;
         p.inf = info + (size_t)p.s * n_frames;
@@ -728,7 +818,7 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
     };
     auto fetch = [&](const Item& p) -> Fetch {
         Fetch r = {};
-        if (!p.valid)
+        if (!p.valid || p.skip)
             return r;
         if (p.staged) {
             const uint32_t* a0 = reinterpret_cast<const uint32_t*>(p.gbase + p.lo_byte - p.mis);
@@ -764,6 +854,13 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
     Item cur = setup(0);
     Fetch got = fetch(cur);
     for (int it = 0; cur.valid; it++) {
+        if (cur.skip) {  // (k_sbc_gen's chunk)
+            if (((it + 1) & 63) == 0)
+                load_entries(it + 1);
+            cur = setup(it + 1);
+            got = fetch(cur);
+            continue;
+        }
         sbc_lds_barrier();  // (the LDS of the previous item is free)
         commit(cur, got);
         if (((it + 1) & 63) == 0)
@@ -941,6 +1038,7 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
         // consecutive blocks (a frame's block count is a multiple of four) out of one pass over the thirteen rows they read
         int16_t* out = pcm + (size_t)s * pcm_stride;
         const int frame_samples = C * blocks * 8;
+        const size_t pcm0 = p.pcm_base != 0xFFFFFFFFu ? (size_t)p.pcm_base : (size_t)f0 * frame_samples;  // where frame f0's PCM goes
 #if !(EFX_SBC_SKIP & 4)
         {
             const int o = tid & 7;
@@ -959,7 +1057,7 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
                     hi[j] = R[j * kSbcRowPitch + o + 8];
                 }
                 const int fl = (int)(__umul24((uint32_t)r0, inv_b) >> 16), blk = r0 - fl * blocks;
-                int16_t* op = out + (size_t)(f0 + fl) * frame_samples + c * blocks * 8 + blk * 8 + o;
+                int16_t* op = out + pcm0 + (size_t)fl * frame_samples + c * blocks * 8 + blk * 8 + o;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     uint32_t acc = 0;
@@ -979,7 +1077,7 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
         // NOT in `states`: the workgroup of the stream's first frames reads the history there, in this same launch, whenever it
         // gets to it.  The new state goes to `states_next` as a whole (what this geometry does not touch copied over) and
         // k_sbc_commit, the next kernel on the stream, puts it in place.
-        if (f1 == n_frames) {
+        if (f1 == n_frames && p.pcm_base == 0xFFFFFFFFu) {  // (a general stream's last frame is k_sbc_gen's)
             SbcState* so = states_next + s;
             const int k_last = n_frames - 1 - fr_lo;
             for (int i = tid; i < 256; i += 256) {
@@ -1016,20 +1114,20 @@ __global__ __launch_bounds__(256, EFX_SBC_WAVES) void k_sbc_par_mono(const uint8
                                                       const SbcTables* __restrict__ tables, const SbcFrameInfo* __restrict__ info,
                                                       int16_t* __restrict__ pcm, size_t pcm_stride, uint32_t* __restrict__ pcm_count,
                                                       int flags, SbcQueues* __restrict__ queues, const uint32_t* __restrict__ lists,
-                                                      int n_streams)
+                                                      int n_streams, const SbcExtraItem* __restrict__ extra, int extra_cap)
 {
     sbc_par_body<1, EFX_SBC_CHUNK_MONO>(frames, stream_stride, frame_bytes, n_frames, states, states_next, tables, info, pcm, pcm_stride, pcm_count, flags,
-                    queues, lists, n_streams);
+                    queues, lists, n_streams, extra + (size_t)kSbcMono * extra_cap);
 }
 __global__ __launch_bounds__(256) void k_sbc_par_stereo(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
                                                         int n_frames, const SbcState* __restrict__ states,
                                                         SbcState* __restrict__ states_next, const SbcTables* __restrict__ tables,
                                                         const SbcFrameInfo* __restrict__ info, int16_t* __restrict__ pcm,
                                                         size_t pcm_stride, uint32_t* __restrict__ pcm_count, int flags,
-                                                        SbcQueues* __restrict__ queues, const uint32_t* __restrict__ lists, int n_streams)
+                                                        SbcQueues* __restrict__ queues, const uint32_t* __restrict__ lists, int n_streams, const SbcExtraItem* __restrict__ extra, int extra_cap)
 {
     sbc_par_body<2, kSbcChunk>(frames, stream_stride, frame_bytes, n_frames, states, states_next, tables, info, pcm, pcm_stride, pcm_count, flags,
-                    queues, lists, n_streams);
+                    queues, lists, n_streams, extra + (size_t)kSbcStereo * extra_cap);
 }
 
 // ---- general streams -------------------------------------------------------------------------------------------------------------
@@ -1046,7 +1144,7 @@ __global__ __launch_bounds__(256) void k_sbc_gen(const uint8_t* __restrict__ fra
                                                  const SbcTables* __restrict__ tables, const SbcFrameInfo* __restrict__ info,
                                                  const SbcFramePlan* __restrict__ plan, int16_t* __restrict__ pcm, size_t pcm_stride,
                                                  int flags, SbcQueues* __restrict__ queues, const uint32_t* __restrict__ lists,
-                                                 int n_streams)
+                                                 int n_streams, const uint8_t* __restrict__ cover, int cover_stride)
 {
     __shared__ SbcTables tb;
     __shared__ int32_t sb[kSbcSlots][16][2][8];       // the sb_sample array as it stood after each slot's get_samples()
@@ -1073,8 +1171,8 @@ __global__ __launch_bounds__(256) void k_sbc_gen(const uint8_t* __restrict__ fra
     int s, chunk;
     for (int it = 0; sbc_next_item(queues, lists, kSbcGeneral, n_streams, chunks, it, &s, &chunk); it++) {
         const int v0 = chunk * kSbcChunk, v1 = min(F, v0 + kSbcChunk);
-        if (v0 >= F)
-            continue;
+        if (v0 >= F || (chunk < cover_stride && cover[(size_t)s * cover_stride + chunk]))
+            continue;  // (nothing there, or a regular kernel's: k_sbc_plan)
         const uint8_t* gbase = frames + (size_t)s * stream_stride;
         const SbcFrameInfo* inf = info + (size_t)s * n_frames;
         const SbcFramePlan* pl = plan + (size_t)s * (n_frames + 1);
