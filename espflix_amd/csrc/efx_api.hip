@@ -738,7 +738,7 @@ static int ensure_ts_buffers(efx_ctx* ctx)
     ctx->pes_cap = ctx->es_cap / 188 + n_max;
     hipError_t e = dalloc(&ctx->d_ts, ctx->es_cap);
     if (e == hipSuccess)
-        e = dev_alloc(reinterpret_cast<void**>(&ctx->d_demux_chunks), (ctx->pes_cap / 128 + n_max + 2) * 16);
+        e = dev_alloc(reinterpret_cast<void**>(&ctx->d_demux_chunks), (ctx->pes_cap / kDemuxChunk + n_max + 2) * 16);
     for (auto& u : ctx->up) {
         if (e == hipSuccess) e = dalloc(&u.d_ts_len, n_max);
         if (e == hipSuccess) e = dalloc(&u.d_pkt_base, n_max);
@@ -926,12 +926,12 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
             size_t max_len = 0;
             for (int i = 0; i < n_streams; i++)
                 max_len = std::max(max_len, len[i]);
-            const unsigned chunks = (unsigned)std::max<size_t>(1, (max_len / 188 + 127) / 128);
-            hipLaunchKernelGGL(k_demux_scan, dim3(chunks, n_streams), dim3(256), 0, st, ctx->d_ts, u.d_stream_off, u.d_ts_len, u.d_pkt_base,
+            const unsigned chunks = (unsigned)std::max<size_t>(1, (max_len / 188 + kDemuxChunk - 1) / kDemuxChunk);
+            hipLaunchKernelGGL(k_demux_scan, dim3(chunks, n_streams), dim3(kDemuxThreads), 0, st, ctx->d_ts, u.d_stream_off, u.d_ts_len, u.d_pkt_base,
                                ctx->d_demux_chunks);
             hipLaunchKernelGGL(k_demux_offsets, dim3(n_streams), dim3(64), 0, st, u.d_ts_len, u.d_pkt_base, ctx->d_demux_chunks, u.d_es,
                                u.d_stream_off, u.d_es_len, u.d_pes_count);
-            hipLaunchKernelGGL(k_demux, dim3(chunks, n_streams), dim3(256), 0, st, ctx->d_ts, u.d_stream_off, u.d_ts_len, u.d_pkt_base,
+            hipLaunchKernelGGL(k_demux, dim3(chunks, n_streams), dim3(kDemuxThreads), 0, st, ctx->d_ts, u.d_stream_off, u.d_ts_len, u.d_pkt_base,
                                ctx->d_demux_chunks, u.d_es, u.d_pes);
         }
         if (ctx->timing) {
@@ -1657,12 +1657,12 @@ int efx_demux_audio(efx_ctx* ctx, int n_streams, const uint8_t* const* ts, const
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_idx_len, tlen.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_idx_base, pbase.data(), n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        const unsigned chunks = (unsigned)std::max<size_t>(1, (max_len / 188 + 127) / 128);
-        hipLaunchKernelGGL(k_demux_audio_scan, dim3(chunks, n_streams), dim3(256), 0, st, ctx->d_ts, ctx->d_ts_off, ctx->d_idx_len, ctx->d_idx_base,
+        const unsigned chunks = (unsigned)std::max<size_t>(1, (max_len / 188 + kDemuxChunk - 1) / kDemuxChunk);
+        hipLaunchKernelGGL(k_demux_audio_scan, dim3(chunks, n_streams), dim3(kDemuxThreads), 0, st, ctx->d_ts, ctx->d_ts_off, ctx->d_idx_len, ctx->d_idx_base,
                            ctx->d_demux_chunks);
         hipLaunchKernelGGL(k_demux_audio_offsets, dim3(n_streams), dim3(64), 0, st, ctx->d_idx_len, ctx->d_idx_base, ctx->d_demux_chunks,
                            audio_len_device);
-        hipLaunchKernelGGL(k_demux_audio, dim3(chunks, n_streams), dim3(256), 0, st, ctx->d_ts, ctx->d_ts_off, ctx->d_idx_len, ctx->d_idx_base,
+        hipLaunchKernelGGL(k_demux_audio, dim3(chunks, n_streams), dim3(kDemuxThreads), 0, st, ctx->d_ts, ctx->d_ts_off, ctx->d_idx_len, ctx->d_idx_base,
                            ctx->d_demux_chunks, audio_device, d_out_off);
         e = hipGetLastError();
     }

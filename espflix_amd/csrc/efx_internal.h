@@ -148,6 +148,19 @@ struct FieldArgs {
     int overlay_progress;
 };
 
+// Packets of a transport stream a k_demux workgroup takes, and its threads (k_demux.hip); a multiple of four packets: 4 x 188
+// bytes = 47 x 16.  16 packets x one wave: the benchmark's 253-packet streams as 16 k small workgroups instead of 2 k of 128
+// packets x 256 threads, whose few long phases left the chip waiting (gather 81 -> 42 us; profiles/r5_demux.md).
+#ifndef EFX_DEMUX_CHUNK
+#define EFX_DEMUX_CHUNK 16
+#endif
+constexpr int kDemuxChunk = EFX_DEMUX_CHUNK;
+#ifndef EFX_DEMUX_THREADS
+#define EFX_DEMUX_THREADS 64
+#endif
+constexpr int kDemuxThreads = EFX_DEMUX_THREADS;
+static_assert(kDemuxChunk % 4 == 0 && kDemuxChunk >= 4 && kDemuxChunk <= 256, "k_demux stages whole 16-byte groups");
+
 // SBC synthesis tables (sbc_decoder.cpp:41-71), generated from the A2DP definitions
 struct SbcTables {
     int32_t syn[128];   // syn[i * 8 + k] = floor(65536 cos((i + 4)(2k + 1) pi / 16))

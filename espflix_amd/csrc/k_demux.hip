@@ -26,27 +26,52 @@ namespace efx {
 
 namespace {
 
-constexpr int kChunk = 128;  // packets per workgroup iteration
+constexpr int kChunk = kDemuxChunk;  // packets per workgroup
 constexpr int kTsPacket = 188;
-constexpr int kThreads = 256;
+constexpr int kThreads = kDemuxThreads;
+constexpr int kSearchSteps = kChunk > 128 ? 8 : kChunk > 64 ? 7 : kChunk > 32 ? 6 : kChunk > 16 ? 5 : kChunk > 8 ? 4 : 3;
+constexpr bool kTwoWaves = kThreads >= 128;  // (a chunk's packets live in the first two waves, or the one there is)
+static_assert((1 << kSearchSteps) >= kChunk && kThreads >= 64 && kThreads >= kChunk && kThreads % 64 == 0, "one thread per packet, a binary search over the chunk");
 
+// Wave-wide inclusive scans as six DPP steps (row_shr 1, 2, 4, 8 inside the rows of sixteen lanes, row_bcast 15 and 31 carry
+// the rows' totals on; gfx9) -- a __shfl_up() step is a ds_bpermute round trip.
+template <int kCtrl, int kRowMask>
+__device__ inline uint32_t demux_dpp(uint32_t identity, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, kCtrl, kRowMask, 0xF, false);
+}
 __device__ inline uint32_t wave_incl_scan(uint32_t v)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(v, d, 64);
-        if (lane >= d)
-            v += o;
-    }
+    v += demux_dpp<0x111, 0xF>(0, v);
+    v += demux_dpp<0x112, 0xF>(0, v);
+    v += demux_dpp<0x114, 0xF>(0, v);
+    v += demux_dpp<0x118, 0xF>(0, v);
+    v += demux_dpp<0x142, 0xA>(0, v);
+    v += demux_dpp<0x143, 0xC>(0, v);
     return v;
+}
+__device__ inline uint32_t wave_incl_max(uint32_t v)
+{
+    v = max(v, demux_dpp<0x111, 0xF>(0, v));
+    v = max(v, demux_dpp<0x112, 0xF>(0, v));
+    v = max(v, demux_dpp<0x114, 0xF>(0, v));
+    v = max(v, demux_dpp<0x118, 0xF>(0, v));
+    v = max(v, demux_dpp<0x142, 0xA>(0, v));
+    v = max(v, demux_dpp<0x143, 0xC>(0, v));
+    return v;
+}
+// the last value that is not zero among lanes 0 .. this one (values < 4; 0 if none): a maximum over lane << 2 | value
+__device__ inline uint32_t wave_last_defined(uint32_t v)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    return wave_incl_max(v ? (lane << 2 | v) : 0u) & 3;
 }
 
 }  // namespace
 
 // One chunk of kChunk packets is the unit of work; a stream is as many chunks as it needs and ALL chunks of ALL streams run side
 // by side (round 5: a workgroup that walked its stream's chunks one after the other was two dependent 128-packet iterations
-// long for the benchmark's streams, 0.11 of the HBM roofline).  What chains from packet to packet in the reference -- the ES
+// long for the benchmark's streams, 0.11 of the HBM roofline; chunks of 16 packets on one wave each: 0.18 -- kDemuxChunk).  What chains from packet to packet in the reference -- the ES
 // position, the PES list position, the audio gate -- is a prefix over chunk totals:
 //   k_demux_scan     grid (chunks, streams): one thread per packet reads the few header bytes it needs straight from global
 //                    memory -> payload bytes, PES-with-PTS count, last audio gate value of the chunk
@@ -54,7 +79,7 @@ __device__ inline uint32_t wave_incl_scan(uint32_t v)
 //                    end-of-data tail + zero fill behind the ES (video)
 //   k_demux_gather   grid (chunks, streams): the chunk staged in LDS, parsed again, local prefix + the chunk's base, and the
 //                    output-centric 16-byte gather
-// Chunk records of stream s start at chunk_slot(pkt_base[s], s): a stream of n packets has at most n / 128 + 1 chunks.
+// Chunk records of stream s start at chunk_slot(pkt_base[s], s): a stream of n packets has at most n / kChunk + 1 chunks.
 struct DemuxChunk {
     uint32_t bytes;  // scan: payload bytes of the chunk; after k_demux_offsets: ES position of its first payload byte
     uint32_t n_pes;  // ... PES headers with a PTS; after: position in the stream's PES list
@@ -119,19 +144,14 @@ __device__ __forceinline__ uint32_t gate_scan(uint32_t gate, uint32_t carry, uin
 {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (wave < 2) {
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(gate, d, 64);
-            if (lane >= d && gate == 0)
-                gate = o;
-        }
+        gate = wave_last_defined(gate);
         if (lane == 63)
             sh_gate[wave] = gate;
     }
     __syncthreads();
     if (wave == 1 && gate == 0)
         gate = sh_gate[0];
-    *last = sh_gate[1] ? sh_gate[1] : sh_gate[0];
+    *last = (kTwoWaves && sh_gate[1]) ? sh_gate[1] : sh_gate[0];
     if (gate == 0)
         gate = carry;
     __syncthreads();
@@ -174,10 +194,10 @@ __device__ __forceinline__ void demux_scan_body(const uint8_t* __restrict__ ts, 
         __syncthreads();
         if (tid == 0) {
             DemuxChunk c;
-            c.bytes = sh_wave[0][0] + sh_wave[0][1];
+            c.bytes = sh_wave[0][0] + (kTwoWaves ? sh_wave[0][1] : 0u);
             c.n_pes = 0;
             c.gate = last;
-            c.pad = sh_wave[1][0] + sh_wave[1][1];
+            c.pad = sh_wave[1][0] + (kTwoWaves ? sh_wave[1][1] : 0u);
             chunks[chunk_slot(pkt_base[s], s) + blockIdx.x] = c;
         }
         return;
@@ -190,8 +210,8 @@ __device__ __forceinline__ void demux_scan_body(const uint8_t* __restrict__ ts, 
     __syncthreads();
     if (tid == 0) {
         DemuxChunk c;
-        c.bytes = sh_wave[0][0] + sh_wave[0][1];
-        c.n_pes = sh_wave[1][0] + sh_wave[1][1];
+        c.bytes = sh_wave[0][0] + (kTwoWaves ? sh_wave[0][1] : 0u);
+        c.n_pes = sh_wave[1][0] + (kTwoWaves ? sh_wave[1][1] : 0u);
         c.gate = 0;
         c.pad = 0;
         chunks[chunk_slot(pkt_base[s], s) + blockIdx.x] = c;
@@ -215,15 +235,8 @@ __device__ __forceinline__ void demux_offsets_body(const uint32_t* __restrict__ 
         if (have)
             c = my[c0 + lane];
         // the gate at the start of each chunk: last defined value of the chunks before it (carried in), a wave scan
-        uint32_t g_before = __shfl_up(c.gate, 1, 64);
-        if (lane == 0)
-            g_before = 0;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(g_before, d, 64);
-            if (lane >= d && g_before == 0)
-                g_before = o;
-        }
+        const uint32_t g_upto = wave_last_defined(c.gate);
+        const uint32_t g_before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g_upto, 0x138, 0xF, 0xF, false);  // wave_shr 1
         const uint32_t g_in = g_before ? g_before : gate;
         const uint32_t bytes = c.bytes + (AUDIO && g_in == 2 ? c.pad : 0u);
         const uint32_t ib = wave_incl_scan(bytes), ip = wave_incl_scan(c.n_pes);
@@ -235,17 +248,10 @@ __device__ __forceinline__ void demux_offsets_body(const uint32_t* __restrict__ 
             o.pad = 0;
             my[c0 + lane] = o;
         }
-        es_pos += __shfl(ib, 63, 64);
-        n_pes += __shfl(ip, 63, 64);
+        es_pos += (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
+        n_pes += (uint32_t)__builtin_amdgcn_readlane((int)ip, 63);
         // the gate after this round: the last defined value among its chunks, else unchanged
-        uint32_t g_last = c.gate;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(g_last, d, 64);
-            if (lane >= d && g_last == 0)
-                g_last = o;
-        }
-        const uint32_t tail_gate = __shfl(g_last, 63, 64);
+        const uint32_t tail_gate = (uint32_t)__builtin_amdgcn_readlane((int)g_upto, 63);
         gate = tail_gate ? tail_gate : gate;
     }
     if (lane == 0) {
@@ -306,7 +312,7 @@ __device__ __forceinline__ void demux_gather_body(const uint8_t* __restrict__ ts
     const uint32_t npk = min((uint32_t)kChunk, n_packets - first);
     // ---- 1. stage the chunk --------------------------------------------------------------
     {
-        const uint4* g = reinterpret_cast<const uint4*>(src + (size_t)first * kTsPacket);  // 128 * 188 = 16 * 1504
+        const uint4* g = reinterpret_cast<const uint4*>(src + (size_t)first * kTsPacket);  // (kChunk * 188 is a multiple of 16)
         const uint32_t n16 = (npk * kTsPacket + 15) / 16;  // may read <= 15 bytes past the packets: inside the buffer
         for (uint32_t i = tid; i < n16; i += kThreads)
             sh_pkt4[i] = g[i];
@@ -340,12 +346,14 @@ __device__ __forceinline__ void demux_gather_body(const uint8_t* __restrict__ ts
         }
     }
     __syncthreads();
-    const uint32_t total = sh_wave[0][0] + sh_wave[0][1];
+    const uint32_t total = sh_wave[0][0] + (kTwoWaves ? sh_wave[0][1] : 0u);
     if (wave < 2) {
         const uint32_t excl_n = incl_n - n + (wave ? sh_wave[0][0] : 0);
         const uint32_t excl_f = incl_f - has_pts + (wave ? sh_wave[1][0] : 0);
-        sh_prefix[tid] = (uint32_t)tid < npk ? excl_n : total;
-        sh_src[tid] = from;
+        if (tid < kChunk) {
+            sh_prefix[tid] = (uint32_t)tid < npk ? excl_n : total;
+            sh_src[tid] = from;
+        }
         if (!AUDIO && has_pts) {
             PesEntry e;
             e.es_off = es_pos + excl_n;
@@ -370,7 +378,7 @@ __device__ __forceinline__ void demux_gather_body(const uint8_t* __restrict__ ts
         uint32_t rel = first_o - lo;
         int a = 0, b = kChunk;  // invariant: prefix[a] <= rel < prefix[b]
 #pragma unroll
-        for (int it = 0; it < 7; it++) {
+        for (int it = 0; it < kSearchSteps; it++) {
             int m = (a + b) >> 1;
             if (sh_prefix[m] <= rel)
                 a = m;
