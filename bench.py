@@ -68,12 +68,13 @@ def log(msg):
 
 
 def kernel_sources_digest() -> str:
-    """SHA-1 over the kernel sources (espflix_amd/csrc): what a PMC summary was measured on, and what this run executes."""
+    """SHA-1 over the kernel sources (espflix_amd/csrc: the k_*.hip files, the headers and the table builder -- not the host
+    side, efx_api.hip / efx_multi.cpp): what a PMC summary was measured on, and what this run executes."""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(ROOT, "espflix_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".cpp")):
+        if (name.startswith("k_") and name.endswith(".hip")) or name.endswith(".h") or name == "efx_tables.cpp":
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:12]

@@ -226,6 +226,7 @@ struct efx_ctx {
     SbcExtraItem* d_sbc_extra = nullptr; // two lists of (stream, granule of eight frames) capacity each
     uint8_t* d_sbc_cover = nullptr;      // per (stream, granule): a regular kernel decodes it
     size_t sbc_info_cap = 0;             // in frames: streams x (frames + 1)
+    size_t sbc_gran_cap = 0;             // in granules: streams x ceil(frames / 8)
     int opt_sbc_serial = 0;              // 1 = every stream through k_sbc, one wave per stream (the tests' comparison)
     bool sbc_flags_clean = false;        // d_sbc_flags[0, n) all kSbcRegularFlag (k_sbc_finish leaves them so)
     uint64_t* d_hash = nullptr;
@@ -1867,22 +1868,27 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
             (void)dev_free(ctx->d_sbc_info);
         if (ctx->d_sbc_plan)
             (void)dev_free(ctx->d_sbc_plan);
+        ctx->d_sbc_info = nullptr;
+        ctx->d_sbc_plan = nullptr;
+        ctx->sbc_info_cap = 0;
+        EFX_HIP(dalloc(&ctx->d_sbc_info, info_need));
+        EFX_HIP(dalloc(&ctx->d_sbc_plan, info_need));
+        ctx->sbc_info_cap = info_need;
+    }
+    // per (stream, granule of eight frames): a slot in each of the two tables of chunks a regular kernel takes, a cover byte
+    const int n_gran = (n_frames + 7) / 8, extra_cap = n_streams * n_gran;
+    if ((size_t)extra_cap > ctx->sbc_gran_cap) {
         if (ctx->d_sbc_extra)
             (void)dev_free(ctx->d_sbc_extra);
         if (ctx->d_sbc_cover)
             (void)dev_free(ctx->d_sbc_cover);
-        ctx->d_sbc_info = nullptr;
-        ctx->d_sbc_plan = nullptr;
         ctx->d_sbc_extra = nullptr;
         ctx->d_sbc_cover = nullptr;
-        ctx->sbc_info_cap = 0;
-        EFX_HIP(dalloc(&ctx->d_sbc_info, info_need));
-        EFX_HIP(dalloc(&ctx->d_sbc_plan, info_need));
-        EFX_HIP(dalloc(&ctx->d_sbc_extra, info_need / 4 + 2));  // (2 lists x streams x ceil(frames / 8) <= streams x (frames + 1) / 4 + 2)
-        EFX_HIP(dalloc(&ctx->d_sbc_cover, info_need));
-        ctx->sbc_info_cap = info_need;
+        ctx->sbc_gran_cap = 0;
+        EFX_HIP(dalloc(&ctx->d_sbc_extra, 2 * (size_t)extra_cap));
+        EFX_HIP(dalloc(&ctx->d_sbc_cover, (size_t)extra_cap));
+        ctx->sbc_gran_cap = (size_t)extra_cap;
     }
-    const int n_gran = (n_frames + 7) / 8, extra_cap = n_streams * n_gran;
     uint32_t* const d_how = ctx->d_sbc_flags;
     uint32_t* const d_lists = d_how + ctx->sbc_flags_cap;
     SbcQueues* const d_queues = reinterpret_cast<SbcQueues*>(d_how + 4 * ctx->sbc_flags_cap);

@@ -240,6 +240,46 @@ def test_frame_that_runs_past_the_stated_frame_size(efx):
     dec.close()
 
 
+_GUARD_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import common, espflix_amd as efx
+efx.load_library()
+for n_streams, frames in ((48, 45), (7, 33), (130, 9), (3, 375)):
+    kw = dict(freq=3, blocks=16, mode=0, alloc=0, bitpool=28)
+    fb = common.sbc_frame_bytes(16, 1, 28)
+    rng = np.random.default_rng(n_streams)
+    streams = [common.sbc_frames(50 + i, frames, **kw) for i in range(n_streams)]
+    streams = [common.sbc_mutate(rng, s, fb, frames, hits=2) if i % 2 else s for i, s in enumerate(streams)]
+    dec = efx.Decoder(1, 1, 2)
+    d_fr, d_st = dec.alloc(n_streams * frames * fb), dec.alloc(n_streams * efx.sbc_state_bytes())
+    d_pcm, d_ret, d_cnt = dec.alloc(n_streams * frames * 256 * 2), dec.alloc(n_streams * frames * 4), dec.alloc(n_streams * 4)
+    d_fr.upload(np.concatenate(streams))
+    d_st.upload(np.zeros(n_streams * efx.sbc_state_bytes(), dtype=np.uint8))
+    for probe in (False, True):
+        dec.sbc_decode(n_streams, d_fr, frames * fb, fb, frames, d_st, d_pcm, frames * 256, d_ret, d_cnt, probe_first=probe)
+        dec.sync()
+    dec.close()
+print("GUARD_OK")
+"""
+
+
+@pytest.mark.parametrize("guard", ["1", "2"])
+def test_every_buffer_of_a_call_under_the_guard_page_allocator(guard):
+    """EFX_GUARD: every device buffer is its own mapping that ends (1) or starts (2) on an unmapped page -- a kernel that
+    reads or writes one element past a buffer faults.  Stream and frame counts whose products do not divide evenly: the
+    tables of (stream, granule) slots were once sized from streams x (frames + 1) / 4 and overran by a few entries at 48 x
+    45, which only this allocator noticed.  The frame buffer ends with the last frame's last byte (no slack): the
+    frame-parallel kernels read whole aligned dwords and the bit fields of a frame that runs past the frame size."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EFX_GUARD=guard)
+    r = subprocess.run([sys.executable, "-c", _GUARD_CHILD, root], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "GUARD_OK" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-1500:])
+
+
 def test_state_no_call_leaves_goes_to_the_serial_kernel(efx):
     """A decoder state with a block count that is no multiple of four (no header leaves one) and frames that are synthesised
     under it -- bad sync bytes up front -- would put 5 rows per frame on a timeline: k_sbc_plan hands such a stream to the one
