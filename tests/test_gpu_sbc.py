@@ -280,6 +280,34 @@ def test_every_buffer_of_a_call_under_the_guard_page_allocator(guard):
     assert r.returncode == 0 and "GUARD_OK" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-1500:])
 
 
+@pytest.mark.parametrize("case", [5, 6], ids=["mono_bp128", "dual_bp128"])
+def test_frames_too_fat_for_the_stage(efx, case):
+    """The frame-parallel kernels copy the frame bytes a work item reaches into 4 KB of LDS; 264-byte mono frames x 17 or
+    524-byte dual-channel frames x 9 do not fit, and the bit fields are read from global memory instead -- over several
+    chunks (the frames before a chunk that hold its nine blocks of filter memory included), clean and with rejected frames,
+    the probe on and off."""
+    name, kw, _, _ = common.SBC_CASES[case]
+    ch = 1 if kw["mode"] == 0 else 2
+    fb = common.sbc_frame_bytes(kw["blocks"], ch, kw["bitpool"])
+    frames = 41
+    rng = np.random.default_rng(case)
+    streams = [common.sbc_frames(8100 + i, frames, **kw) for i in range(6)]
+    for i in (1, 3, 5):
+        streams[i] = common.sbc_mutate(rng, streams[i], fb, frames, hits=2)
+    dec = efx.Decoder(1, 1, 2)
+    for probe in (False, True):
+        got, rets, states = _decode_batch(efx, dec, streams, fb, frames, probe, 1, serial=False)
+        ser, sret, sstates = _decode_batch(efx, dec, streams, fb, frames, probe, 1, serial=True)
+        for i, fr in enumerate(streams):
+            want, wret = oracle.sbc_decode(fr, fb, probe)
+            if probe:
+                want, wret = want[wret[0][1] // 2:], wret[1:]
+            assert rets[i] == wret == sret[i], (name, probe, i)
+            assert np.array_equal(got[i], want) and np.array_equal(ser[i], want), (name, probe, i)
+            assert np.array_equal(states[i], sstates[i]), (name, probe, i)
+    dec.close()
+
+
 def test_state_no_call_leaves_goes_to_the_serial_kernel(efx):
     """A decoder state with a block count that is no multiple of four (no header leaves one) and frames that are synthesised
     under it -- bad sync bytes up front -- would put 5 rows per frame on a timeline: k_sbc_plan hands such a stream to the one
