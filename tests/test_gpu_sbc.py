@@ -308,6 +308,35 @@ def test_frames_too_fat_for_the_stage(efx, case):
     dec.close()
 
 
+@pytest.mark.parametrize("n_streams,frames,fb_override", [(3000, 3, None), (1, 1, None), (5, 10, 3), (2, 130, None), (257, 17, None)])
+def test_odd_batch_shapes(efx, n_streams, frames, fb_override):
+    """Many streams of a few frames (the work lists are longer than one pass of the classifier, a chunk is the whole call), one
+    frame, frames too short to hold a header (every one rejected: nothing is synthesised under a zero state), streams of more
+    frames than a wave has lanes (the plan's carries from tile to tile): every other stream damaged, the frame-parallel
+    kernels against the one-wave kernel -- PCM, return values, decoder states."""
+    kw = dict(freq=3, blocks=16, mode=0, alloc=0, bitpool=28)
+    fb = common.sbc_frame_bytes(16, 1, 28)
+    rng = np.random.default_rng(n_streams * 1000 + frames)
+    base = [common.sbc_frames(9000 + i, frames, **kw) for i in range(min(n_streams, 16))]
+    streams = []
+    for i in range(n_streams):
+        st = base[i % len(base)]
+        if i % 2 and frames > 1:
+            st = common.sbc_mutate(rng, st, fb, frames, hits=1 + i % 3)
+        streams.append(st)
+    if fb_override:
+        streams = [st[:frames * fb_override].copy() for st in streams]
+        fb = fb_override
+    dec = efx.Decoder(1, 1, 2)
+    for probe in (False, True):
+        got, rets, states = _decode_batch(efx, dec, streams, fb, frames, probe, 1, serial=False)
+        ser, sret, sstates = _decode_batch(efx, dec, streams, fb, frames, probe, 1, serial=True)
+        assert rets == sret
+        assert all(np.array_equal(a, b) for a, b in zip(got, ser))
+        assert np.array_equal(states, sstates)
+    dec.close()
+
+
 def test_state_no_call_leaves_goes_to_the_serial_kernel(efx):
     """A decoder state with a block count that is no multiple of four (no header leaves one) and frames that are synthesised
     under it -- bad sync bytes up front -- would put 5 rows per frame on a timeline: k_sbc_plan hands such a stream to the one

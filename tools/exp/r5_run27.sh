@@ -1,4 +1,4 @@
 #!/bin/bash
-# round 5, run 27: SBC tests with the unstaged (fat frames) cases
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r5t27
-timeout 600 python -m pytest tests/test_gpu_sbc.py -x -q > gpurun_out/r5t27/sbc.log 2>&1; echo "sbc tests rc=$?"; tail -12 gpurun_out/r5t27/sbc.log | cut -c1-600
+# round 5, run 27+: SBC tests
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r5t28
+timeout 600 python -m pytest tests/test_gpu_sbc.py -x -q > gpurun_out/r5t28/sbc.log 2>&1; echo "sbc tests rc=$?"; tail -12 gpurun_out/r5t28/sbc.log | cut -c1-600
