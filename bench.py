@@ -67,17 +67,39 @@ def log(msg):
     sys.stderr.flush()
 
 
+def _kernel_source_files():
+    """The kernel sources proper (espflix_amd/csrc: the k_*.hip files, the headers and the table builder -- not the host side,
+    efx_api.hip / efx_multi.cpp)."""
+    d = os.path.join(ROOT, "espflix_amd", "csrc")
+    return [(n, os.path.join(d, n)) for n in sorted(os.listdir(d))
+            if (n.startswith("k_") and n.endswith(".hip")) or n.endswith(".h") or n == "efx_tables.cpp"]
+
+
+def kernel_source_digests() -> dict:
+    """SHA-1 per kernel source file: what a PMC summary was measured on (tools/summarize_profiles.py), and what this run
+    executes."""
+    import hashlib
+    out = {}
+    for name, path in _kernel_source_files():
+        with open(path, "rb") as f:
+            out[name] = hashlib.sha1(f.read()).hexdigest()[:12]
+    return out
+
+
 def kernel_sources_digest() -> str:
-    """SHA-1 over the kernel sources (espflix_amd/csrc: the k_*.hip files, the headers and the table builder -- not the host
-    side, efx_api.hip / efx_multi.cpp): what a PMC summary was measured on, and what this run executes."""
+    """One SHA-1 over all of them."""
     import hashlib
     h = hashlib.sha1()
-    d = os.path.join(ROOT, "espflix_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if (name.startswith("k_") and name.endswith(".hip")) or name.endswith(".h") or name == "efx_tables.cpp":
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
+    for name, path in _kernel_source_files():
+        with open(path, "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:12]
+
+
+# the file a kernel of the summaries lives in (beside the headers and the tables, which every kernel includes)
+_KERNEL_FILE = {"k_recon": "k_recon.hip", "k_recon_all": "k_recon.hip", "k_parse": "k_parse.hip", "k_composite": "k_video.hip",
+                "k_pdm": "k_video.hip", "k_demux": "k_demux.hip", "k_sbc": "k_sbc.hip", "k_index": "k_index.hip",
+                "k_slice_scan": "k_index.hip", "k_slice_emit": "k_index.hip", "k_advance": "k_index.hip"}
 
 
 def pmc_traffic(kernel, S, P, key="kernels"):
@@ -85,8 +107,8 @@ def pmc_traffic(kernel, S, P, key="kernels"):
     (FETCH_SIZE and WRITE_SIZE, separate runs, gfx950 correction applied by
     tools/summarize_profiles.py).  PMC counters cannot be collected from inside this process, so
     the figure is the one measured on this exact workload (1024 streams x GOP 12), None otherwise.
-    The summary records the digest of the kernel sources it was measured on (tools/collect_profiles.sh); when the
-    sources have changed since, the provenance says so and a warning goes to stderr."""
+    The summary records a digest per kernel source file it was measured on; when the kernel's own file, a header or the
+    table builder has changed since, the provenance says so and a warning goes to stderr."""
     for name in ("r5_pmc_summary.json", "r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if (S, P) != (1024, 12) or not os.path.exists(path):
@@ -96,12 +118,19 @@ def pmc_traffic(kernel, S, P, key="kernels"):
         v = doc.get(key, {}).get(kernel, {}).get("hbm_traffic_bytes")
         if v is None:
             continue
-        measured_on, now = doc.get("kernel_sources_digest"), kernel_sources_digest()
-        stale = measured_on != now
-        if stale:
-            log(f"warning: {name} was measured on kernel sources {measured_on}, this run executes {now}: roofline.traffic of "
-                f"{kernel} may be out of date (re-run tools/collect_profiles.sh)")
-        return v, {"file": "profiles/" + name, "kernel_sources_digest": measured_on, "this_run": now, "stale": stale,
+        base = kernel.split("::")[-1].split(":")[0]
+        own = next((f for k, f in sorted(_KERNEL_FILE.items(), key=lambda kv: -len(kv[0])) if base.startswith(k)), None)
+        then, now = doc.get("kernel_source_files"), kernel_source_digests()
+        if then is not None:
+            moved = [f for f in now if (f == own or not f.endswith(".hip")) and then.get(f) != now[f]]
+            measured_on, this_run = {f: then.get(f) for f in moved}, {f: now[f] for f in moved}
+        else:  # (summaries of earlier rounds: one digest over everything)
+            measured_on, this_run = doc.get("kernel_sources_digest"), kernel_sources_digest()
+            moved = [] if measured_on == this_run else ["(all kernel sources)"]
+        if moved:
+            log(f"warning: {name} was measured before {', '.join(moved)} changed: roofline.traffic of {kernel} may be out of date "
+                f"(re-run tools/collect_profiles.sh)")
+        return v, {"file": "profiles/" + name, "stale": bool(moved), "changed_since": moved, "measured_on": measured_on, "this_run": this_run,
                    "note": "separate rocprofv3 --pmc passes of this command, not this run"}
     return None, None
 

@@ -6,18 +6,21 @@
 // decoded in order, the synthesis filter memory carrying over from frame to frame.
 //
 // FRAME-PARALLEL.  The synthesis filter is an FIR: the matrixing outputs of a block depend on that block's samples only, a
-// PCM sample on the last ten blocks' outputs -- a workgroup takes eight consecutive frames, dequantises them and the frames
-// that hold the nine blocks before them, matrixes, windows.  The kernels of an efx_sbc_decode call:
+// PCM sample on the last ten blocks' outputs -- a workgroup takes a chunk of consecutive frames, dequantises them and the
+// frames that hold the nine blocks before them, matrixes, windows.  The kernels of an efx_sbc_decode call:
 //   k_sbc_frames   one thread per frame: the header's verdict and the bit allocation (SbcFrameInfo) -- the one long serial
 //                  piece of a frame, with every lane of its waves busy;
-//   k_sbc_plan     one wave per stream: sorts the stream onto a work list -- REGULAR (every frame decodes, one geometry; mono /
-//                  stereo) or GENERAL -- and, for a general stream, resolves what the reference chains from frame to frame (a
-//                  rejected frame re-synthesises the samples and the geometry the state holds: sbc_decoder.cpp:346-373) into
-//                  prefix scans over the frames (SbcFramePlan);
-//   k_sbc_par_*    persistent workgroups that pull (stream, chunk of eight frames) items of the regular lists;
-//   k_sbc_gen      the same for the general list, every index looked up in the plan instead of computed in closed form;
-//   k_sbc_commit   puts the new decoder states in place (the last chunk of a stream must not overwrite the state its first
-//                  chunk may still be reading).
+//   k_sbc_plan     its last workgroup sorts the streams onto the work lists -- REGULAR (every frame decodes, one geometry;
+//                  mono / stereo) or GENERAL; one wave per general stream resolves what the reference chains from frame to
+//                  frame (a rejected frame is synthesised from the samples and under the geometry the state holds:
+//                  sbc_decoder.cpp:346-373) into prefix scans over the frames (SbcFramePlan), and finds the granules of eight
+//                  frames that are regular again (SbcExtraItem slots, cover bytes);
+//   k_sbc_par_*    persistent workgroups over the (stream, chunk of 16 / 8 frames) items of the regular lists, dealt round
+//                  robin, then over the general streams' slots;
+//   k_sbc_gen      the same for what is left of the general streams, every index looked up in the plan instead of computed
+//                  in closed form;
+//   k_sbc_finish   puts the new decoder states in place (the last chunk of a stream must not overwrite the state its first
+//                  chunk may still be reading) and decodes the streams no list took.
 // k_sbc, one wave per stream walking its frames, stays for a state no efx_sbc_decode call can have left (a block count that
 // is no multiple of four) and as the comparison the tests run the other kernels against (EFX_OPT_SBC_SERIAL).  In all of them:
 //   * the reference's lazy bit reader is replaced by direct addressing -- every block of a frame
@@ -416,7 +419,7 @@ namespace {
 
 // Wave-wide inclusive scans (64 lanes) as six DPP steps: row_shr 1, 2, 4, 8 inside the rows of sixteen lanes, then row_bcast 15
 // and 31 carry the rows' totals on (gfx9; a lane without a source takes the identity).  __shfl_up() would be a ds_bpermute
-// round trip per step -- sixteen scans a tile made k_sbc_plan 58 us for 256 streams.
+// round trip per step -- fifteen scans a tile: k_sbc_plan took 58 us for 256 streams.
 template <int kCtrl, int kRowMask>
 __device__ inline int sbc_dpp(int identity, int v)
 {

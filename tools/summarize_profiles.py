@@ -139,7 +139,8 @@ for k, cs in video.items():
 if summary or video:
     sys.path.insert(0, root)
     import bench  # (kernel_sources_digest: what the counters were measured on; bench.py warns when the sources move on)
-    doc = {"note": a.note, "kernel_sources_digest": bench.kernel_sources_digest(), "kernels": summary, "video_kernels": video}
+    doc = {"note": a.note, "kernel_sources_digest": bench.kernel_sources_digest(), "kernel_source_files": bench.kernel_source_digests(),
+           "kernels": summary, "video_kernels": video}
     doc.update(extra)
     json.dump(doc, open(os.path.join(out, f"{a.tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps({k: v for k, v in doc.items() if k != "note"}, indent=1, sort_keys=True))
