@@ -47,7 +47,7 @@ __global__ void k_fill(uint32_t*, uint32_t, size_t);
 __global__ void k_composite(const uint8_t*, const VideoTables*, const VideoLineTemplates*, FieldArgs, uint16_t*);
 __global__ void k_pdm(const int16_t*, int, int, int32_t*, uint16_t*);
 __global__ void k_sbc(const uint8_t*, size_t, int, int, SbcState*, const SbcTables*, int16_t*, size_t, uint32_t*, uint32_t*, int);
-__global__ void k_sbc_frames(const uint8_t*, size_t, int, int, SbcFrameInfo*, uint32_t*, uint32_t*);
+__global__ void k_sbc_frames(const uint8_t*, size_t, int, int, SbcFrameInfo*, uint32_t*, uint32_t*, SbcQueues*);
 __global__ void k_sbc_plan(const SbcFrameInfo*, int, int, const SbcState*, SbcFramePlan*, uint32_t*, SbcQueues*, uint32_t*, int, int, uint32_t*,
                            uint32_t*, SbcExtraItem*, uint8_t*);
 __global__ void k_sbc_par_stereo(const uint8_t*, size_t, int, int, const SbcState*, SbcState*, const SbcTables*, const SbcFrameInfo*, int16_t*,
@@ -1897,7 +1897,7 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
         EFX_HIP(hipMemsetAsync(d_how, 0xFF, ctx->sbc_flags_cap * sizeof(uint32_t), ctx->stream));
     ctx->sbc_flags_clean = false;
     hipLaunchKernelGGL(k_sbc_frames, dim3((n_frames + 255) / 256, n_streams), dim3(256), 0, ctx->stream, frames_device, stream_stride,
-                       frame_bytes, n_frames, ctx->d_sbc_info, ret_device, d_how);
+                       frame_bytes, n_frames, ctx->d_sbc_info, ret_device, d_how, d_queues);
     hipLaunchKernelGGL(k_sbc_plan, dim3(n_streams + 1), dim3(256), 0, ctx->stream, ctx->d_sbc_info, n_frames, flags, state, ctx->d_sbc_plan,
                        d_how, d_queues, d_lists, n_streams, (int)ctx->sbc_flags_cap, ret_device, pcm_count_device, ctx->d_sbc_extra,
                        ctx->d_sbc_cover);

@@ -351,9 +351,11 @@ static_assert(EFX_SBC_CHUNK_MONO == kSbcChunk * kSbcMonoGranules && (kSbcMonoGra
 // reference's return value of a frame that decodes is its own affair (a frame it rejects: k_sbc_plan / k_sbc).
 __global__ __launch_bounds__(256) void k_sbc_frames(const uint8_t* __restrict__ frames, size_t stream_stride, int frame_bytes,
                                                     int n_frames, SbcFrameInfo* __restrict__ info, uint32_t* __restrict__ ret,
-                                                    uint32_t* __restrict__ parallel)
+                                                    uint32_t* __restrict__ parallel, SbcQueues* __restrict__ queues)
 {
     const int s = blockIdx.y, f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0 && f < 4)
+        queues->extra[f] = 0;  // (k_sbc_plan: "a general stream has a chunk for the regular kernel of kind f")
     if (f >= n_frames)
         return;
     const uint8_t* base = frames + (size_t)s * stream_stride;
@@ -608,6 +610,10 @@ __global__ __launch_bounds__(256) void k_sbc_plan(const SbcFrameInfo* __restrict
             const bool take_stereo = mine == 3;
             const bool take_mono = kSbcMonoGranules == 1 ? mine == 1 : ((lane & 15) == 15 && mine == 1 && even == 1);
             const uint32_t entry = (uint32_t)s | (((h1 >> 4) & 3) << 30);
+            if (take_stereo)
+                queues->extra[kSbcStereo] = 1;  // (plain stores of the same value: a kernel whose flag stays 0 does not walk the slots)
+            if (take_mono)
+                queues->extra[kSbcMono] = 1;
             if (last_of_gran && gi < n_gran) {
                 SbcExtraItem e;
                 e.entry = take_stereo ? entry : kSbcSkipEntry;
@@ -734,7 +740,7 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
 
     const int tid = threadIdx.x;
     constexpr int cls = C == 1 ? kSbcMono : kSbcStereo;
-    const uint32_t count = queues->count[cls], n_general = queues->count[kSbcGeneral];
+    const uint32_t count = queues->count[cls], n_general = queues->extra[cls] ? queues->count[kSbcGeneral] : 0u;
     if (count + n_general == 0)
         return;
     {
