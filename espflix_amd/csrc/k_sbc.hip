@@ -80,18 +80,28 @@ __device__ void bit_allocation(int frequency, int allocation, int bitpool, const
         bitneed[sb] = need;
         max_bitneed = max(max_bitneed, need);
     }
-    int bitcount = 0, slicecount = 0, bitslice = max_bitneed + 1;
+    // The reference's bit-slice loop (sbc_decoder.cpp:186-198) counts, slice by slice, the subbands with bitslice + 1 < bitneed <
+    // bitslice + 16 once and those with bitneed == bitslice + 1 twice.  With G(x) = subbands whose bitneed is at least x that is
+    // 2 G(bitslice + 1) - G(bitslice + 2) - G(bitslice + 16), and G(bitslice + 2) is the slice before's G(bitslice + 1): two
+    // counts a slice, each over the eight needs as BYTES (bitneed + 32: 27 .. 47) -- byte + (128 - x) has bit 7 set iff byte >= x.
+    uint32_t e_lo = 0, e_hi = 0;
+#pragma unroll
+    for (int sb = 0; sb < 4; sb++) {
+        e_lo |= (uint32_t)(bitneed[sb] + 32) << (8 * sb);
+        e_hi |= (uint32_t)(bitneed[sb + 4] + 32) << (8 * sb);
+    }
+    auto at_least = [&](int need) -> int {
+        const uint32_t x = (uint32_t)min(max(need + 32, 0), 128);
+        const uint32_t k = __builtin_amdgcn_perm(0u, 128u - x, 0u);  // (the byte in all four)
+        return __popc((e_lo + k) & 0x80808080u) + __popc((e_hi + k) & 0x80808080u);
+    };
+    int bitcount = 0, slicecount = 0, bitslice = max_bitneed + 1, above = 0;  // above = G(bitslice + 2) of the slice to come: none
     do {
         bitslice--;
         bitcount += slicecount;
-        slicecount = 0;
-#pragma unroll
-        for (int sb = 0; sb < 8; sb++) {
-            if (bitneed[sb] > bitslice + 1 && bitneed[sb] < bitslice + 16)
-                slicecount++;
-            else if (bitneed[sb] == bitslice + 1)
-                slicecount += 2;
-        }
+        const int here = at_least(bitslice + 1);
+        slicecount = 2 * here - above - at_least(bitslice + 16);
+        above = here;
     } while (bitcount + slicecount < bitpool);
     if (bitcount + slicecount == bitpool) {
         bitcount += slicecount;
