@@ -1837,7 +1837,7 @@ int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, si
 {
     bind_device(ctx);
     if (!ctx || !frames_device || !state_device || !pcm_device || n_streams <= 0 || n_frames < 0 || frame_bytes <= 0 ||
-        (size_t)frame_bytes * (size_t)n_frames > 0x7FFFFFFFu || ((uintptr_t)state_device & 3))
+        (size_t)frame_bytes * (size_t)n_frames >= (1u << 28) || ((uintptr_t)state_device & 3))
         return EFX_ERR_ARG;
     SbcState* const state = static_cast<SbcState*>(state_device);
     if (n_frames == 0 || ctx->opt_sbc_serial) {

@@ -802,7 +802,10 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
         const bool work = p.valid && !p.skip;
         p.s = work ? (int)(e & 0x3FFFFFFFu) : 0;
         p.blocks = 4 * (int)(((work ? e : 0u) >> 30) + 1);  // (k_sbc_plan packs the block count of the stream's frames into the entry)
-        p.inv_b = p.blocks == 4 ? 16385u : p.blocks == 8 ? 8193u : p.blocks == 12 ? 5462u : 4097u;  // x / blocks = x * inv_b >> 16 (x < 4096)
+        // x / blocks = x * inv_b >> 16, exact for x < 4096 ONLY: it is applied to block numbers counted from the first frame
+        // in reach (< FR * 16), never to a block of the call's timeline -- that grows with the number of frames of the call
+        // (round-5 ADVICE: with the absolute number the quotient was first wrong at frame 688 of a 12-block stream)
+        p.inv_b = p.blocks == 4 ? 16385u : p.blocks == 8 ? 8193u : p.blocks == 12 ? 5462u : 4097u;
         p.gbase = frames + (size_t)p.s * stream_stride;
         p.inf = info + (size_t)p.s * n_frames;
         p.f0 = chunk * CH;
@@ -812,7 +815,9 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
         p.vb0 = p.f0 * p.blocks;
         p.vb1 = p.f1 * p.blocks;
         p.first_vb = max(p.vb0 - 9, probe ? -p.blocks : 0);      // first block whose samples this workgroup needs
-        p.fr_lo = p.first_vb < 0 ? -1 : (int)(((uint32_t)p.first_vb * p.inv_b) >> 16);  // ... it lies in this frame (-1: the probe's frame 0)
+        // ... it lies in this frame (-1: the probe's frame 0).  first_vb >= (f0 - 3) * blocks: the quotient is f0 minus
+        // what the (at most nine) blocks below vb0 make in frames -- a division of a number below 16, exact
+        p.fr_lo = p.first_vb < 0 ? -1 : p.f0 - (int)(((uint32_t)(p.vb0 - p.first_vb + p.blocks - 1) * p.inv_b) >> 16);
         p.n_fr = p.f1 - p.fr_lo;                                   // frames in reach (<= FR)
         // the frame bytes in reach (contiguous in the stream), whole aligned dwords, bytes beyond the stream's frames as zeros
         p.lo_byte = (uint32_t)max(p.fr_lo, 0) * (uint32_t)frame_bytes;
@@ -892,6 +897,8 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
                   n_fr = p.n_fr;
         const uint32_t inv_b = p.inv_b, lo_byte = p.lo_byte, mis = p.mis;
         const bool staged = p.staged;
+        // block vb >= 0 of the call's timeline, counted from the first frame in reach: frame fr_base + rel / blocks, rel < FR * 16
+        const int fr_base = max(fr_lo, 0), vb_base = fr_base * blocks, k_base = fr_base - fr_lo;
         const uint8_t* gbase = p.gbase;
         // byte `pos` of the stream (bytes at or beyond `limit` read as zero); the stage holds its dwords MSB first
         auto byte_at = [&](uint32_t pos) -> uint32_t {
@@ -981,9 +988,9 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
             const int c = i / 144, rr = i - c * 144, t = rr >> 4, o = rr & 15, vb = vb0 - 9 + t;
             if (vb < hist_end)
                 continue;
-            const int vbp = vb < 0 ? vb + blocks : vb;
-            const int fq = (int)(__umul24((uint32_t)vbp, inv_b) >> 16);
-            const int k = (vb < 0 ? -1 : fq) - fr_lo, blk = vb < 0 ? vbp : vbp - (int)__umul24((uint32_t)fq, (uint32_t)blocks);
+            const int rel = vb < 0 ? 0 : vb - vb_base;
+            const int fq = (int)(__umul24((uint32_t)rel, inv_b) >> 16);
+            const int k = vb < 0 ? -1 - fr_lo : fq + k_base, blk = vb < 0 ? vb + blocks : rel - (int)__umul24((uint32_t)fq, (uint32_t)blocks);
             const int32_t* x = &sb[((k * 16 + blk) * C + c) * 8];
             uint32_t acc = 0;
 #pragma unroll
@@ -1006,7 +1013,8 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
             const int RH = (vb1 - vb0) >> 1;
             for (int idx = tid >> 3; idx < C * RH; idx += 32) {
                 const int c = (C == 2 && idx >= RH) ? 1 : 0, row = 2 * (idx - c * RH), vb = vb0 + row;
-                const int fq = (int)(__umul24((uint32_t)vb, inv_b) >> 16), k = fq - fr_lo, blk = vb - (int)__umul24((uint32_t)fq, (uint32_t)blocks);
+                const int rel = vb - vb_base, fq = (int)(__umul24((uint32_t)rel, inv_b) >> 16), k = fq + k_base,
+                          blk = rel - (int)__umul24((uint32_t)fq, (uint32_t)blocks);
                 const int4* sp = reinterpret_cast<const int4*>(&sb[((k * 16 + blk) * C + c) * 8]);
                 const int4 x0 = sp[0], x1 = sp[1], y0 = sp[2 * C], y1 = sp[2 * C + 1];
                 const int32_t x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
@@ -1037,7 +1045,8 @@ __device__ __forceinline__ void sbc_par_body(const uint8_t* __restrict__ frames,
             const int RB = vb1 - vb0;
             for (int idx = tid >> 3; idx < C * RB; idx += 32) {
                 const int c = (C == 2 && idx >= RB) ? 1 : 0, row = idx - c * RB, vb = vb0 + row;
-                const int fq = (int)(__umul24((uint32_t)vb, inv_b) >> 16), k = fq - fr_lo, blk = vb - (int)__umul24((uint32_t)fq, (uint32_t)blocks);
+                const int rel = vb - vb_base, fq = (int)(__umul24((uint32_t)rel, inv_b) >> 16), k = fq + k_base,
+                          blk = rel - (int)__umul24((uint32_t)fq, (uint32_t)blocks);
                 const int4* sp = reinterpret_cast<const int4*>(&sb[((k * 16 + blk) * C + c) * 8]);
                 const int4 x0 = sp[0], x1 = sp[1];
                 const int32_t x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};

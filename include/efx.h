@@ -305,7 +305,9 @@ size_t efx_sbc_state_bytes(void);
  * Every stream is decoded in chunks of frames that run side by side (espflix_amd/csrc/k_sbc.hip): what the reference
  * chains from frame to frame -- a rejected frame is synthesised from the samples and under the geometry the state holds
  * -- is resolved into prefix scans over the stream's frames first.  `state` must be zeros or what a call left there
- * (the filter memory is multiplied as 24-bit values, which every value a call can leave fits). */
+ * (the filter memory is multiplied as 24-bit values, which every value a call can leave fits).
+ * frame_bytes x n_frames < 2^28 per call (bit positions inside a stream are 32-bit): longer streams take several
+ * calls, the state carries over; EFX_ERR_ARG otherwise. */
 int efx_sbc_decode(efx_ctx* ctx, int n_streams, const uint8_t* frames_device, size_t stream_stride, int frame_bytes,
                    int n_frames, void* state_device, int16_t* pcm_device, size_t pcm_stride, uint32_t* ret_device,
                    uint32_t* pcm_count_device, int flags);

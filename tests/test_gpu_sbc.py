@@ -221,6 +221,42 @@ def test_rejected_frames_decode_frame_parallel(efx, case):
     dec.close()
 
 
+@pytest.mark.parametrize("blocks,mode,frames", [(12, 0, 760), (12, 1, 700), (8, 0, 1150), (8, 2, 1100), (16, 0, 2450), (16, 1, 2400),
+                                                (4, 0, 4300), (4, 2, 4200)],
+                         ids=["mono12x760", "dual12x700", "mono8x1150", "stereo8x1100", "mono16x2450", "dual16x2400", "mono4x4300",
+                              "stereo4x4200"])
+def test_calls_of_thousands_of_frames(efx, blocks, mode, frames):
+    """Round-5 ADVICE (high): the frame-parallel kernels divided a block's number ON THE CALL'S TIMELINE by the block count
+    with a 16-bit reciprocal that is exact below 4096 only -- first wrong at frame 688 of a 12-block stream, 1032 (8 blocks),
+    2312 (16), 4104 (4); no test had more than 130 frames per call.  One call of more frames than that for every block count,
+    mono and two channels, with and without decode_audio()'s probe: a clean stream (k_sbc_par_*), one with a rejected frame
+    near the end and one with a rejected frame near the start (k_sbc_plan + k_sbc_gen, and the regular granules of a general
+    stream), against the oracle and against the one-wave kernel (states byte for byte)."""
+    kw = dict(freq=3, blocks=blocks, mode=mode, alloc=frames & 1, bitpool=21 if mode == 0 else 37)
+    ch = 1 if mode == 0 else 2
+    fb = common.sbc_frame_bytes(blocks, ch, kw["bitpool"])
+    streams = [common.sbc_frames(7000 + blocks + 3 * mode + i, frames, **kw) for i in range(3)]
+    streams[1] = streams[1].copy()
+    streams[1].reshape(frames, fb)[frames - 19, 0] = 0x9D  # bad sync byte: the samples before it are synthesised again
+    streams[2] = streams[2].copy()
+    streams[2].reshape(frames, fb)[11, 0] = 0x9D
+    dec = efx.Decoder(1, 1, 2)
+    for probe in (False, True):
+        got, rets, states = _decode_batch(efx, dec, streams, fb, frames, probe, 1, serial=False)
+        ser, sret, sstates = _decode_batch(efx, dec, streams, fb, frames, probe, 1, serial=True)
+        for i, fr in enumerate(streams):
+            want, wret = oracle.sbc_decode(fr, fb, probe)
+            if probe:
+                want, wret = want[wret[0][1] // 2:], wret[1:]
+            assert rets[i] == wret, (probe, i)
+            bad = np.flatnonzero(got[i] != want) if got[i].size == want.size else None
+            assert bad is not None and bad.size == 0, (probe, i, got[i].size, want.size,
+                                                        None if bad is None else int(bad[0]) // (ch * blocks * 8))
+            assert np.array_equal(got[i], ser[i]) and rets[i] == sret[i], (probe, i)
+            assert np.array_equal(states[i], sstates[i]), (probe, i)
+    dec.close()
+
+
 def test_frame_that_runs_past_the_stated_frame_size(efx):
     """The caller states ONE frame size (decode_audio() takes it from the probe); a frame with a larger bitpool runs past
     it and the reference reads on into the next frame's bytes (get_samples() never looks at the length again,
