@@ -90,6 +90,7 @@ _SYMBOLS = {
     "efx_last_error": (C.c_char_p, [_P]),
     "efx_status_string": (C.c_char_p, [C.c_int]),
     "efx_upload_streams": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t), C.c_int]),
+    "efx_upload_streams_inplace": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t), C.c_int]),
     "efx_download_es": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "efx_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "efx_host_free": (C.c_int, [_P, _P]),
@@ -308,9 +309,12 @@ class Decoder:
         n = len(arrs)
         return arrs, (_P * n)(*[a.ctypes.data for a in arrs]), (C.c_size_t * n)(*[a.size for a in arrs]), n
 
-    def upload_prepared(self, prepared, fmt: int = FORMAT_ES):
+    def upload_prepared(self, prepared, fmt: int = FORMAT_ES, in_place: bool = False):
+        """in_place: efx_upload_streams_inplace -- the batch must lie in an arena of this context (place_in_arena); the
+        library writes the tails into the layout's gaps and the transfer reads the arena.  Otherwise the staged path."""
         _, ptrs, lens, n = prepared
-        _check(self._ctx, self._lib.efx_upload_streams(self._ctx, n, ptrs, lens, fmt))
+        fn = self._lib.efx_upload_streams_inplace if in_place else self._lib.efx_upload_streams
+        _check(self._ctx, fn(self._ctx, n, ptrs, lens, fmt))
         self.n_streams = n
 
     # -- in-place ingest (efx_host_alloc / efx_stream_layout / efx_upload_done) ---------------
@@ -322,7 +326,7 @@ class Decoder:
 
     def place_in_arena(self, arena: np.ndarray, streams):
         """Lay a batch out in `arena` the way efx_stream_layout prescribes and return the prepared argument arrays
-        for upload_prepared(): such a batch is transferred straight from the arena, no staging copy."""
+        for upload_prepared(..., in_place=True): such a batch is transferred straight from the arena, no staging copy."""
         arrs = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray, memoryview))
                 else np.ascontiguousarray(s, dtype=np.uint8) for s in streams]
         n = len(arrs)

@@ -377,7 +377,10 @@ hipError_t guard_alloc(void** out, size_t bytes)
         (void)hipMemAddressFree(r.va, r.va_bytes);
         return e;
     }
-    // mode 1: the buffer ends with the mapping (256-byte granules keep every alignment the kernels assume)
+    // mode 1: the buffer ENDS with the mapping, so its start is 16-byte aligned and no more (round-5 ADVICE: the comment here
+    // claimed 256): every kernel is correct at 16 bytes -- the widest access is a dwordx4 -- and layouts that are tuned to
+    // 128-byte lines (one hand-over word per line in d_recon_sync) merely straddle lines in this debugging mode.  Mode 2
+    // (the buffer STARTS with the mapping) keeps the allocator's natural alignment.
     const size_t span = (bytes + 255) & ~(size_t)255;
     void* p = guard_mode() == 2 ? base : base + (r.map_bytes - span) + (span - ((bytes + 15) & ~(size_t)15));
     {
@@ -410,7 +413,8 @@ hipError_t dev_free(void* p)
     (void)hipDeviceSynchronize();  // hipFree's implicit barrier
     hipError_t e = hipMemUnmap(static_cast<char*>(r.va) + r.gran, r.map_bytes);
     hipError_t e2 = hipMemRelease(r.handle);
-    // The address range is NOT given back: a freed pointer then stays unmapped for the rest of the process (a use after free
+    // (debugging mode only) The address range is NOT given back, so a long soak run under EFX_GUARD grows its address space
+    // by every buffer it ever freed: a freed pointer then stays unmapped for the rest of the process (a use after free
     // faults too), and the runtime never sees an address twice -- one soak process of this round died in the HIP runtime's own
     // bookkeeping ("Memobj map does not have ptr") after some two thousand reserve / free cycles of recycled ranges.
     return e != hipSuccess ? e : e2;
@@ -762,7 +766,10 @@ static int ensure_ts_buffers(efx_ctx* ctx)
     return EFX_OK;
 }
 
-int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, const size_t* len, int format)
+// efx_upload_streams (in_place = false: the caller's bytes are only ever READ, whatever the pointers look like) and
+// efx_upload_streams_inplace (the batch lies in an arena in the device layout; the library writes the tails and the zero fill
+// into the gaps of the layout and the transfer reads the arena)
+static int upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, const size_t* len, int format, bool in_place)
 {
     bind_device(ctx);
     if (!ctx || !data || !len || n_streams <= 0 || (format != EFX_FORMAT_ES && format != EFX_FORMAT_TS))
@@ -802,16 +809,23 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
     const int ui = (ctx->cur_up + 1) % kUploads;
     efx_ctx::Upload& u = ctx->up[ui];
     hipStream_t st = ctx->copy_stream;
-    // in place: the batch lies in one arena exactly as the device buffer holds it (efx_stream_layout)
+    // in place (asked for by name, round-5 ADVICE: never inferred from what the pointers look like -- a caller that packs
+    // streams back to back in page-locked memory and uploads them one at a time would have had the next stream's first bytes
+    // overwritten by this stream's tail): the batch must lie in one arena exactly as the device buffer holds it
+    // (efx_stream_layout), else the call is refused
     const uint8_t* arena_src = nullptr;
-    for (const auto& a : ctx->arenas)
-        if (data[0] >= a.base && data[0] + pos <= a.base + a.bytes) {
-            arena_src = data[0];
-            for (int i = 1; i < n_streams && arena_src; i++)
-                if (data[i] != data[0] + stream_off[i])
-                    arena_src = nullptr;
-            break;
-        }
+    if (in_place) {
+        for (const auto& a : ctx->arenas)
+            if (data[0] >= a.base && data[0] + pos <= a.base + a.bytes) {
+                arena_src = data[0];
+                for (int i = 1; i < n_streams && arena_src; i++)
+                    if (data[i] != data[0] + stream_off[i])
+                        arena_src = nullptr;
+                break;
+            }
+        if (!arena_src)
+            return fail(ctx, EFX_ERR_ARG, "efx_upload_streams_inplace: the batch does not lie in an arena of this context in the layout of efx_stream_layout");
+    }
     if (u.valid) {
         // this record's pinned metadata (and, staged path, its staging buffer) are about to be rewritten by the host: its own
         // previous transfer must have read them -- three uploads ago, long done
@@ -955,6 +969,17 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
     ctx->cur_up = ui;
     return EFX_OK;
 }
+
+int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, const size_t* len, int format)
+{
+    return upload_streams(ctx, n_streams, data, len, format, false);
+}
+
+int efx_upload_streams_inplace(efx_ctx* ctx, int n_streams, uint8_t* const* data, const size_t* len, int format)
+{
+    return upload_streams(ctx, n_streams, data, len, format, true);
+}
+
 
 int efx_stream_layout(int n_streams, const size_t* len, size_t* offsets)
 {

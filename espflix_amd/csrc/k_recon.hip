@@ -78,6 +78,17 @@ __device__ inline void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v
     v4 = even3 + odd_c;
 }
 
+// v_bitop3_b32: any function of three words bit by bit, table index = a << 2 | b << 1 | c (a = 0xF0, b = 0xCC, c = 0xAA).
+// Full rate on gfx950 (2 cycles per wave64) where v_bfi_b32 / v_and_or_b32 / v_cndmask_b32 take 4 (profiles/r6_valu_rates.md);
+// the compiler still selects those, hence by name.
+template <int kTable>
+__device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4" : "=v"(r) : "v"(a), "v"(b), "v"(c), "n"(kTable));
+    return r;
+}
+
 __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // byte offset of plane row inside a frame (Frame::get_y/get_cr/get_cb, player.cpp:33-46)
@@ -172,6 +183,11 @@ __device__ __forceinline__ BlockAt block_at(int g, int lane)
     // Block order inside a picture: by macroblock row, and inside it by plane row -- the 44 upper luma
     // blocks, the 44 lower ones, the 22 "cr" and the 22 "cb" blocks -- so that the lanes of a wave
     // write (and mostly read) long contiguous runs of every frame row they touch.
+#if defined(EFX_RECON_MB_MAJOR)
+    o.mb = b / 6;
+    o.blk = b - o.mb * 6;
+    return o;
+#endif
     const int mbrow = b / 132, rr = b - mbrow * 132;
     int mbx;
     if (rr < 88) {
@@ -196,7 +212,11 @@ template <int kLoad, int kStore, class PreStore>
 __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const uint32_t* __restrict__ coefs,
                                             const uint32_t* __restrict__ qt_custom, uint8_t* __restrict__ frames, int ring_depth,
                                             int pic, int pos0, int first_pts, int epoch, int s, int g, const uint4 rw,
-                                            PreStore&& pre_store)
+                                            PreStore&& pre_store
+#if defined(EFX_RECON_ABL) && EFX_RECON_ABL == 2
+                                            , const uint32_t (&efx_abl_early)[3]
+#endif
+                                            )
 {
     int16_t* const cfh = reinterpret_cast<int16_t*>(lds);
     uint16_t* const s_pre = reinterpret_cast<uint16_t*>(lds + 64 * kLaneDwords);  // entries before the block in the wave
@@ -353,16 +373,31 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
 #pragma unroll
         for (int k = 0; k < kPerRound; k++) {
             const uint32_t i = i0 + 64 * k;
-            int L = 0;
+            // (L2 = 2 L, the byte offset into s_pre: the probe's address is L2 + an immediate; "prefix <= i" as the sign
+            // of a difference -- both are below 2^13 -- and the step merged in by a bit operation: three full-rate
+            // instructions per step, where compare + select + shift + or cost seventeen cycles -- profiles/r6_valu_rates.md)
+            uint32_t L2 = 0;
 #pragma unroll
-            for (int step = 32; step > 0; step >>= 1)
-                L += (uint32_t)s_pre[L + step] <= i ? step : 0;
-            const uint32_t o_pf = (uint32_t)__builtin_amdgcn_ds_bpermute(L * 4, (int)pre_flags);
-            const uint32_t o_base = (uint32_t)__builtin_amdgcn_ds_bpermute(L * 4, (int)my_base);
+            for (int step = 32; step > 0; step >>= 1) {
+                const uint32_t probe = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(s_pre) + L2 + 2 * step);
+                int32_t diff = (int32_t)(i - probe);
+                asm("" : "+v"(diff));  // (opaque: the compiler knows the ranges and would rebuild the compare + select)
+                const uint32_t below = (uint32_t)(diff >> 31);  // all ones: prefix > i
+                L2 = bitop3<0xF4>(L2, (uint32_t)(2 * step), below);             // L2 | (2 step & ~below)
+            }
+            const int L = (int)(L2 >> 1);
+            const uint32_t o_pf = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(L2 + L2), (int)pre_flags);
+            const uint32_t o_base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(L2 + L2), (int)my_base);
             own[k] = L | (int)(o_pf >> 16 << 8);  // owner lane | its flags << 8
             // (always a load, beyond the end from entry 0: the compiler then knows how many loads are in flight and
             // the prediction below waits for the windows only)
+#if defined(EFX_RECON_ABL) && EFX_RECON_ABL >= 1
+            // (ablation, timing only -- wrong pixels: the wave's entries as ONE contiguous run; 2: the first round's requested
+            // before the record is waited for, efx_abl_early)
+            ent[k] = coefs[(uint32_t)__builtin_amdgcn_readfirstlane((int)my_base) + (i < total ? i : 0u)];
+#else
             ent[k] = coefs[i < total ? o_base + (i - (o_pf & 0xFFFF)) : 0u];
+#endif
         }
     };
     auto apply = [&](uint32_t i0) {
@@ -405,6 +440,11 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
         }
     };
     fetch(lane, own, ent);  // (also when the wave has no entry at all: the same three loads in flight on every path)
+#if defined(EFX_RECON_ABL) && EFX_RECON_ABL == 2
+#pragma unroll
+    for (int k = 0; k < kPerRound; k++)
+        ent[k] = efx_abl_early[k];
+#endif
 
     // ---- prediction of the 8 rows, in the shadow of the entry loads just issued (a wave's life is its chain of
     // memory round trips: record -> owner search -> entries; this arithmetic needs only the windows, which were
@@ -421,11 +461,10 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
     {
         const uint32_t selP = 0x03020100u + 0x01010101u * (uint32_t)(px0 & 3), selQ = selP + 0x01010101u * (uint32_t)hx;
         const uint32_t hym = 0u - (uint32_t)hy;
-        const uint32_t keep = intra ? 0u : ~0u;  // (an intra block has no prediction: its window registers hold its own position)
-        auto pick = [](uint32_t m, uint32_t set, uint32_t clear) {  // bit by bit: m ? set : clear  (v_bfi_b32)
-            uint32_t r;
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(set), "v"(clear));
-            return r;
+        uint32_t keep = intra ? 0u : ~0u;  // (an intra block has no prediction: its window registers hold its own position)
+        asm volatile("" : "+v"(keep));     // (a mask, not a condition: sixteen full-rate ANDs instead of sixteen selects)
+        auto pick = [](uint32_t m, uint32_t set, uint32_t clear) {  // bit by bit: m ? set : clear
+            return bitop3<0xCA>(m, set, clear);
         };
         auto row = [&](int r, uint32_t& Hl, uint32_t& Hh, uint32_t& Xl, uint32_t& Xh) {
             const uint32_t Pl = __builtin_amdgcn_perm(wb[r], wa[r], selP), Ph = __builtin_amdgcn_perm(wc[r], wb[r], selP);
@@ -476,6 +515,39 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const uint32_t zd = s_zd[lane];
     EFX_PROBE_STAMP_AFTER(5, zd);  // the entries have been dealt out: the IDCT starts
+#ifdef EFX_RECON_SENS
+    // (sensitivity builds, tools/exp/recon_sens.sh: which unit of the CU is the launch waiting for?  Dummy work of ONE kind
+    // is added and the launch timed: full-rate vector instructions, half-rate ones, LDS reads, L1-resident loads)
+    {
+        uint32_t d0 = zd, d1 = zd + 1, d2 = zd + 2, d3 = zd + 3;
+#if EFX_RECON_SENS == 1
+#pragma unroll
+        for (int i = 0; i < EFX_RECON_SENS_N / 4; i++)
+            asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %1, %1, %2\n v_add_u32 %2, %2, %3\n v_add_u32 %3, %3, %0" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+#elif EFX_RECON_SENS == 2
+#pragma unroll
+        for (int i = 0; i < EFX_RECON_SENS_N / 4; i++)
+            asm volatile("v_perm_b32 %0, %0, %1, %2\n v_perm_b32 %1, %1, %2, %3\n v_perm_b32 %2, %2, %3, %0\n v_perm_b32 %3, %3, %0, %1" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+#elif EFX_RECON_SENS == 3
+#pragma unroll
+        for (int i = 0; i < EFX_RECON_SENS_N / 4; i++) {
+            d0 += lds[(lane * kLaneDwords + (d1 & 7)) & 2047];
+            d1 += lds[(lane * kLaneDwords + 8 + (d2 & 7)) & 2047];
+            d2 += lds[(lane * kLaneDwords + 16 + (d3 & 7)) & 2047];
+            d3 += lds[(lane * kLaneDwords + 24 + (d0 & 7)) & 2047];
+            asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+        }
+#elif EFX_RECON_SENS == 4
+#pragma unroll
+        for (int i = 0; i < EFX_RECON_SENS_N; i++) {
+            d0 += __builtin_nontemporal_load(coefs + (my_base & ~63u) + lane + 64 * (i & 1));   // (this wave's own entries again: L1 / L2 hits)
+            asm volatile("" : "+v"(d0));
+        }
+#endif
+        if ((d0 ^ d1 ^ d2 ^ d3) == 0x9E3779B9u)
+            s_zd[lane] = 1;
+    }
+#endif
     const bool zf = (zd & 0x80) != 0;  // an entry sits at scan position 0
     // intra DC value (22 bits: a slice adds at most 1584 differentials of +-255 to the predictor)
     const int dc_raw = (int)((uint32_t)(uint16_t)mine[0] | ((uint32_t)((int)(zd << 26) >> 26) << 16));
@@ -548,6 +620,8 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
     uint32_t flat4 = (uint32_t)(v[0] >> 8);  // intra DC-only block: replicated exactly as copy_block_dc does, unclamped and
     flat4 |= flat4 << 8;                      // unmasked (player.cpp:1175-1187)
     flat4 |= flat4 << 16;
+    uint32_t clamped_m = clamped ? ~0u : 0u;
+    asm volatile("" : "+v"(clamped_m));
     pre_store();  // (k_recon_all: the place where the previous item's stores are known to have left)
     uint32_t out_lo[8], out_hi[8];
 #pragma unroll
@@ -565,8 +639,8 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
             w[h] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 0x06040200u);
         }
         // prediction only (skipped macroblock, block without coefficients) / intra DC-only replica / the clamped sum
-        out_lo[r] = clamped ? w[0] : flat4;
-        out_hi[r] = clamped ? w[1] : flat4;
+        out_lo[r] = bitop3<0xCA>(clamped_m, w[0], flat4);
+        out_hi[r] = bitop3<0xCA>(clamped_m, w[1], flat4);
         if constexpr (kStore < 2) {
             if (stored) {
                 if constexpr (kStore == 1) {
@@ -644,10 +718,22 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
     lds[lane * kLaneDwords + kLaneData] = scan_tab[lane];
     const BlockAt at = block_at(blockIdx.y, lane);
+#if defined(EFX_RECON_ABL) && EFX_RECON_ABL == 2
+    uint32_t efx_abl_early[3];
+    {
+        const uint32_t fake = (uint32_t)((((size_t)s * max_pictures + pic) * 25 + blockIdx.y) * 256u);
+        for (int k = 0; k < 3; k++)
+            efx_abl_early[k] = coefs[fake + lane + 64 * k];
+    }
+#endif
     const uint4 rw = *reinterpret_cast<const uint4*>(mbrecs + ((size_t)s * max_pictures + pic) * kMbCount + at.mb);
     EFX_PROBE_STAMP_AFTER(3, rw.x);  // the record has arrived
     recon_group<0, EFX_RECON_STORE>(lds, coefs, qtab_custom + ((size_t)s * max_pictures + pic) * 64, frames, ring_depth, pic, call_pos[2 * s],
-                       call_pos[2 * s + 1], epoch, s, blockIdx.y, rw, [] {});
+                       call_pos[2 * s + 1], epoch, s, blockIdx.y, rw, [] {}
+#if defined(EFX_RECON_ABL) && EFX_RECON_ABL == 2
+                       , efx_abl_early
+#endif
+                       );
     EFX_PROBE_STAMP(4);
     EFX_PROBE_CYCLES_END(2);
 }
@@ -675,6 +761,14 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
 // MI355X_MICROARCH.md "dequeue"); with the eight heads in one line the whole launch ran at that rate, 5.7 instead of
 // 0.9 ms per 307 200 items.  Zeroed by the host before every launch.  Restates, for a whole call, the order MpegDecoder::run() gives one stream: picture after picture
 // (player.cpp:692-702).
+// Ordering (round-5 ADVICE asked for release / acquire or the reason they are not needed): the hand-over is correct with
+// RELAXED agent-scope atomics because no plain cached access is involved on either side -- every frame store of an item is a
+// write-through `sc1` store and the signal goes out only after `s_waitcnt vmcnt(0)` has seen them complete (drain(); memory
+// operations of a wave complete in issue order), every frame load of the dependent item is an L1-bypassing `sc1` load issued
+// after the poll returned the count, and both go to the same L2 / fabric point of coherence.  A release fence would write back
+// an L2 that holds no dirty frame line, an acquire would invalidate an L1 that holds no frame line (MI355X_MICROARCH.md,
+// "Valid forms": {sc0 sc1 stores and loads both sides}); the plain-access build, which does need them, fails parity.
+constexpr unsigned long long kReconAllPatienceTicks = 1000000000ull;  // 10 s of the 100 MHz wall clock
 constexpr int kGroupsPerPicture = (kBlocksPerPicture + 63) / 64;  // 25
 constexpr uint32_t kSyncLine = 32;  // words per line
 constexpr uint32_t kSyncHeads = 0, kSyncSpins = 8 * kSyncLine, kSyncAbort = 9 * kSyncLine, kSyncDone = 64 * kSyncLine;
@@ -800,14 +894,20 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
                 signal(pending_signal);
                 pending_signal = -1;
             }
+            // The wait is bounded by WALL-CLOCK time (round-5 ADVICE: a count of polls -- 2^19 x s_sleep(8), 0.1-0.2 s -- can run
+            // out under a legitimate wait on a shared or preempted GPU): kReconAllPatienceTicks of the 100 MHz counter = 10 s,
+            // looked at every 1024 polls.  When it does run out the stream is flagged EFX_STREAM_INTERNAL and the launch
+            // gives up: the frames of that call are NOT valid (include/efx.h).
             uint32_t spins = 0;
             bool abort = false;
+            const unsigned long long t_wait0 = wall_clock64();
             do {
                 __builtin_amdgcn_s_sleep(8);
                 seen_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)done_of(a));
                 if ((++spins & 1023) == 0)
-                    abort = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(sync + kSyncAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
-            } while (seen_a < need && !abort && spins < (1u << 19));
+                    abort = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(sync + kSyncAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0 ||
+                            wall_clock64() - t_wait0 > kReconAllPatienceTicks;
+            } while (seen_a < need && !abort);
             if (seen_a < need && lane == 0) {
                 // never observed: a lost hand-over must not hang the device -- the stream is flagged, every other wait of the
                 // launch gives up at its next look, the call ends
@@ -826,7 +926,11 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
                                                        signal(pending_signal);
                                                    seen_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)done_b);
                                                    idx_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)claim_c);
-                                               });
+                                               }
+#if defined(EFX_RECON_ABL) && EFX_RECON_ABL == 2
+                                               , {0u, 0u, 0u}
+#endif
+                                               );
         pending_signal = a.s;
 #ifdef EFX_RA_STATS
         {

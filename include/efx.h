@@ -66,7 +66,9 @@ typedef enum efx_status {
                                          this bit */
 
 #define EFX_STREAM_INTERNAL 256u      /* never expected: a reconstruction wave gave up waiting for the stream's previous picture \
-                                         (k_recon_all's hand-over counter) -- the stream's frames are not to be trusted */
+                                         (k_recon_all's hand-over counter, optional EFX_OPT_RECON_MODE only; patience: 10 s \
+                                         of wall-clock time) -- the launch was abandoned: NO frame of that call is valid, \
+                                         for this stream or any other */
 
 typedef enum efx_format {
     EFX_FORMAT_ES = 0, /* raw ISO 11172-2 video elementary stream */
@@ -117,12 +119,14 @@ int efx_upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* data, 
  * MpegDecoder::more, src/player.cpp:459-493).  Its batch form: an ARENA of page-locked, device-visible host memory
  * (efx_host_alloc, or the caller's own memory made so by efx_host_register) in which the caller lays the streams of
  * a batch out the way the device buffer holds them -- stream i at offsets[i] of efx_stream_layout(), i.e. 16-byte
- * aligned starts with room behind every stream for the end-of-data tail.  efx_upload_streams recognises such a batch
- * (every data[i] == data[0] + offsets[i], all of it inside one arena): it writes the tails and the zero fill INTO the gaps
- * the layout leaves (the only bytes of the arena the library ever writes), and the H2D transfer reads the caller's
- * memory directly -- no staging copy, one transfer.  The caller keeps ownership throughout and must leave the batch's
- * bytes alone until efx_upload_done() says the transfer no longer reads them; any other pointer pattern takes the
- * staged path above. */
+ * aligned starts with room behind every stream for the end-of-data tail.  efx_upload_streams_inplace takes such a batch
+ * (every data[i] == data[0] + offsets[i], all of it inside one arena; anything else: EFX_ERR_ARG): it writes the tails and
+ * the zero fill INTO the gaps the layout leaves (the only bytes of the arena the library ever writes -- hence the
+ * non-const pointers), and the H2D transfer reads the caller's memory directly -- no staging copy, one transfer.  The
+ * caller keeps ownership throughout and must leave the batch's bytes alone until efx_upload_done() says the transfer no
+ * longer reads them.  In-place ingest is asked for BY NAME: efx_upload_streams() never writes through its `const` data
+ * pointers and always takes the staged path, wherever the streams lie (round 5 inferred it from the pointer pattern). */
+int efx_upload_streams_inplace(efx_ctx* ctx, int n_streams, uint8_t* const* data, const size_t* len, int format);
 int efx_host_alloc(efx_ctx* ctx, size_t bytes, void** host_ptr);
 int efx_host_free(efx_ctx* ctx, void* host_ptr);
 int efx_host_register(efx_ctx* ctx, void* host_ptr, size_t bytes);
@@ -130,8 +134,8 @@ int efx_host_unregister(efx_ctx* ctx, void* host_ptr);
 /* offsets[0 .. n_streams]: where stream i of the given lengths starts inside an arena (offsets[0] = 0), offsets[n_streams] =
  * bytes the batch occupies.  Host only. */
 int efx_stream_layout(int n_streams, const size_t* len, size_t* offsets);
-/* 1: the most recent efx_upload_streams no longer reads caller memory (always so for the staged path once the call has
- * returned); 0: its transfer is still in flight; negative: error. */
+/* 1: the most recent efx_upload_streams[_inplace] no longer reads caller memory (always so for the staged path once the
+ * call has returned); 0: its transfer is still in flight; negative: error. */
 int efx_upload_done(efx_ctx* ctx);
 /* The elementary stream the decoder sees for `stream` (what MpegDecoder::more() feeds the bit
  * reader, src/player.cpp:459-493), without the end-of-data tail: *es_len receives its length,

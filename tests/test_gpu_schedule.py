@@ -86,6 +86,33 @@ def test_decode_range_small_budgets_through_the_single_launch(efx, batch):
     dec.close()
 
 
+def test_staged_upload_never_writes_caller_memory(efx, batch):
+    """Round-5 ADVICE (medium): efx_upload_streams used to choose the in-place path from the pointer pattern -- ONE stream
+    lying in an arena always matched, and the library wrote its 9-byte tail and the zero fill behind it, i.e. over the first
+    bytes of whatever the caller had packed there.  Streams packed back to back in an arena and uploaded one at a time through
+    efx_upload_streams must leave every byte of the arena as it was."""
+    streams, golden = batch
+    dec = efx.Decoder(1, P, P + 1, max_stream_bytes=int(max(s.size for s in streams[:4])) + 4096)
+    total = sum(int(s.size) for s in streams[:4])
+    arena = dec.host_arena(total + 64)
+    pos, at = 0, []
+    for s_ in streams[:4]:
+        arena[pos:pos + s_.size] = s_
+        at.append(pos)
+        pos += s_.size
+    arena[pos:] = 0xA5
+    before = arena.copy()
+    import ctypes as C
+    for k, s_ in enumerate(streams[:4]):
+        ptrs = (C.c_void_p * 1)(arena.ctypes.data + at[k])
+        lens = (C.c_size_t * 1)(int(s_.size))
+        dec.upload_prepared((None, ptrs, lens, 1), efx.FORMAT_ES)
+        dec.decode()
+        assert np.array_equal(all_pictures(efx, dec, 1)[0], golden[k]), k
+        assert np.array_equal(arena, before), k
+    dec.close()
+
+
 def test_in_place_ingest_equals_staged(efx, batch):
     """A batch laid out in a page-locked arena of the context (efx_host_alloc + efx_stream_layout) is transferred where it lies;
     the decoder must see exactly the bytes the staged path gives it -- ES and TS input -- and upload_done() must come true."""
@@ -99,17 +126,19 @@ def test_in_place_ingest_equals_staged(efx, batch):
         arena = dec.host_arena(total + 32 * n + 4096)
         prep = dec.place_in_arena(arena, data)
         for rep in range(3):  # both bitstream buffers, and the first one again
-            dec.upload_prepared(prep, fmt)
+            dec.upload_prepared(prep, fmt, in_place=True)
             dec.decode()
             assert dec.upload_done()
             assert np.array_equal(all_pictures(efx, dec, n), golden[:n]), (fmt, rep)
         es_in_place = [dec.es(k) for k in (0, 1, n - 1)]
         dec.upload(data, fmt)  # the staged path
         assert [dec.es(k) for k in (0, 1, n - 1)] == es_in_place
-        # a batch that is NOT in layout order (two streams swapped) takes the staged path and still decodes
+        # a batch that is NOT in layout order (two streams swapped) is refused in place, and decodes through the staged path
         swapped = list(prep[1])
         ptrs = type(prep[1])(*([swapped[1], swapped[0]] + swapped[2:]))
         lens = type(prep[2])(*([prep[2][1], prep[2][0]] + list(prep[2])[2:]))
+        with pytest.raises(Exception):
+            dec.upload_prepared((prep[0], ptrs, lens, n), fmt, in_place=True)
         dec.upload_prepared((prep[0], ptrs, lens, n), fmt)
         dec.decode()
         got = all_pictures(efx, dec, n)
