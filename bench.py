@@ -55,6 +55,9 @@ FNV_BASIS, FNV_PRIME, M64 = 0xCBF29CE484222325, 0x100000001B3, (1 << 64) - 1
 WORKLOADS = {
     "gop12": (0, "bench_gop12.u64", 8192, 12),
     "wide1500k": (4 | 32, "bench_wide1500k.u64", 1024, 12),
+    # the same shape as streams of 36 and 72 pictures (three / six GOPs), decoded in one call: the reference's hashes of those streams
+    "wide1500k_p36": (4 | 32, "bench_wide1500k_p36.u64", 1024, 36),
+    "wide1500k_p72": (4 | 32, "bench_wide1500k_p72.u64", 1024, 72),
 }
 
 
@@ -169,11 +172,12 @@ def chain_hashes(table: np.ndarray) -> np.ndarray:
 
 
 def load_golden(workload: str):
-    flags, fname, rows, pics = WORKLOADS[workload]
+    flags, fname, rows, pics = WORKLOADS[workload][:4]
+    cols = WORKLOADS[workload][4] if len(WORKLOADS[workload]) > 4 else pics  # (columns of the table: pictures of its streams)
     path = os.path.join(GOLDEN_DIR, fname)
     if not os.path.exists(path):
         raise SystemExit(f"{path} is missing: the bench refuses to time a decoder it cannot check against the reference")
-    return np.fromfile(path, dtype="<u8").reshape(rows, pics)
+    return np.ascontiguousarray(np.fromfile(path, dtype="<u8").reshape(rows, cols)[:, :pics])
 
 
 def cpu_baseline(batch, n_streams: int, n_pictures: int, budget_streams: int, seconds: float = 5.0):
@@ -553,7 +557,7 @@ def run_workload(job, args, workload, S, ids, gen_threads, steps, warmup, want_s
     """Generate, gate, time one workload on this rank.  Returns a dict of rank-local + job results."""
     from espflix_amd import dist as edist
     from espflix_amd import gen
-    flags, _, _, P = WORKLOADS[workload]
+    flags, _, _, P = WORKLOADS[workload][:4]
     golden = load_golden(workload)
     t_gen = time.perf_counter()
     # ids are contiguous per rank (or wrapped for the small tables): generate in runs of consecutive ids
@@ -833,6 +837,22 @@ def run(job, args):
                                                "chosen per stream for ~6.25 kB per picture (the service's 1.5 Mbit/s profile, reference "
                                                "indexer/indexer.cpp:306-309), every picture gated against the reference decoder",
                                        **stage_report(ow, min(args.steps, 10))}
+        # The parse-parallelism lever of this shape (round-5 verdict item 4): 5 slices x 12 pictures x 1024 streams are 61 k parse
+        # lanes -- 960 waves, less than one per SIMD -- so the 12-picture call is bound by the longest lanes' token chains; the
+        # same streams at 36 and 72 pictures per call (the streaming adapter cuts windows of up to 30)
+        # give the parser three and six times the lanes.  Every picture gated against the reference's hashes of these streams.
+        curve = {12: {"frames_per_s": others["wide_slices_1500k"]["frames_per_s"], "ms_per_step": others["wide_slices_1500k"]["ms_per_step"],
+                      "serial_stage_ms": others["wide_slices_1500k"].get("serial_stage_ms")}}
+        for pics in (36, 72):
+            wsteps = max(2, min(args.steps, 10) * 12 // pics)
+            o2 = run_workload(job, args, f"wide1500k_p{pics}", S, np.arange(S) % 1024, threads, wsteps, 1)
+            rep = stage_report(o2, wsteps)
+            curve[pics] = {"frames_per_s": rep["frames_per_s"], "ms_per_step": rep["ms_per_step"], "serial_stage_ms": rep.get("serial_stage_ms"),
+                           "steps": wsteps}
+        others["wide_slices_1500k"]["pictures_per_call"] = {
+            "what": "the same 5-slice 1.5 Mbit/s streams at 12 / 36 / 72 pictures per stream and efx_decode call (one, three, six GOPs): "
+                    "frames/s of back-to-back calls and the stages one call at a time",
+            **{str(k): v for k, v in curve.items()}}
         others["vmedia_x%d" % S] = run_clip(job, args, "vmedia", S, max(2, min(args.steps, 5)))
 
     log("leg: video out")

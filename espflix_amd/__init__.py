@@ -23,7 +23,7 @@ STRIPS = 12
 STRIP_BYTES = 8448
 FRAME_BYTES = 101376
 
-OPT_GROUPS, OPT_PARSE_CAP, OPT_RECON_MODE, OPT_RECON_WAVES, OPT_RECON_SPINS, OPT_RECON_ITEMS, OPT_SBC_SERIAL = 1, 2, 3, 4, 5, 6, 7   # efx_option
+OPT_GROUPS, OPT_PARSE_CAP, OPT_RECON_MODE, OPT_RECON_WAVES, OPT_RECON_SPINS, OPT_RECON_ITEMS, OPT_SBC_SERIAL, OPT_DEMUX_FUSED = 1, 2, 3, 4, 5, 6, 7, 8   # efx_option
 SBC_PROBE_FIRST = 1
 FORMAT_ES = 0
 FORMAT_TS = 1

@@ -25,6 +25,8 @@ struct DemuxChunk;
 __global__ void k_demux_scan(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, DemuxChunk*);
 __global__ void k_demux_offsets(const uint32_t*, const uint32_t*, DemuxChunk*, uint8_t*, const uint64_t*, uint32_t*, uint32_t*);
 __global__ void k_demux(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, const DemuxChunk*, uint8_t*, PesEntry*);
+__global__ void k_demux_fused(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, DemuxChunk*, uint8_t*, PesEntry*, uint32_t*, uint32_t*,
+                              uint32_t*);
 __global__ void k_demux_audio_scan(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, DemuxChunk*);
 __global__ void k_demux_audio_offsets(const uint32_t*, const uint32_t*, DemuxChunk*, uint32_t*);
 __global__ void k_demux_audio(const uint8_t*, const uint64_t*, const uint32_t*, const uint32_t*, const DemuxChunk*, uint8_t*, const uint64_t*);
@@ -228,6 +230,7 @@ struct efx_ctx {
     size_t sbc_info_cap = 0;             // in frames: streams x (frames + 1)
     size_t sbc_gran_cap = 0;             // in granules: streams x ceil(frames / 8)
     int opt_sbc_serial = 0;              // 1 = every stream through k_sbc, one wave per stream (the tests' comparison)
+    int opt_demux_fused = 0;             // 1 = TS input through the one-pass demultiplexer (k_demux_fused: measured slower, kept as an option)
     bool sbc_flags_clean = false;        // d_sbc_flags[0, n) all kSbcRegularFlag (k_sbc_finish leaves them so)
     uint64_t* d_hash = nullptr;
 
@@ -599,6 +602,8 @@ int efx_create(const efx_config* cfg, efx_ctx** out)
             ctx->opt_recon_mode = atoi(v);
         if (const char* v = getenv("EFX_RECON_WAVES"))
             ctx->opt_recon_waves = atoi(v);
+        if (const char* v = getenv("EFX_DEMUX_FUSED"))
+            ctx->opt_demux_fused = atoi(v) != 0;
         if (const char* v = getenv("EFX_RECON_ITEMS"))
             ctx->opt_recon_items = atoi(v);
         if (const char* cap = getenv("EFX_PARSE_WG_CAP"))  // (development: 0 = no cap)
@@ -743,7 +748,8 @@ static int ensure_ts_buffers(efx_ctx* ctx)
     ctx->pes_cap = ctx->es_cap / 188 + n_max;
     hipError_t e = dalloc(&ctx->d_ts, ctx->es_cap);
     if (e == hipSuccess)
-        e = dev_alloc(reinterpret_cast<void**>(&ctx->d_demux_chunks), (ctx->pes_cap / kDemuxChunk + n_max + 2) * 16);
+        // (the chunk descriptors, and behind them one ticket counter per stream for the one-pass kernel: zeroed together)
+        e = dev_alloc(reinterpret_cast<void**>(&ctx->d_demux_chunks), (ctx->pes_cap / kDemuxChunk + n_max + 2) * 16 + n_max * sizeof(uint32_t));
     for (auto& u : ctx->up) {
         if (e == hipSuccess) e = dalloc(&u.d_ts_len, n_max);
         if (e == hipSuccess) e = dalloc(&u.d_pkt_base, n_max);
@@ -942,12 +948,24 @@ static int upload_streams(efx_ctx* ctx, int n_streams, const uint8_t* const* dat
             for (int i = 0; i < n_streams; i++)
                 max_len = std::max(max_len, len[i]);
             const unsigned chunks = (unsigned)std::max<size_t>(1, (max_len / 188 + kDemuxChunk - 1) / kDemuxChunk);
-            hipLaunchKernelGGL(k_demux_scan, dim3(chunks, n_streams), dim3(kDemuxThreads), 0, st, ctx->d_ts, u.d_stream_off, u.d_ts_len, u.d_pkt_base,
-                               ctx->d_demux_chunks);
-            hipLaunchKernelGGL(k_demux_offsets, dim3(n_streams), dim3(64), 0, st, u.d_ts_len, u.d_pkt_base, ctx->d_demux_chunks, u.d_es,
-                               u.d_stream_off, u.d_es_len, u.d_pes_count);
-            hipLaunchKernelGGL(k_demux, dim3(chunks, n_streams), dim3(kDemuxThreads), 0, st, ctx->d_ts, u.d_stream_off, u.d_ts_len, u.d_pkt_base,
-                               ctx->d_demux_chunks, u.d_es, u.d_pes);
+            if (kDemuxThreads == 64 && ctx->opt_demux_fused) {
+                // one pass, one launch: tickets + decoupled look-back over the chunk descriptors (k_demux.hip); both zeroed here.
+                // The tickets sit in front of the descriptors this batch uses, so that ONE memset covers them.
+                const size_t n_desc = packets / kDemuxChunk + (size_t)n_streams + 2;
+                uint8_t* const desc_bytes = reinterpret_cast<uint8_t*>(ctx->d_demux_chunks);
+                uint32_t* tickets = reinterpret_cast<uint32_t*>(desc_bytes + (ctx->pes_cap / kDemuxChunk + (size_t)ctx->cfg.max_streams + 2) * 16);
+                EFX_HIP(hipMemsetAsync(desc_bytes, 0, n_desc * 16, st));
+                EFX_HIP(hipMemsetAsync(tickets, 0, (size_t)n_streams * sizeof(uint32_t), st));
+                hipLaunchKernelGGL(k_demux_fused, dim3(chunks, n_streams), dim3(kDemuxThreads), 0, st, ctx->d_ts, u.d_stream_off, u.d_ts_len,
+                                   u.d_pkt_base, ctx->d_demux_chunks, u.d_es, u.d_pes, tickets, u.d_es_len, u.d_pes_count);
+            } else {
+                hipLaunchKernelGGL(k_demux_scan, dim3(chunks, n_streams), dim3(kDemuxThreads), 0, st, ctx->d_ts, u.d_stream_off, u.d_ts_len, u.d_pkt_base,
+                                   ctx->d_demux_chunks);
+                hipLaunchKernelGGL(k_demux_offsets, dim3(n_streams), dim3(64), 0, st, u.d_ts_len, u.d_pkt_base, ctx->d_demux_chunks, u.d_es,
+                                   u.d_stream_off, u.d_es_len, u.d_pes_count);
+                hipLaunchKernelGGL(k_demux, dim3(chunks, n_streams), dim3(kDemuxThreads), 0, st, ctx->d_ts, u.d_stream_off, u.d_ts_len, u.d_pkt_base,
+                                   ctx->d_demux_chunks, u.d_es, u.d_pes);
+            }
         }
         if (ctx->timing) {
             EFX_HIP(hipEventRecord(u.ev_demux[1], st));
@@ -1085,6 +1103,9 @@ int efx_set_option(efx_ctx* ctx, int option, int value)
     case EFX_OPT_SBC_SERIAL:
         ctx->opt_sbc_serial = value != 0;
         return EFX_OK;
+    case EFX_OPT_DEMUX_FUSED:
+        ctx->opt_demux_fused = value != 0;
+        return EFX_OK;
     default:
         return EFX_ERR_ARG;
     }
@@ -1102,6 +1123,7 @@ int efx_get_option(efx_ctx* ctx, int option, int* value)
     case EFX_OPT_RECON_WAVES: *value = ctx->opt_recon_waves; return EFX_OK;
     case EFX_OPT_RECON_ITEMS: *value = ctx->opt_recon_items; return EFX_OK;
     case EFX_OPT_SBC_SERIAL: *value = ctx->opt_sbc_serial; return EFX_OK;
+    case EFX_OPT_DEMUX_FUSED: *value = ctx->opt_demux_fused; return EFX_OK;
     case EFX_OPT_RECON_SPINS: {
         int r = sync_all(ctx);
         if (r)

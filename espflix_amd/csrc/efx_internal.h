@@ -159,6 +159,7 @@ constexpr int kDemuxChunk = EFX_DEMUX_CHUNK;
 #define EFX_DEMUX_THREADS 64
 #endif
 constexpr int kDemuxThreads = EFX_DEMUX_THREADS;
+constexpr uint32_t kDemuxFailedFlag = 0x80000000u;  // in a stream's PES count: k_demux_fused gave up on it (k_index: EFX_STREAM_INTERNAL)
 static_assert(kDemuxChunk % 4 == 0 && kDemuxChunk >= 4 && kDemuxChunk <= 256, "k_demux stages whole 16-byte groups");
 
 // SBC synthesis tables (sbc_decoder.cpp:41-71), generated from the A2DP definitions

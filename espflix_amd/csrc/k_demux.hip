@@ -285,12 +285,89 @@ __device__ __forceinline__ void demux_offsets_body(const uint32_t* __restrict__ 
     }
 }
 
-// grid = (chunks, streams), block = 256
-template <bool AUDIO>
+// ---- one pass, one launch (video; round 6) ------------------------------------------------------------------------------------
+// The three launches above read the transport stream twice (the scan touches every line for four header bytes a packet) and
+// pay two launch boundaries for a prefix over a few chunk totals.  Fused: a chunk's wave stages its packets ONCE, parses them,
+// publishes the chunk's totals, and gets its base -- the totals of the stream's chunks before it -- by DECOUPLED LOOK-BACK
+// (Merrill & Garland): one 64-bit descriptor per chunk, {state, PES-with-PTS count, payload bytes}, state EMPTY -> AGGREGATE
+// (the chunk's own totals, published right after its local scan) -> INCLUSIVE (with everything before it); a wave reads the
+// descriptors of up to 64 predecessors at once, adds aggregates back to the first inclusive one, and never waits for more than
+// "that predecessor has parsed its 16 packets".
+//   * Which chunk a wave takes is a TICKET (one atomic add per wave on the stream's counter), not blockIdx.x: tickets are
+//     handed out in the order waves actually start, so every predecessor a wave waits for is running or done -- no order of
+//     dispatch is assumed (HIP promises none).  The wait is bounded all the same (wall clock): a lost descriptor flags the
+//     stream (EFX_STREAM_INTERNAL) instead of hanging the device.
+//   * Descriptors and tickets are 8- / 4-byte agent-scope atomics on both sides (relaxed: the descriptor IS the data; a valid
+//     hand-off form of MI355X_MICROARCH.md, "8-B agent atomics both sides"); the host zeroes them before the launch.
+//   * The stream's last chunk knows the stream's totals: it writes es_len / pes_count, the end-of-data tail and the zero fill
+//     (k_demux_offsets' second half).  A stream without a whole packet is one empty chunk.
+constexpr uint64_t kDescAggregate = 1ull << 62, kDescInclusive = 2ull << 62, kDescFailed = 3ull << 62;
+constexpr int kDescPesShift = 36;  // bytes [35:0], PES-with-PTS count [61:36]
+__device__ __forceinline__ uint64_t desc_pack(uint64_t state, uint32_t bytes, uint32_t n_pes)
+{
+    return state | ((uint64_t)n_pes << kDescPesShift) | bytes;
+}
+
+// `my` = descriptor of chunk `c` of its stream (descriptors 16 bytes apart: the DemuxChunk slots); returns the totals of chunks
+// 0 .. c - 1 and publishes chunk c's inclusive totals.  false: gave up waiting.
+__device__ __forceinline__ bool demux_look_back(uint64_t* my, uint32_t c, uint32_t bytes, uint32_t n_pes, uint32_t& base_bytes,
+                                                uint32_t& base_pes)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    if (lane == 0)
+        __hip_atomic_store(my, desc_pack(c == 0 ? kDescInclusive : kDescAggregate, bytes, n_pes), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t sum_b = 0, sum_p = 0;
+    int32_t idx = (int32_t)c - 1;  // the nearest predecessor not yet accounted for
+    const unsigned long long t0 = wall_clock64();
+    while (idx >= 0) {
+        const int32_t mine = idx - (int32_t)lane;
+        uint64_t d = kDescInclusive;  // (lanes beyond chunk 0: nothing)
+        if (mine >= 0)
+            d = __hip_atomic_load(my - 2 * (ptrdiff_t)(c - (uint32_t)mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__ballot((d >> 62) == 3))  // a predecessor gave up: so does this chunk (the stream's last chunk reports it)
+            break;
+        const uint64_t empty = __ballot((d >> 62) == 0);
+        if (empty) {
+            if (wall_clock64() - t0 > 200000000ull)  // 2 s of the 100 MHz counter
+                break;
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        const uint64_t incl = __ballot((d >> 62) == 2);  // (lanes beyond chunk 0 count as inclusive with nothing in them)
+        // lanes 0 .. first inclusive one (or all 64 / down to chunk 0) contribute
+        const uint32_t stop = incl ? (uint32_t)__builtin_ctzll(incl) : 63u;
+        const bool take = lane <= stop && mine >= 0;
+        uint32_t vb = take ? (uint32_t)(d & 0xFFFFFFFFull) : 0u, vp = take ? (uint32_t)((d >> kDescPesShift) & 0x3FFFFFFu) : 0u;
+        vb = wave_incl_scan(vb);
+        vp = wave_incl_scan(vp);
+        sum_b += (uint32_t)__builtin_amdgcn_readlane((int)vb, 63);
+        sum_p += (uint32_t)__builtin_amdgcn_readlane((int)vp, 63);
+        if (incl) {
+            idx = -1;
+            break;
+        }
+        idx -= 64;
+    }
+    if (idx >= 0) {  // (left the loop without reaching an inclusive descriptor or chunk 0)
+        if (lane == 0)
+            __hip_atomic_store(my, kDescFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
+    base_bytes = (uint32_t)sum_b;
+    base_pes = (uint32_t)sum_p;
+    if (lane == 0 && c != 0)
+        __hip_atomic_store(my, desc_pack(kDescInclusive, base_bytes + bytes, base_pes + n_pes), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
+// grid = (chunks, streams), block = kThreads
+template <bool AUDIO, bool FUSED = false>
 __device__ __forceinline__ void demux_gather_body(const uint8_t* __restrict__ ts, const uint64_t* __restrict__ ts_off,
                                                   const uint32_t* __restrict__ ts_len, const uint32_t* __restrict__ pkt_base,
                                                   const DemuxChunk* __restrict__ chunks, uint8_t* __restrict__ es,
-                                                  const uint64_t* __restrict__ out_off, PesEntry* __restrict__ pes)
+                                                  const uint64_t* __restrict__ out_off, PesEntry* __restrict__ pes,
+                                                  uint32_t* __restrict__ tickets = nullptr, uint32_t* __restrict__ es_len = nullptr,
+                                                  uint32_t* __restrict__ pes_count = nullptr)
 {
     __shared__ uint4 sh_pkt4[kChunk * kTsPacket / 16 + 1];
     __shared__ uint32_t sh_prefix[kChunk + 1];  // exclusive prefix of payload bytes; [npk] = chunk total
@@ -300,16 +377,30 @@ __device__ __forceinline__ void demux_gather_body(const uint8_t* __restrict__ ts
 
     const int s = blockIdx.y;
     const int tid = threadIdx.x;
-    const uint32_t n_packets = ts_len[s] / kTsPacket, first = blockIdx.x * kChunk;  // a trailing partial packet is never read (player.cpp:459-468)
-    if (first >= n_packets)
+    const uint32_t n_packets = ts_len[s] / kTsPacket;  // a trailing partial packet is never read (player.cpp:459-468)
+    uint32_t chunk = blockIdx.x;
+    if (FUSED) {
+        static_assert(!FUSED || kThreads == 64, "the fused kernel is one wave per chunk");
+        uint32_t t = 0;
+        if (tid == 0)
+            t = atomicAdd(&tickets[s], 1u);
+        chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        const uint32_t n_chunks = max(1u, (n_packets + kChunk - 1) / kChunk);  // (a stream without a packet: one empty chunk)
+        if (chunk >= n_chunks)
+            return;
+    }
+    const uint32_t first = chunk * kChunk;
+    if (!FUSED && first >= n_packets)
         return;
     const uint8_t* src = ts + ts_off[s];
     uint8_t* dst = es + out_off[s];
     PesEntry* my_pes = AUDIO ? nullptr : pes + pkt_base[s];
-    const DemuxChunk base = chunks[chunk_slot(pkt_base[s], s) + blockIdx.x];
-    const uint32_t es_pos = base.bytes, n_pes = base.n_pes;
+    DemuxChunk base = {0, 0, 0, 0};
+    if (!FUSED)
+        base = chunks[chunk_slot(pkt_base[s], s) + chunk];
+    uint32_t es_pos = base.bytes, n_pes = base.n_pes;
     const uint8_t* pk = reinterpret_cast<const uint8_t*>(sh_pkt4);
-    const uint32_t npk = min((uint32_t)kChunk, n_packets - first);
+    const uint32_t npk = first < n_packets ? min((uint32_t)kChunk, n_packets - first) : 0u;
     // ---- 1. stage the chunk --------------------------------------------------------------
     {
         const uint4* g = reinterpret_cast<const uint4*>(src + (size_t)first * kTsPacket);  // (kChunk * 188 is a multiple of 16)
@@ -347,6 +438,49 @@ __device__ __forceinline__ void demux_gather_body(const uint8_t* __restrict__ ts
     }
     __syncthreads();
     const uint32_t total = sh_wave[0][0] + (kTwoWaves ? sh_wave[0][1] : 0u);
+    if (FUSED) {
+        // the chunk's totals are known: publish, and collect the chunks before it
+        uint64_t* my = reinterpret_cast<uint64_t*>(const_cast<DemuxChunk*>(chunks) + chunk_slot(pkt_base[s], s) + chunk);
+        const bool ok = demux_look_back(my, chunk, total, sh_wave[1][0], es_pos, n_pes);
+        const uint32_t n_chunks = max(1u, (n_packets + kChunk - 1) / kChunk);
+        if (!ok) {
+            // never expected (a descriptor that did not arrive within two seconds); the failure runs down the stream's chunks
+            // and its last chunk leaves an empty stream whose PES count carries the flag k_index turns into EFX_STREAM_INTERNAL
+            if (tid == 0 && chunk == n_chunks - 1) {
+                es_len[s] = 0;
+                pes_count[s] = kDemuxFailedFlag;
+            }
+            return;
+        }
+        if (chunk == n_chunks - 1) {
+            // the stream's last chunk: its totals, the end-of-data tail and the zero fill (MpegDecoder::more() at the end of
+            // data, player.cpp:456,469-473)
+            const uint32_t end = es_pos + total;
+            if (tid == 0) {
+                es_len[s] = end;
+                pes_count[s] = n_pes + sh_wave[1][0];
+            }
+            const uint32_t region = (uint32_t)(out_off[s + 1] - out_off[s]);
+            for (uint32_t d = (end >> 2) + tid; d * 4 < region; d += kThreads) {
+                const uint32_t o0 = d * 4;
+                uint32_t word = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t o = o0 + k;
+                    if (o >= end && o < end + kEsTailBytes) {
+                        const uint32_t t = o - end;  // 00 | 00 00 01 B7 | 00 00 01 B7
+                        const uint32_t byte = (t == 3 || t == 7) ? 0x01u : ((t == 4 || t == 8) ? 0xB7u : 0u);
+                        word |= byte << (k * 8);
+                    }
+                }
+                if (o0 >= end)
+                    *reinterpret_cast<uint32_t*>(dst + o0) = word;
+                else
+                    for (uint32_t o = end; o < o0 + 4; o++)
+                        dst[o] = (uint8_t)(word >> ((o & 3) * 8));
+            }
+        }
+    }
     if (wave < 2) {
         const uint32_t excl_n = incl_n - n + (wave ? sh_wave[0][0] : 0);
         const uint32_t excl_f = incl_f - has_pts + (wave ? sh_wave[1][0] : 0);
@@ -435,6 +569,16 @@ __global__ __launch_bounds__(kThreads) void k_demux(const uint8_t* __restrict__ 
                                                     PesEntry* __restrict__ pes)
 {
     demux_gather_body<false>(ts, stream_off, ts_len, pkt_base, chunks, es, stream_off, pes);
+}
+
+// video, one pass: grid (chunks, streams), one wave per chunk; `chunks` (descriptors) and `tickets` zeroed by the host
+__global__ __launch_bounds__(kThreads) void k_demux_fused(const uint8_t* __restrict__ ts, const uint64_t* __restrict__ stream_off,
+                                                          const uint32_t* __restrict__ ts_len, const uint32_t* __restrict__ pkt_base,
+                                                          DemuxChunk* __restrict__ chunks, uint8_t* __restrict__ es,
+                                                          PesEntry* __restrict__ pes, uint32_t* __restrict__ tickets,
+                                                          uint32_t* __restrict__ es_len, uint32_t* __restrict__ pes_count)
+{
+    demux_gather_body<false, kThreads == 64>(ts, stream_off, ts_len, pkt_base, chunks, es, stream_off, pes, tickets, es_len, pes_count);
 }
 
 // audio: the byte stream push_audio() receives (PID 0x101 / 0x102)

@@ -393,7 +393,12 @@ __global__ __launch_bounds__(64 * kIndexWaves) void k_index(
     // force is that of the newest PES whose payload starts at or before start_off + 1.
     if (pts_out) {
         const PesEntry* mp = pes + pkt_base[s];
-        const uint32_t np = pes_count[s];
+        uint32_t np = pes_count[s];
+        if (np & kDemuxFailedFlag) {  // (never expected: the one-pass demultiplexer gave up on this stream, k_demux.hip)
+            np = 0;
+            if (tid == 0)
+                atomicOr(&status[s], EFX_STREAM_INTERNAL);
+        }
         // the newest PES PTS of this upload, for k_advance: that kernel runs on the reconstruction stream, possibly
         // after a later upload has recycled this upload's lists -- it must not read them itself
         if (tid == 0)

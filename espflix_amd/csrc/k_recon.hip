@@ -84,9 +84,8 @@ __device__ inline void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v
 template <int kTable>
 __device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c)
 {
-    uint32_t r;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4" : "=v"(r) : "v"(a), "v"(b), "v"(c), "n"(kTable));
-    return r;
+    // (the builtin: behind an inline asm statement the hazard recognizer puts an `s_nop`)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, kTable);
 }
 
 __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

@@ -180,6 +180,20 @@ __global__ __launch_bounds__(256) void k_composite(const uint8_t* __restrict__ f
 //   i1 += i0 - sign * a1 - (i2 >> 7);   i2 += i1 - sign * a2;   with sign = i2 >= 0 ? 1 : -1.
 namespace {
 
+// One delta-sigma step costs a wave EIGHT vector instructions (round 6; ten before): the sign of i2 as a mask (one shift),
+// the feedback term (one shift), the two sign-dependent constants  i0 -+ a1  and  -+a2  each by ONE bit select on that mask
+// (v_bitop3_b32, full rate; compare + three selects before), i1 in two additions, i2 in one three-operand addition, and the
+// output bit folded into a running  nb = 2 nb + mask  (one v_add3_u32; the word is (nb - 1) & 0xFFFF).  At the batch the
+// service runs (1024 streams = 16 waves on 1024 SIMDs) a wave is alone on its SIMD and issues one instruction per 4.4 cycles
+// whatever it is (profiles/r6_valu_rates.md, `wave cyc`): the recurrence is serial per stream, so a stream-second costs
+// 48 000 samples x 32 steps x instructions per step x 4.4 cycles -- the instruction COUNT of the step is the lever.
+__device__ __forceinline__ uint32_t pdm_sel(uint32_t mask, uint32_t if_set, uint32_t if_clear)  // bit by bit: mask ? if_set : if_clear
+{
+    // (the builtin, not inline assembly: behind an asm statement the compiler's hazard recognizer puts an `s_nop`, and a wave
+    // that is alone on its SIMD pays 4.4 cycles for that like for any other instruction)
+    return __builtin_amdgcn_bitop3_b32(mask, if_set, if_clear, 0xCA);
+}
+
 __device__ __forceinline__ uint32_t pdm_sample(int32_t pcm, uint32_t& i0, uint32_t& i1, uint32_t& i2)
 {
     const uint32_t a1 = 38973;  // int32(0x7FFF * 1.18940)
@@ -189,16 +203,19 @@ __device__ __forceinline__ uint32_t pdm_sample(int32_t pcm, uint32_t& i0, uint32
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         i0 = (uint32_t)(((int32_t)(i0 + x)) >> 1);
-        uint32_t bits = 0;
+        const uint32_t c_pos = i0 - a1, c_neg = i0 + a1;  // what i1 gains besides the feedback, by the sign of i2
+        uint32_t nb = 0;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const bool pos = (int32_t)i2 >= 0;
+            uint32_t neg = (uint32_t)((int32_t)i2 >> 31);  // all ones: i2 < 0
+            asm("" : "+v"(neg));                           // (a mask, not a condition: the compiler would rebuild compare + selects)
             const uint32_t fb = (uint32_t)(((int32_t)i2) >> 7);
-            i1 += i0 - fb + (pos ? 0u - a1 : a1);
-            i2 += i1 + (pos ? 0u - a2 : a2);
-            bits = (bits << 1) | (pos ? 1u : 0u);
+            i1 = (i1 - fb) + pdm_sel(neg, c_neg, c_pos);
+            i2 = i2 + i1 + pdm_sel(neg, a2, 0u - a2);
+            nb = nb + nb + neg;
+            asm("" : "+v"(nb));  // (one v_lshl_add_u32 per step: left alone the compiler re-associates two steps into three instructions)
         }
-        word |= (bits & 0xFFFF) << (16 * half);  // consecutive uint16 words, little endian
+        word |= ((nb - 1u) & 0xFFFF) << (16 * half);  // consecutive uint16 words, little endian
     }
     return word;
 }

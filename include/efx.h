@@ -353,6 +353,9 @@ typedef enum efx_option {
                                 slot (default 16); 0 = as many as there are (a grid of what the chip holds) */
     EFX_OPT_SBC_SERIAL = 7,  /* 1 = efx_sbc_decode runs every stream through the one-wave-per-stream kernel (the comparison the tests
                                 run the frame-parallel kernels against); 0 = default */
+    EFX_OPT_DEMUX_FUSED = 8, /* 1 = transport-stream uploads run the ONE-PASS demultiplexer (a ticket per chunk, decoupled look-back over
+                                chunk descriptors, one launch: k_demux_fused) instead of scan / prefix / gather.  Bit-exact and tested,
+                                but measured slower (82 against 63 us per 48.8 MB: profiles/r6_demux.md) -- 0 = default */
     EFX_OPT_RECON_SPINS = 5  /* read only: polls the reconstruction waves of the most recent call spent waiting for a predecessor
                                 picture (synchronises) */
 } efx_option;

@@ -10,6 +10,9 @@ Writes (little-endian uint64, FNV-1a-64 of each pushed frame incl. the final flu
   bench_ionly.u64    [256][8]    SURVEY.md 8d config 2: stream ids 0..255, 8 I pictures (FLAG_I_ONLY)
   bench_wide1500k.u64 [1024][12] the service's stream shape: 5 slices per picture, ~6.25 kB per picture
                                  (FLAG_WIDE_SLICES | FLAG_RATE_1500K), ids 0..1023
+  bench_wide1500k_p36.u64 [1024][36], bench_wide1500k_p72.u64 [1024][72]  the same shape as streams of 36 / 72 pictures = three /
+                                 six GOP(12) (round 6: bench.py's pictures-per-call curve; the generator's rate control looks at
+                                 the whole stream, so a shorter stream is not a prefix of a longer one)
 bench.py compares every stream of its shard against these before the timed region; the -m gpu tests
 compare every stream of BASELINE configs[1] / configs[2]; a CPU test pins the C restatement to a sample.
 """
@@ -24,7 +27,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-SETS = [("bench_gop12.u64", 8192, 12, 12, 0), ("bench_ionly.u64", 256, 8, 12, 1), ("bench_wide1500k.u64", 1024, 12, 12, 4 | 32)]
+SETS = [("bench_gop12.u64", 8192, 12, 12, 0), ("bench_ionly.u64", 256, 8, 12, 1), ("bench_wide1500k.u64", 1024, 12, 12, 4 | 32),
+        ("bench_wide1500k_p36.u64", 1024, 36, 12, 4 | 32), ("bench_wide1500k_p72.u64", 1024, 72, 12, 4 | 32)]
 CHUNK = 64
 
 

@@ -206,3 +206,50 @@ def test_pts_carry_with_uploads_running_ahead_of_the_reconstruction(efx):
             assert pts == int(ref_pts[k]) and fh == int(ref_h[k]), (attempt, k)
         dec.close()
     big.close()
+
+
+def test_one_pass_demux_equals_three_launches_and_the_oracle(efx, clips):
+    """Round 6: the demultiplexer as ONE kernel -- a chunk's wave takes a ticket, stages its 16 packets once, publishes its totals and
+    gets its base by decoupled look-back over the stream's chunk descriptors (k_demux_fused, EFX_OPT_DEMUX_FUSED; measured slower than
+    scan / prefix / gather and not the default).  Both held against the oracle and against each other: a batch whose streams have 0, 1, 15,
+    16, 17 packets, no whole packet at all, hundreds of chunks (the look-back window is 64 descriptors: longer than that loops),
+    hostile muxing and both clips -- ES bytes, PTS lists (through the decoded pictures' PTS) and frames; uploaded five times over
+    so that descriptors and tickets of earlier uploads are shown to be cleared."""
+    from espflix_amd import gen
+    rng = np.random.default_rng(5)
+    b = gen.Batch(0, 8, 6)
+
+    def packets(n):  # n packets of one random ES, PES header with a PTS in the first
+        es = bytes(rng.integers(0, 256, max(0, 184 * n - 14), dtype=np.uint8))
+        out, pos = bytearray(), 0
+        for k in range(n):
+            head = common.pes_header(int(rng.integers(0, 1 << 33))) if k == 0 else b""
+            take = 184 - len(head)
+            out += common.ts_packet(0x100, head + es[pos:pos + take], pusi=k == 0)
+            pos += take
+        return bytes(out)
+
+    long_es = b.es(0).tobytes() * 24  # ~ 24 x 45 kB: > 5000 packets = > 320 chunks
+    blobs = [b"", packets(1), packets(15), packets(16), packets(17), b"\x47" * 100, packets(33) + b"\x47\x01", b.ts(1).tobytes(),
+             common.hostile_ts(b.es(2).tobytes(), 3), bytes(common.packetize(long_es, [(0, 129003, False, 0)], rng, noise=False)),
+             clips["splash"].tobytes(), clips["vmedia"].tobytes()] + [b.ts(k).tobytes() for k in range(3, 8)]
+    cap = sum(len(x) for x in blobs) + 64 * len(blobs) + 4096
+    got = {}
+    for three in (0, 1):  # the one-pass kernel first
+        dec = efx.Decoder(max_streams=len(blobs), max_pictures=100, ring_depth=2, max_stream_bytes=cap)
+        dec.set_option(efx.OPT_DEMUX_FUSED, 1 - three)
+        for rep in range(5 if not three else 1):
+            order = list(range(len(blobs))) if rep % 2 == 0 else list(range(len(blobs)))[::-1]
+            dec.upload([blobs[i] for i in order], efx.FORMAT_TS)
+            dec.decode()
+            es = {order[j]: dec.es(j) for j in range(len(blobs))}
+            pts = {order[j]: [dec.picture_pts(j, p) for p in range(dec.picture_count(j))] for j in range(len(blobs))}
+            st = {order[j]: dec.stream_status(j) for j in range(len(blobs))}
+            if (three, rep) == (0, 0):
+                for i, ts in enumerate(blobs):
+                    want = oracle.ts_to_es(np.frombuffer(ts, dtype=np.uint8)).tobytes()
+                    assert es[i] == want, (i, len(es[i]), len(want))
+                got = (es, pts, st)
+            else:
+                assert es == got[0] and pts == got[1] and st == got[2], (three, rep)
+        dec.close()
