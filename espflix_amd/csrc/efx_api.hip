@@ -195,7 +195,14 @@ struct efx_ctx {
     };
     Group groups[kMaxGroups];  // reconstruction groups of the most recent efx_decode
     int n_groups = 0;
-    hipEvent_t last_recon_done = nullptr;  // end of the most recently queued reconstruction group (k_parse's cap, efx_decode_range)
+    hipEvent_t last_recon_done = nullptr;  // end of the most recently queued reconstruction group
+    // Reconstruction groups queued since the host last KNEW the reconstruction stream idle (context creation, any call that
+    // synchronises it: sync_all).  The launch structure of a decode call is decided from this count, not from a hipEventQuery of
+    // the stream (round 5: a race against the GPU -- the same call sequence could run different launches from run to run):
+    // 0 = the call finds the stream idle by the library's own book-keeping (it is split into groups, its first parse half may
+    // have the whole chip), otherwise it pipelines against what is queued (one group, capped parser).  A caller that lets the
+    // GPU drain WITHOUT synchronising is treated as back to back: that costs the one call some latency, never a result.
+    uint64_t recon_groups_unsynced = 0;
     int last_upload = 0;       // batch the most recent efx_decode read
     int last_n_streams = 0;    // ... its stream count and format, as they were when the decode was queued (a later upload may
     bool last_ts_input = false;  // have recycled the Upload record by the time the results are fetched)
@@ -435,6 +442,7 @@ int sync_all(efx_ctx* ctx)
     for (auto ps : ctx->parse_streams)
         EFX_HIP(hipStreamSynchronize(ps));
     EFX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->recon_groups_unsynced = 0;
     return EFX_OK;
 }
 
@@ -1179,6 +1187,7 @@ int efx_reset(efx_ctx* ctx)
     }
     EFX_HIP(hipMemcpyAsync(ctx->d_state, init.data(), n * sizeof(StreamState), hipMemcpyHostToDevice, ctx->stream));
     EFX_HIP(hipStreamSynchronize(ctx->stream));  // (pageable source)
+    ctx->recon_groups_unsynced = 0;  // (the host knows the reconstruction stream idle)
     return EFX_OK;
 }
 
@@ -1245,8 +1254,7 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
     // fatter reconstruction launches have fewer draining tails.  A call that finds the reconstruction stream idle (one call
     // at a time) has nothing to pipeline against but itself: it runs as groups of kGroupStreams streams, the parse half of
     // group g + 1 beside the reconstruction of group g.  Results do not depend on the split.
-    const bool idle_at_call = !(ctx->last_recon_done && hipEventQuery(ctx->last_recon_done) == hipErrorNotReady);
-    (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+    const bool idle_at_call = ctx->recon_groups_unsynced == 0;  // (by the library's own count: efx_ctx::recon_groups_unsynced)
     // (efx_set_option pins the structure: the same call sequence then runs the same launches whatever the timing)
     const int G = ctx->opt_groups > 0 ? std::min(std::min(ctx->opt_groups, kMaxGroups), std::max(1, n_all / 8))
                                       : (idle_at_call ? group_count(n_all) : 1);
@@ -1347,9 +1355,7 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
             // The cap protects the reconstruction launches the parser runs beside.  When the reconstruction stream has
             // nothing queued at this moment -- one call at a time, the first call after a synchronisation -- the parser
             // may have the chip: 0.84 instead of 1.38 ms per 1024 streams x 12 pictures.
-            const bool recon_busy = ctx->opt_parse_cap == 1 ||
-                                    (ctx->opt_parse_cap == 0 && ctx->last_recon_done && hipEventQuery(ctx->last_recon_done) == hipErrorNotReady);
-            (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+            const bool recon_busy = ctx->opt_parse_cap == 1 || (ctx->opt_parse_cap == 0 && ctx->recon_groups_unsynced > 0);
             if (ctx->parse_wg_cap > 0 && recon_busy)
                 parse_wgs = std::min(parse_wgs, ctx->parse_wg_cap);
             hipLaunchKernelGGL(k_parse, dim3(parse_wgs), dim3(64 * kParseWaves), 0, sp, u.d_es,
@@ -1394,6 +1400,7 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
             EFX_HIP(hipEventRecord(te0->ev[3], sr));
         EFX_HIP(hipEventRecord(sl.recon_done, sr));
         ctx->last_recon_done = sl.recon_done;
+        ctx->recon_groups_unsynced++;
     }
     EFX_HIP(hipGetLastError());
     ctx->decoded = true;
@@ -1542,6 +1549,7 @@ int efx_download_frame(efx_ctx* ctx, int stream, int slot, uint8_t* dst)
     if (r || !dst)
         return r ? r : EFX_ERR_ARG;
     EFX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->recon_groups_unsynced = 0;  // (the host knows the reconstruction stream idle)
     EFX_HIP(hipMemcpy(dst, p, kFrameBytes, hipMemcpyDeviceToHost));
     return EFX_OK;
 }
@@ -1554,6 +1562,7 @@ int efx_upload_frame(efx_ctx* ctx, int stream, int slot, const uint8_t* src)
     if (r || !src)
         return r ? r : EFX_ERR_ARG;
     EFX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->recon_groups_unsynced = 0;  // (the host knows the reconstruction stream idle)
     EFX_HIP(hipMemcpy(p, src, kFrameBytes, hipMemcpyHostToDevice));
     return EFX_OK;
 }
@@ -1569,6 +1578,7 @@ int efx_frame_hashes(efx_ctx* ctx, int first_stream, int n, uint64_t* out)
                        ctx->d_frames + (size_t)first_stream * D * kFrameBytes, frames, ctx->d_hash);
     EFX_HIP(hipGetLastError());
     EFX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->recon_groups_unsynced = 0;  // (the host knows the reconstruction stream idle)
     EFX_HIP(hipMemcpy(out, ctx->d_hash, (size_t)frames * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return EFX_OK;
 }
@@ -2056,6 +2066,7 @@ int efx_debug_poke(efx_ctx* ctx, void* dptr, size_t bytes, long long offset_byte
     hipLaunchKernelGGL(k_fill, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<uint32_t*>(at), 0xDEADBEEFu, (size_t)1);
     EFX_HIP(hipGetLastError());
     EFX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->recon_groups_unsynced = 0;  // (the host knows the reconstruction stream idle)
     return EFX_OK;
 }
 
@@ -2100,6 +2111,7 @@ int efx_memcpy_h2d(efx_ctx* ctx, void* dst_device, const void* src, size_t bytes
     if (!ctx || !dst_device || !src)
         return EFX_ERR_ARG;
     EFX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->recon_groups_unsynced = 0;  // (the host knows the reconstruction stream idle)
     EFX_HIP(hipMemcpy(dst_device, src, bytes, hipMemcpyHostToDevice));
     return EFX_OK;
 }
@@ -2110,6 +2122,7 @@ int efx_memcpy_d2h(efx_ctx* ctx, void* dst, const void* src_device, size_t bytes
     if (!ctx || !dst || !src_device)
         return EFX_ERR_ARG;
     EFX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->recon_groups_unsynced = 0;  // (the host knows the reconstruction stream idle)
     EFX_HIP(hipMemcpy(dst, src_device, bytes, hipMemcpyDeviceToHost));
     return EFX_OK;
 }

@@ -97,7 +97,7 @@ static_assert(sizeof(MbRec) == 16, "MbRec must be 16 bytes");
 
 // scan / quantiser table of k_index and k_recon (the VLC tables of the slice parser are parse_tm.h's TmTables)
 struct ParseTables {
-    uint32_t scan[64];       // scan position n -> zz | premul << 8 | default intra q << 16 | 16 << 24
+    uint32_t scan[64];       // scan position n -> zz | slot in k_recon's paired block layout << 8 | default intra q << 16 | 16 << 24
 };
 
 struct DecodeCounters {

@@ -27,10 +27,16 @@ void build_parse_tables(ParseTables* t)
     s[0] = 1.0;
     for (int k = 1; k < 8; k++)
         s[k] = std::sqrt(2.0) * std::cos(k * M_PI / 16);
+    (void)s;  // (k_recon scales by the pre-multipliers as compile-time constants: premul_at(), k_recon.hip)
     for (int n = 0; n < 64; n++) {
         int zz = kZigZag[n];
-        int premul = (int)std::floor(32.0 * s[zz >> 3] * s[zz & 7] + 0.5);
-        t->scan[n] = (uint32_t)zz | ((uint32_t)premul << 8) | ((uint32_t)kDefaultIntraQ[zz] << 16) | (16u << 24);
+        // Where raster position zz = 8 r + c sits in k_recon's per-lane block of 64 int16 (round 6): column by column, and
+        // inside a column the rows in the PAIRS the butterfly's first stage combines -- (0,4) (2,6) (1,7) (3,5), one pair per
+        // dword -- so that a dword read + one v_dot2_i32_i16 with the two pre-multipliers packed in a constant delivers
+        // x_a p_a + x_b p_b (or the difference) directly.
+        static const int kRowSlot[8] = {0, 4, 2, 6, 1, 7, 3, 5};  // row -> 2 * pair + half
+        int slot = (zz & 7) * 8 + kRowSlot[zz >> 3];
+        t->scan[n] = (uint32_t)zz | ((uint32_t)slot << 8) | ((uint32_t)kDefaultIntraQ[zz] << 16) | (16u << 24);
     }
 }
 

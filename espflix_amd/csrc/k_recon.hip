@@ -52,17 +52,13 @@ __device__ inline int mad24(int a, int k, int c)
 // and AC coefficients are clamped to +-2048 and scaled by a premultiplier <= 62, which bounds the
 // operands by 2^19 in the column pass and 2^22.5 in the row pass (L1 norm of the linear map).  The
 // low 32 bits of the 48-bit product equal the reference's wrapped 32-bit product.
-__device__ inline void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v5, int& v6, int& v7, int half)
+// (the butterfly from its first stage on: the sums and differences of the input pairs (0,4) (2,6) (1,7) (3,5))
+__device__ inline void idct8_paired(int dc_sum, int dc_dif, int c_sum, int c_dif, int p17, int m17, int p35, int m53, int& v0, int& v1,
+                                    int& v2, int& v3, int& v4, int& v5, int& v6, int& v7, int half)
 {
-    // even half: inputs 0, 4 as sum / difference; inputs 2, 6 through one rotation (362 / 256)
-    const int dc_sum = v0 + v4, dc_dif = v0 - v4;
-    const int c_sum = v2 + v6;
-    const int c_rot = (mad24(v2 - v6, 362, half) >> 8) - c_sum;
+    const int c_rot = (mad24(c_dif, 362, half) >> 8) - c_sum;
     const int even0 = dc_sum + c_sum, even3 = dc_sum - c_sum;
     const int even1 = dc_dif + c_rot, even2 = dc_dif - c_rot;
-    // odd half: inputs 1, 7 and 3, 5 as sums and differences, three rotations (473, 196, 362 over 256)
-    const int p17 = v1 + v7, m17 = v1 - v7;
-    const int p35 = v3 + v5, m53 = v5 - v3;
     const int odd_all = p17 + p35;
     const int odd_a = (mad24(m17, 473, mad24(m53, -196, half)) >> 8) - odd_all;
     const int odd_b = odd_a - (mad24(p17 - p35, 362, half) >> 8);
@@ -76,6 +72,12 @@ __device__ inline void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v
     v5 = even2 + odd_b;
     v3 = even3 - odd_c;
     v4 = even3 + odd_c;
+}
+__device__ inline void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v5, int& v6, int& v7, int half)
+{
+    // even half: inputs 0, 4 as sum / difference; inputs 2, 6 through one rotation (362 / 256);
+    // odd half: inputs 1, 7 and 3, 5 as sums and differences, three rotations (473, 196, 362 over 256)
+    idct8_paired(v0 + v4, v0 - v4, v2 + v6, v2 - v6, v1 + v7, v1 - v7, v3 + v5, v5 - v3, v0, v1, v2, v3, v4, v5, v6, v7, half);
 }
 
 // v_bitop3_b32: any function of three words bit by bit, table index = a << 2 | b << 1 | c (a = 0xF0, b = 0xCC, c = 0xAA).
@@ -434,7 +436,7 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
                 if ((val & 1) == 0)
                     val -= (val > 0) ? 1 : -1;
                 val = val > 2047 ? 2047 : (val < -2048 ? -2048 : val);
-                cfh[L * kLaneHalfwords + (t & 63)] = (int16_t)val;
+                cfh[L * kLaneHalfwords + ((t >> 8) & 63)] = (int16_t)val;  // (its slot in the paired layout, efx_tables.cpp)
             }
         }
     };
@@ -569,17 +571,39 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
         for (int i = 0; i < 64; i++)
             v[i] = 128;
     } else {
+    const uint32_t* mine32 = reinterpret_cast<const uint32_t*>(mine);
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        // column c: eight int16 from the private block, scaled by immediates, one butterfly
-#pragma unroll
-        for (int r = 0; r < 8; r++)
-            v[r * 8 + c] = __mul24((int)mine[r * 8 + c], premul_at(r, c));
+        // Column c (round 6): FOUR dwords from the private block -- the rows in the pairs the butterfly's first stage combines,
+        // (0,4) (2,6) (1,7) (3,5) (efx_tables.cpp lays the block out so) -- and the first stage INCLUDING the pre-multipliers
+        // as one v_dot2_i32_i16 per sum / difference, x_a p_a +- x_b p_b with the two pre-multipliers packed in a constant:
+        // eight instructions where eight multiplies and eight additions stood, and half the LDS reads.
+        auto dot = [](uint32_t pair, int pa, int pb) {
+            // (by name: the builtin is selected as v_dot2c_i32_i16, the accumulating two-operand form, plus a v_mov to clear
+            // its accumulator -- what the fusion saves)
+            int r;
+            asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(pair), "s"((uint32_t)(uint16_t)(short)pa | ((uint32_t)(uint16_t)(short)pb << 16)));
+            return r;
+        };
+        const uint32_t q04 = mine32[c * 4], q26 = mine32[c * 4 + 1], q17 = mine32[c * 4 + 2], q35 = mine32[c * 4 + 3];
+        int dc_sum, dc_dif;
         if (c == 0) {
-            v[0] = intra ? (dc_raw << 8) : v[0];
-            v[0] = dc_only ? (v[0] & ~0xFF) : v[0];
+            // the DC term: an intra block's is the parser's value << 8 (wider than the block's int16), and a block whose only
+            // coefficient it is has its low byte cleared (the reference's n == 1 shortcut, see above)
+            int v0 = __mul24((int)(int16_t)(q04 & 0xFFFF), premul_at(0, 0));
+            v0 = intra ? (dc_raw << 8) : v0;
+            v0 = dc_only ? (v0 & ~0xFF) : v0;
+            const int v4 = __mul24((int)q04 >> 16, premul_at(4, 0));
+            dc_sum = v0 + v4;
+            dc_dif = v0 - v4;
+        } else {
+            dc_sum = dot(q04, premul_at(0, c), premul_at(4, c));
+            dc_dif = dot(q04, premul_at(0, c), -premul_at(4, c));
         }
-        idct8(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c], half);
+        idct8_paired(dc_sum, dc_dif, dot(q26, premul_at(2, c), premul_at(6, c)), dot(q26, premul_at(2, c), -premul_at(6, c)),
+                     dot(q17, premul_at(1, c), premul_at(7, c)), dot(q17, premul_at(1, c), -premul_at(7, c)),
+                     dot(q35, premul_at(3, c), premul_at(5, c)), dot(q35, -premul_at(3, c), premul_at(5, c)),
+                     v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c], half);
         // one butterfly at a time (volatile asm statements keep their order): with all sixteen in
         // flight the temporaries push the kernel past 128 registers and an occupancy step
         asm volatile("" : "+v"(v[c]), "+v"(v[8 + c]), "+v"(v[16 + c]), "+v"(v[24 + c]), "+v"(v[32 + c]), "+v"(v[40 + c]),
