@@ -61,8 +61,24 @@ WORKLOADS = {
 }
 
 
-PDM_VALU_PER_STEP = 10.2          # VALU instructions per delta-sigma step and lane in k_pdm's main loop (hipcc -S)
-VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # int32 lane-operations per second, every SIMD-32 issuing a wave64 op per 2 cycles
+# ONE convention for vector-instruction issue (round 6; profiles/r6_valu_rates.md, measured by tools/exp/valu_rates.hip):
+# a SIMD issues a wave64 instruction of the FULL-rate class (v_add / v_sub / v_and / v_or / v_xor / v_mov / v_lshrrev / v_ashrrev /
+# v_bitop3 / v_fma_f32) every 2.2 cycles and of the HALF-rate class (everything else this path uses: 24-bit multiplies, byte
+# permutes, v_lerp_u8, packed 16-bit, v_bfi, v_cndmask, v_cmp, v_lshlrev, v_min / v_max, DPP) every 4.2; a wave that is ALONE on
+# its SIMD issues one instruction per 4.4 cycles whatever it is.  profiles/r6_issue_floor.json (tools/issue_floor.py) holds the
+# mix-weighted cycles per instruction of every kernel and, with rocprofv3's SQ_INSTS_VALU, its issue floor per launch.
+SIMDS, CLOCK_HZ = 256 * 4, 2.4e9
+PDM_VALU_PER_STEP = 9.3           # VALU instructions per delta-sigma step and lane in k_pdm's main loop (hipcc -S: 2382 per 8 samples = 256
+                                  # steps; 8 in the step itself, the rest is the sample's low-pass and the word assembly); 10.2 in round 5
+
+
+def issue_model():
+    """profiles/r6_issue_floor.json (kernel -> cycles per VALU instruction, dynamic VALU per launch), or {}."""
+    path = os.path.join(ROOT, "profiles", "r6_issue_floor.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f).get("kernels", {})
 
 
 def log(msg):
@@ -112,7 +128,7 @@ def pmc_traffic(kernel, S, P, key="kernels"):
     the figure is the one measured on this exact workload (1024 streams x GOP 12), None otherwise.
     The summary records a digest per kernel source file it was measured on; when the kernel's own file, a header or the
     table builder has changed since, the provenance says so and a warning goes to stderr."""
-    for name in ("r5_pmc_summary.json", "r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
+    for name in ("r6_pmc_summary.json", "r5_pmc_summary.json", "r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if (S, P) != (1024, 12) or not os.path.exists(path):
             continue
@@ -133,8 +149,12 @@ def pmc_traffic(kernel, S, P, key="kernels"):
         if moved:
             log(f"warning: {name} was measured before {', '.join(moved)} changed: roofline.traffic of {kernel} may be out of date "
                 f"(re-run tools/collect_profiles.sh)")
-        return v, {"file": "profiles/" + name, "stale": bool(moved), "changed_since": moved, "measured_on": measured_on, "this_run": this_run,
-                   "note": "separate rocprofv3 --pmc passes of this command, not this run"}
+        # (round-5 verdict: the two fields were empty whenever nothing had changed) what the passes were measured ON and what
+        # this run executes, always: the digest over all kernel sources, the collection's own note, and the files that differ
+        return v, {"file": "profiles/" + name, "stale": bool(moved), "changed_since": moved,
+                   "measured_on": {"kernel_sources_digest": doc.get("kernel_sources_digest"), "collected": doc.get("note", ""), "files": measured_on},
+                   "this_run": {"kernel_sources_digest": kernel_sources_digest(), "files": this_run},
+                   "note": "separate rocprofv3 --pmc passes of this command (tools/collect_profiles.sh), not this run"}
     return None, None
 
 
@@ -346,13 +366,15 @@ def run_video_out(job, args, S):
         raise SystemExit("parity gate (video_out): PDM words differ from the reference's pdm_second_order()")
     for bfr in (d_pcm, d_state, d_out):
         bfr.free()
+    pdm_cpi = issue_model().get("k_pdm", {}).get("cycles_per_valu", 3.0)
     out["pdm"] = {"what": "stream-seconds of 48 kHz audio modulated per second (32 delta-sigma steps per sample, one lane per stream: "
                           "the recurrence is serial, so the rate grows with the stream count until every SIMD holds waves -- 1024 "
                           "streams are 16 waves on a chip of 1024 SIMDs: an occupancy artefact, not a property of the kernel)",
-                  "bound": "valu",
-                  "valu_peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                  "valu_peak_note": "256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md: a wave64 VALU instruction issues over "
-                                    "2 cycles); valu_frac = streams x samples x 32 steps x %.1f VALU instructions per step / time / peak" % PDM_VALU_PER_STEP,
+                  "bound": "valu_issue",
+                  "issue_note": "issue_frac = streams / 64 waves x samples x 32 steps x %.1f vector instructions per step x %.2f cycles per "
+                                "instruction (the kernel's mix at the measured rates, profiles/r6_issue_floor.json) / (1024 SIMDs x 2.4 GHz x "
+                                "time); at 1024 streams the 16 waves sit alone on 16 of the 1024 SIMDs and issue one instruction per ~4 cycles "
+                                "whatever its class: the time is samples x 32 x instructions per step x that interval" % (PDM_VALU_PER_STEP, pdm_cpi),
                   "by_streams": {}}
     for n_streams, samples in ((S, 48000), (16 * S, 9600), (64 * S, 4800), (256 * S, 2400)):
         d_pcm, d_state, d_out = dec.alloc(n_streams * samples * 2), dec.alloc(n_streams * 12), dec.alloc(n_streams * samples * 4)
@@ -365,10 +387,10 @@ def run_video_out(job, args, S):
         alg = n_streams * samples * 6
         # the recurrence's roof is the integer VALU, not HBM: 32 delta-sigma steps per sample, PDM_VALU_PER_STEP VALU
         # instructions per step and lane in the kernel's 8-sample loop body (hipcc -S: 2.6 k v_* for 256 steps)
-        lane_ops = n_streams * samples * 32 * PDM_VALU_PER_STEP / (ms * 1e-3)
+        wave_instr = (n_streams + 63) // 64 * samples * 32 * PDM_VALU_PER_STEP
         out["pdm"]["by_streams"][str(n_streams)] = {"samples_per_stream": samples, "ms_per_launch": ms,
                                                     "stream_seconds_per_s": n_streams * samples / 48000 / ms * 1e3,
-                                                    "valu_lane_ops_per_s": lane_ops, "valu_frac": lane_ops / VALU_PEAK_LANE_OPS,
+                                                    "issue_frac": wave_instr * pdm_cpi / (SIMDS * CLOCK_HZ * ms * 1e-3),
                                                     "achieved_GBs": alg / ms / 1e6, "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS}
         for bfr in (d_pcm, d_state, d_out):
             bfr.free()
@@ -844,7 +866,7 @@ def run(job, args):
         curve = {12: {"frames_per_s": others["wide_slices_1500k"]["frames_per_s"], "ms_per_step": others["wide_slices_1500k"]["ms_per_step"],
                       "serial_stage_ms": others["wide_slices_1500k"].get("serial_stage_ms")}}
         for pics in (36, 72):
-            wsteps = max(2, min(args.steps, 10) * 12 // pics)
+            wsteps = max(4, min(args.steps, 10))  # (as many CALLS as the 12-picture leg: a region of two calls is all fill and drain)
             o2 = run_workload(job, args, f"wide1500k_p{pics}", S, np.arange(S) % 1024, threads, wsteps, 1)
             rep = stage_report(o2, wsteps)
             curve[pics] = {"frames_per_s": rep["frames_per_s"], "ms_per_step": rep["ms_per_step"], "serial_stage_ms": rep.get("serial_stage_ms"),
@@ -891,6 +913,26 @@ def run(job, args):
     traffic, traffic_src = pmc_traffic("efx::" + recon_kernel, S, P)
     ptraffic, _ = pmc_traffic("efx::k_parse", S, P)
     serial_ms = r["serial_ms"]
+    # the issue floor of the kernels of a step, ONE convention (issue_model): dynamic vector instructions x the kernel's
+    # mix-weighted cycles per instruction / (1024 SIMDs x 2.4 GHz)
+    im = issue_model()
+    issue = None
+    bound = "hbm"
+    kr, kp = im.get("k_recon"), im.get("k_parse")
+    if kr and kr.get("dynamic_valu_per_launch") and recon_kernel == "k_recon" and S // G == 1024:
+        floor_launch_s = kr["dynamic_valu_per_launch"] * kr["cycles_per_valu"] / (SIMDS * CLOCK_HZ)
+        parse_floor_s = (kp["dynamic_valu_per_launch"] * kp["cycles_per_valu"] / (SIMDS * CLOCK_HZ)) if kp and kp.get("dynamic_valu_per_launch") else None
+        step_floor_s = floor_launch_s * L + (parse_floor_s or 0.0)
+        issue = {"unit": "SIMD issue cycles", "convention": "full-rate opcodes 2.2 cycles per wave64 instruction and SIMD, half-rate 4.2 "
+                 "(profiles/r6_valu_rates.md); floor = SQ_INSTS_VALU x mix-weighted cycles per instruction / (1024 SIMDs x 2.4 GHz)",
+                 "cycles_per_instruction": kr["cycles_per_valu"], "vector_instructions_per_launch": kr["dynamic_valu_per_launch"],
+                 "floor_us_per_launch": floor_launch_s * 1e6, "frac": floor_launch_s / dur_s,
+                 "serial_frac": floor_launch_s * L / (serial_ms[2] / 1e3),
+                 "k_parse_floor_us": parse_floor_s * 1e6 if parse_floor_s else None,
+                 "whole_step_floor_ms": step_floor_s * 1e3, "whole_step_frac": step_floor_s / (r["elapsed"] / steps),
+                 "source": "profiles/r6_issue_floor.json (tools/issue_floor.py)"}
+        # what the numbers say: the larger of the two fractions names the nearer roof
+        bound = "valu_issue" if issue["frac"] > achieved / HBM_PEAK_GBS else "hbm"
     out = {
         "metric": "MPEG-1 352x192 frames/s", "value": value, "unit": "frames/s", "n_gpus": world,
         "steps": steps, "warmup": args.warmup, "ms_per_step": r["elapsed"] / steps * 1e3,
@@ -900,9 +942,16 @@ def run(job, args):
                    "streams_per_gpu": S, "streams_total": S * world, "pictures_per_stream": P, "es_bytes_per_gpu": r["es_bytes"],
                    "mean_bytes_per_picture": r["es_bytes"] / (S * P), "parallelism": f"stream-partition x{world}",
                    "coefficients_per_gpu": r["n_coefs"], "ring_depth": 2},
-        "roofline": {"bound": "hbm", "limiter": "what a CU can issue and turn around with its 12-14 resident waves, not any one wave's chain: 25 600 waves per launch living 10.6 us each (record 1.5 us -> owner search, entry loads, dequantisation 5.9 us -> IDCT, sum, stores 2.8 us); the same 1.25-1.3 items per us and CU whether the pictures are twelve launches or one (k_recon_all: record fetched an item ahead, no launch tails -- on a par alone, 3 % shorter beside the parser, profiles/r5_recon_all.md), and between 10 and 16 resident waves per CU; with all pixel and coefficient traffic removed a launch still takes 53 of 81 us (instruction issue, profiles/r4_ablations.md); DESIGN.md section 6", "kernel": names[2], "achieved": achieved,
+        "roofline": {"bound": bound, "bound_note": "achieved / peak / frac are SURVEY 8d's algorithmic bytes against the HBM roofline, as the "
+                     "contract asks; the resource this kernel is nearest to is vector-instruction ISSUE (`issue`): its arithmetic at the "
+                     "measured opcode rates (profiles/r6_valu_rates.md) fills issue.frac of the chip's SIMD cycles in the timed region and "
+                     "issue.serial_frac one call at a time, against %.2f of the HBM roofline -- the rest of a launch is the waves' dependent "
+                     "round trips at 12-14 resident waves per CU and the launch's fill and drain (profiles/r6_recon_vmem.md: neither fewer "
+                     "vector-memory instructions nor fewer vector instructions shorten it any more)" % (achieved / HBM_PEAK_GBS),
+                     "kernel": names[2], "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src,
+                     "issue": issue,
                      "algorithmic_bytes_per_launch": alg_launch, "avg_launch_ms": dur_s * 1e3, "launches_per_step": L,
                      "streams_per_launch": S // G, "pictures_per_launch": P * G // L,
                      "launch_structure": {"pinned": r.get("pinned", False), "mixed": r.get("mixed", 0), "groups": G, "parse_halves": r["halves"],

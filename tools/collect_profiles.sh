@@ -35,15 +35,17 @@ done
 # the video-out kernels (BASELINE configs[3]): kernel-trace stats and FETCH / WRITE passes of tools/bench_video.py
 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o video -- python tools/bench_video.py > $out/bench_video.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 150 rocprofv3 --pmc $c --output-format csv -d $out/vpmc_$c -o p -- python tools/bench_video.py > /dev/null 2>&1
+  timeout 150 rocprofv3 --pmc $c --output-format csv -d $out/vpmc_$c -o p -- python tools/bench_video.py > /dev/null 2>&1 < /dev/null
 done
+# (round 6) the instruction counts of the video / audio kernels, for their issue floors (tools/issue_floor.py)
+timeout 150 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $out/vpmc_SQ -o p -- python tools/bench_video.py > /dev/null 2>&1 < /dev/null
 # The merge back from the GPU box is limited to 64 MiB and the per-dispatch counter tables are 200 MB: they are condensed HERE
 # (tools/summarize_profiles.py, the same script that writes profiles/) and only the summary, the stats tables and the logs travel.
 python tools/summarize_profiles.py $1 --out $out/summary --stats $out/pipelined $out/serial $out/video \
-    --pmc $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_SQ --video-pmc $out/vpmc_FETCH_SIZE $out/vpmc_WRITE_SIZE \
+    --pmc $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_SQ --video-pmc $out/vpmc_FETCH_SIZE $out/vpmc_WRITE_SIZE $out/vpmc_SQ \
     --extra kernels_uncapped_parse=$out/pmcu_FETCH_SIZE,$out/pmcu_WRITE_SIZE \
             k_recon_queueing_18_waves_per_cu=$out/pmcq_1,$out/pmcq_2,$out/pmcq_3,$out/pmcq_4 \
             k_recon_queueing_14_waves_per_cu=$out/pmcq14_1,$out/pmcq14_2,$out/pmcq14_3,$out/pmcq14_4 \
-    --note "round 5: one MI355X, 1024 streams x GOP 12; kernels = PMC passes with the parse cap pinned (EFX_FORCE_PARSE_CAP=1: the schedule the timed region runs), kernels_uncapped_parse = the same one call at a time without it; k_recon_queueing_* = TA / TCP / SQ / LDS counters of k_recon per launch of 1024 streams at the shipped LDS footprint and padded to 14 waves per CU" > $out/summary.log 2>&1
+    --note "round 6 ($(date -u +%Y-%m-%d), box $(hostname)): one MI355X, 1024 streams x GOP 12; kernels = PMC passes with the parse cap pinned (EFX_FORCE_PARSE_CAP=1: the schedule the timed region runs), kernels_uncapped_parse = the same one call at a time without it; k_recon_queueing_* = TA / TCP / SQ / LDS counters of k_recon per launch of 1024 streams at the shipped LDS footprint and padded to 14 waves per CU" > $out/summary.log 2>&1
 rm -rf $out/pmc_* $out/pmcu_* $out/pmcq_? $out/pmcq14_? $out/vpmc_* $out/*_kernel_trace.csv $out/*_agent_info.csv
 grep "^{" $out/bench_pipelined.log | cut -c1-200; du -sh $out
