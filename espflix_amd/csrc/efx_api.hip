@@ -1378,9 +1378,14 @@ int efx_decode_range(efx_ctx* ctx, int first_picture, int n_pictures)
                            u.ts_input ? sl.d_pts : nullptr, u.ts_input ? sl.d_pts + (size_t)ctx->cfg.max_streams * P : nullptr, rs0, rn,
                            P, sl.d_call_pos);
         constexpr int kGroupsPerPicture = (kMbCount * 6 + 63) / 64;
+#ifdef EFX_RECON_ITEMS2
+        constexpr int kReconGridY = (kGroupsPerPicture + 1) / 2;  // (experiment: two block groups per wave, k_recon.hip)
+#else
+        constexpr int kReconGridY = kGroupsPerPicture;
+#endif
         if (ctx->opt_recon_mode == 0) {
             for (int p = 0; p < n_pictures; p++)
-                hipLaunchKernelGGL(k_recon, dim3(rn, kGroupsPerPicture), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs,
+                hipLaunchKernelGGL(k_recon, dim3(rn, kReconGridY), dim3(64), 0, sr, sl.d_mbrecs, sl.d_coefs,
                                    ctx->d_tables->scan, sl.d_qtab, ctx->d_frames, P, D, p, sl.d_call_pos, sl.epoch, rs0);
         } else if (rn > 0) {
             // ONE launch for all picture indices of the group: persistent waves pull (picture, stream, block group) items in

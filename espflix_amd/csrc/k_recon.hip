@@ -133,6 +133,7 @@ __device__ constexpr double kAan[8] = {1.0,          1.3870398453221475, 1.30656
 __device__ constexpr int premul_at(int r, int c) { return (int)(32.0 * kAan[r] * kAan[c] + 0.5); }
 
 constexpr int kBlocksPerPicture = kMbCount * 6;
+constexpr int kGroupsPerPictureK = (kBlocksPerPicture + 63) / 64;  // 25 groups of 64 blocks
 constexpr int kLaneDwords = 33, kLaneData = 32;  // per-lane LDS block: 64 int16 + one dword (see k_recon)
 constexpr int kLaneHalfwords = 2 * kLaneDwords;
 
@@ -740,6 +741,25 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
     EFX_PROBE_SET(6, (unsigned long long)pic | (unsigned long long)(epoch & 0xFF) << 8 | (unsigned long long)stream0 << 16);
     // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
     lds[lane * kLaneDwords + kLaneData] = scan_tab[lane];
+#if defined(EFX_RECON_ITEMS2)
+    // (experiment, round 6: TWO block groups per wave, the second group's record requested before the first group's work -- its
+    // round trip is off the chain for half the items; the grid is (streams, 13))
+    {
+        const int g0 = 2 * blockIdx.y, g1 = g0 + 1;
+        const MbRec* recs = mbrecs + ((size_t)s * max_pictures + pic) * kMbCount;
+        const uint4 rw0 = *reinterpret_cast<const uint4*>(recs + block_at(g0, lane).mb);
+        const uint4 rw1 = *reinterpret_cast<const uint4*>(recs + block_at(g1 < kGroupsPerPictureK ? g1 : g0, lane).mb);
+        recon_group<0, EFX_RECON_STORE>(lds, coefs, qtab_custom + ((size_t)s * max_pictures + pic) * 64, frames, ring_depth, pic, call_pos[2 * s],
+                                        call_pos[2 * s + 1], epoch, s, g0, rw0, [] {});
+        if (g1 < kGroupsPerPictureK) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            recon_group<0, EFX_RECON_STORE>(lds, coefs, qtab_custom + ((size_t)s * max_pictures + pic) * 64, frames, ring_depth, pic, call_pos[2 * s],
+                                            call_pos[2 * s + 1], epoch, s, g1, rw1, [] {});
+        }
+        return;
+    }
+#endif
     const BlockAt at = block_at(blockIdx.y, lane);
 #if defined(EFX_RECON_ABL) && EFX_RECON_ABL == 2
     uint32_t efx_abl_early[3];
