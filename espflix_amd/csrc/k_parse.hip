@@ -36,7 +36,11 @@ constexpr int kRingDwords = 16;  // per-lane bitstream ring in LDS (64 bytes)
 constexpr int kTripsPerTopup = EFX_TRIPS_PER_TOPUP;  // trips between two looks at the ring, the stage and who is alive
 constexpr int kRingLow = kTripsPerTopup + 4;  // top up when any lane of the wave has fewer dwords than this ahead (a trip consumes less
                                               // than a dword, the window reads two dwords ahead)
-constexpr int kStageWords = kTripsPerTopup <= 4 ? 8 : 16;  // parked stream words per lane (a power of two >= trips + 3)
+#ifndef EFX_DRAIN_WORDS
+#define EFX_DRAIN_WORDS 4  // stream words a lane stores at a time: 4 = one 16-byte store; 8 (experiment, round 6) = a whole 32-byte sector
+#endif
+constexpr int kDrainWords = EFX_DRAIN_WORDS;
+constexpr int kStageWords = (kTripsPerTopup <= 4 && kDrainWords == 4) ? 8 : 16;  // parked stream words per lane (a power of two >= trips + drain - 1)
 
 // Each lane owns a ring of kRingDwords big-endian dwords of ITS slice in LDS, laid out ring[k][lane] (a wave's accesses
 // hit 64 different banks).  Global memory is read in WAVE-SYNCHRONOUS top-ups: when any lane runs low every lane refills
@@ -127,9 +131,33 @@ struct StageSink {
     {
 #pragma unroll
         for (int rep = 0; rep < (kTripsPerTopup + 3) / 4; rep++)
+        if (kDrainWords == 8) {
+            // whole aligned 32-byte sectors: regions start (and an abandoned block rewinds) on multiples of four slots, so a lane
+            // whose position is an odd multiple of four stores one 16-byte half first
+            const uint32_t* g = stage + (flushed & (kStageWords - 4)) * 64;
+            if ((flushed & 4) && next - flushed >= 4) {
+                if (flushed + 3 <= coef_last)
+                    *reinterpret_cast<uint4*>(coefs + (size_t)flushed) = make_uint4(g[0], g[64], g[128], g[192]);
+                flushed += 4;
+            } else if (next - flushed >= 8) {
+                const uint32_t* h = stage + ((flushed + 4) & (kStageWords - 4)) * 64;
+                uint4* dst = reinterpret_cast<uint4*>(coefs + (size_t)flushed);
+                if (flushed + 3 <= coef_last)
+                    dst[0] = make_uint4(g[0], g[64], g[128], g[192]);
+                if (flushed + 7 <= coef_last)
+                    dst[1] = make_uint4(h[0], h[64], h[128], h[192]);
+                flushed += 8;
+            }
+        } else
         if (next - flushed >= 4) {
             const uint32_t* g = stage + (flushed & (kStageWords - 4)) * 64;
+#if defined(EFX_PARSE_ABL) && EFX_PARSE_ABL == 1
+            // (ablation, timing only -- wrong pictures: no stream word ever leaves the LDS ring; the upper bound of what any
+            // better store pattern could win, profiles/r6_recon_vmem.md)
+            if (flushed + 3 <= coef_last && g[0] == 0xDEADBEEFu && g[64] == 0x12345678u)
+#else
             if (flushed + 3 <= coef_last)  // (words beyond the slice's region are dropped: the slice is flagged)
+#endif
                 *reinterpret_cast<uint4*>(coefs + (size_t)flushed) = make_uint4(g[0], g[64], g[128], g[192]);
             flushed += 4;
         }
