@@ -39,6 +39,10 @@ __device__ inline unsigned long long* probe_claim(unsigned tag, unsigned wave, l
     return r;
 }
 }  // namespace efx
+// a device function that stamps on behalf of the kernel that claimed the record takes it as a trailing parameter
+#define EFX_PROBE_PARAM , unsigned long long* const efx_probe_rec
+#define EFX_PROBE_PASS , efx_probe_rec
+#define EFX_PROBE_PASS_NONE , (efx::g_probe + (size_t)(efx::kProbeRecords - 1) * 8)  // (the dump record: a caller that claimed none)
 #define EFX_PROBE_CLAIM(tag, wave) unsigned long long* const efx_probe_rec = efx::probe_claim(tag, wave)
 #define EFX_PROBE_CLAIM_AT(tag, wave, seq, when) unsigned long long* const efx_probe_rec = efx::probe_claim(tag, wave, seq, when)
 #define EFX_PROBE_STAMP(i)                        \
@@ -90,6 +94,9 @@ __device__ inline unsigned long long* probe_claim(unsigned tag, unsigned wave, l
     }
 #else
 #define EFX_PROBE_READER(name)
+#define EFX_PROBE_PARAM
+#define EFX_PROBE_PASS
+#define EFX_PROBE_PASS_NONE
 #define EFX_PROBE_CLAIM(tag, wave) ((void)0)
 #define EFX_PROBE_CLAIM_AT(tag, wave, seq, when) ((void)0)
 #define EFX_PROBE_STAMP(i) ((void)0)

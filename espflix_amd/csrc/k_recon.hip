@@ -218,7 +218,7 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
 #if defined(EFX_RECON_ABL) && EFX_RECON_ABL == 2
                                             , const uint32_t (&efx_abl_early)[3]
 #endif
-                                            )
+                                            EFX_PROBE_PARAM)
 {
     int16_t* const cfh = reinterpret_cast<int16_t*>(lds);
     uint16_t* const s_pre = reinterpret_cast<uint16_t*>(lds + 64 * kLaneDwords);  // entries before the block in the wave
@@ -750,12 +750,12 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
         const uint4 rw0 = *reinterpret_cast<const uint4*>(recs + block_at(g0, lane).mb);
         const uint4 rw1 = *reinterpret_cast<const uint4*>(recs + block_at(g1 < kGroupsPerPictureK ? g1 : g0, lane).mb);
         recon_group<0, EFX_RECON_STORE>(lds, coefs, qtab_custom + ((size_t)s * max_pictures + pic) * 64, frames, ring_depth, pic, call_pos[2 * s],
-                                        call_pos[2 * s + 1], epoch, s, g0, rw0, [] {});
+                                        call_pos[2 * s + 1], epoch, s, g0, rw0, [] {} EFX_PROBE_PASS);
         if (g1 < kGroupsPerPictureK) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             recon_group<0, EFX_RECON_STORE>(lds, coefs, qtab_custom + ((size_t)s * max_pictures + pic) * 64, frames, ring_depth, pic, call_pos[2 * s],
-                                            call_pos[2 * s + 1], epoch, s, g1, rw1, [] {});
+                                            call_pos[2 * s + 1], epoch, s, g1, rw1, [] {} EFX_PROBE_PASS);
         }
         return;
     }
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
 #if defined(EFX_RECON_ABL) && EFX_RECON_ABL == 2
                        , efx_abl_early
 #endif
-                       );
+                       EFX_PROBE_PASS);
     EFX_PROBE_STAMP(4);
     EFX_PROBE_CYCLES_END(2);
 }
@@ -973,7 +973,7 @@ __device__ __forceinline__ void recon_all_body(uint32_t* __restrict__ lds, const
 #if defined(EFX_RECON_ABL) && EFX_RECON_ABL == 2
                                                , {0u, 0u, 0u}
 #endif
-                                               );
+                                               EFX_PROBE_PASS_NONE);
         pending_signal = a.s;
 #ifdef EFX_RA_STATS
         {
