@@ -442,6 +442,9 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
         }
     };
     fetch(lane, own, ent);  // (also when the wave has no entry at all: the same three loads in flight on every path)
+#ifdef EFX_PROBE_FINE
+    EFX_PROBE_STAMP(2);  // (fine probe: the owner search is through, the first round's entries are requested)
+#endif
 #if defined(EFX_RECON_ABL) && EFX_RECON_ABL == 2
 #pragma unroll
     for (int k = 0; k < kPerRound; k++)
@@ -495,6 +498,9 @@ __device__ __forceinline__ void recon_group(uint32_t* __restrict__ lds, const ui
         }
     }
 
+#ifdef EFX_PROBE_FINE
+    EFX_PROBE_STAMP_AFTER(6, pr_lo[7]);  // (fine probe: windows arrived, prediction computed -- and, vmcnt(0), the first round's entries are there)
+#endif
     if (total) {
         for (uint32_t i0 = lane;;) {  // (uniform trip count: i0 - lane < total)
             // the next round's owners are searched and its entries requested before this round's are applied
@@ -738,7 +744,9 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
                        (unsigned)(epoch & 0xFF));
     EFX_PROBE_STAMP(1);
     EFX_PROBE_CYCLES_BEGIN();
+#ifndef EFX_PROBE_FINE
     EFX_PROBE_SET(6, (unsigned long long)pic | (unsigned long long)(epoch & 0xFF) << 8 | (unsigned long long)stream0 << 16);
+#endif
     // scan/quantiser table entry: zz | premultiplier << 8 | intra q << 16 | non-intra q << 24
     lds[lane * kLaneDwords + kLaneData] = scan_tab[lane];
 #if defined(EFX_RECON_ITEMS2)
@@ -778,7 +786,9 @@ __global__ __launch_bounds__(64) void k_recon(const MbRec* __restrict__ mbrecs, 
 #endif
                        EFX_PROBE_PASS);
     EFX_PROBE_STAMP(4);
+#ifndef EFX_PROBE_FINE
     EFX_PROBE_CYCLES_END(2);
+#endif
 }
 
 // ---- all pictures of a decode call in ONE launch ----------------------------------------------------------------------------
